@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite
+only ever read the resulting ``*.npz`` files.  The reference is imported unmodified with a
+single-rank ``mpi4py`` stand-in (``_mpi_standin.py``, our code) whose communicator records
+every all-reduce so that the per-rank accumulators -- function locals in the reference --
+can be stored.  No reference source text is copied: fixtures hold inputs and outputs only.
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+
+Fixture families
+  kat_bars.npz            seed-42 bars run of examples/bars-test (F after 3 EM steps, EBSC+ES3C)
+  step_<name>.npz         one or more full ``model.step()`` calls with everything observable
+  lpj_<model>.npz         direct ``log_pseudo_joint`` calls on hand-made states (k = 0 ... dense)
+  vary_kn.npz             ``vary_Kn`` known answers + random cases
+  full_F.npz              ``free_energy(full=True)`` (exact enumeration) on bars data
+"""
+import hashlib
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+import _mpi_standin  # noqa: E402
+
+COMM = _mpi_standin.install()
+
+import evo.models._models as ref_models  # noqa: E402
+import evo.models.sssc as ref_sssc  # noqa: E402
+from evo.models import BSC, SSSC  # noqa: E402
+from evo.variational.eas import evolve_states as ref_evolve  # noqa: E402
+from evo.variational.utils import init_states, vary_Kn  # noqa: E402
+
+
+def pack(bits):
+    """bool (..., H) -> uint8 (..., ceil(H/8)), h=0 in the MSB of byte 0."""
+    return np.packbits(np.asarray(bits, dtype=bool), axis=-1)
+
+
+def bars(H):
+    R = H // 2
+    W = np.zeros((R, R, H))
+    for i in range(R):
+        W[i, :, i] = 1.0
+        W[:, i, R + i] = 1.0
+    return W.reshape(R * R, H)
+
+
+# ---- candidate-batch recorder: wrap the evolve_states symbol the models call -------------
+TRACE = []
+
+
+def _recording_evolve(my_suff_stat, model_params, eval_lpj):
+    out_states, out_lpj = ref_evolve(my_suff_stat, model_params, eval_lpj)
+    TRACE.append((out_states.copy(), out_lpj.copy()))
+    return out_states, out_lpj
+
+
+ref_models.evolve_states = _recording_evolve
+ref_sssc.evolve_states = _recording_evolve
+
+
+def theta_arrays(prefix, theta, keys):
+    return {prefix + k: np.array(theta[k], dtype=np.float64) for k in keys}
+
+
+BSC_KEYS = ("W", "pi", "sigma")
+SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
+BSC_SUMS = ("Wp", "Wq", "pies", "sigma")
+
+
+def run_steps(model, keys, theta, suff, my_data, n_steps, seed0):
+    """Run n_steps reference steps, re-seeding np.random before each so a replay can follow."""
+    out = {}
+    for t in range(n_steps):
+        np.random.seed(seed0 + t)
+        theta = model.check_params(theta)  # step() does it again (idempotent); lets us save Theta-in
+        out.update(theta_arrays("t%d_in_" % t, theta, keys))
+        out["t%d_ss_in" % t] = pack(suff["ss"])
+        TRACE.clear()
+        COMM.log.clear()
+        COMM.recording = True
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+        COMM.recording = False
+        out["t%d_F" % t] = np.float64(F)
+        out["t%d_S_nunique" % t] = np.float64(nu)
+        out["t%d_S_sub" % t] = np.float64(nsub)
+        out["t%d_ss_out" % t] = pack(suff["ss"])
+        out["t%d_lpj_out" % t] = suff["lpj"].copy()
+        out.update(theta_arrays("t%d_out_" % t, theta, keys))
+        # ragged candidate batches
+        counts = np.array([s.shape[0] for s, _ in TRACE], dtype=np.int64)
+        out["t%d_cand_counts" % t] = counts
+        H = suff["ss"].shape[2]
+        out["t%d_cand_states" % t] = pack(np.concatenate([s for s, _ in TRACE], axis=0)) if counts.sum() else np.zeros((0, (H + 7) // 8), np.uint8)
+        out["t%d_cand_lpj" % t] = np.concatenate([l for _, l in TRACE]) if counts.sum() else np.zeros(0)
+        # recorded buffer all-reduces, in call order
+        bufs = [p for kind, p in COMM.log if kind == "Allreduce"]
+        if isinstance(model, BSC):
+            names = ["Wp", "Wq", "pies"]  # bsc.py:230,231,257
+            scal = [float(p) for kind, p in COMM.log if kind == "allreduce" and np.ndim(p) == 0]
+            # scalar order in BSC.step: N (E_step), N (precompute), S_nunique, S_sub, Fs, N (M_step),
+            # 3 reset counters, my_sigma  -> Fs is index 4, my_sigma the last
+            out["t%d_sum_Fs" % t] = np.float64(scal[4])
+            out["t%d_sum_sigma" % t] = np.float64(scal[-1])
+        else:
+            # sssc.py:671-674, 677, 682, 691, 763
+            names = ["xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag"]
+            scal = [float(p) for kind, p in COMM.log if kind == "allreduce" and np.ndim(p) == 0]
+            # scalar order in SSSC.EM_step: N, N(precompute), S_nunique, S_sub, Fs, 4 counters
+            out["t%d_sum_Fs" % t] = np.float64(scal[4])
+        assert len(bufs) == len(names), (len(bufs), names)
+        for nm, b in zip(names, bufs):
+            out["t%d_sum_%s" % (t, nm)] = b
+    return out
+
+
+def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=("fit", "randflip", 10, 1, 1),
+                      bitflip_prob=None, Mprime=None, p_init=None, use_storage=True):
+    np.random.seed(seed)
+    if algo == "ebsc":
+        model = BSC(D, H, S)
+        keys = BSC_KEYS
+    else:
+        model = SSSC(D, H, S, use_storage=use_storage)
+        keys = SSSC_KEYS
+    if data == "bars":
+        gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
+        Y = BSC(D, H, S).generate_data(gen, N)["y"]
+    else:
+        Y = np.random.randn(N, D)
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, ea[0], ea[1], ea[2], ea[3], ea[4], bitflip_prob, Mprime, p_init)
+    out = {
+        "algo": np.array(algo), "D": np.int64(D), "H": np.int64(H), "S": np.int64(S), "N": np.int64(N),
+        "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y": Y,
+        "ea_parent_selection": np.array(ea[0]), "ea_mutation": np.array(ea[1]),
+        "ea_n_parents": np.int64(suff["n_parents"]), "ea_n_children": np.int64(suff["n_children"]),
+        "ea_n_generations": np.int64(suff["n_generations"]),
+        "ea_bitflip_prob": np.float64(np.nan if bitflip_prob is None else bitflip_prob),
+        "ea_Mprime": np.int64(suff["Mprime"]), "use_storage": np.bool_(use_storage),
+    }
+    out.update(run_steps(model, keys, theta, suff, my_data, n_steps, seed0=1000 + seed))
+    path = os.path.join(HERE, "step_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_kat_bars():
+    """BASELINE.md section 2 determinism check: seed 42, H=10, D=25, N=500, S=32, 3 EM steps."""
+    out = {}
+    for algo in ("ebsc", "es3c"):
+        np.random.seed(42)
+        H, D, N, S = 10, 25, 500, 32
+        if algo == "ebsc":
+            model = BSC(D, H, S)
+            gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
+        else:
+            model = SSSC(D, H, S)
+            gen = {"W": 10.0 * bars(H), "pies": np.ones(H) * 2.0 / H, "sigma2": np.array(1.0),
+                   "mus": np.ones(H) * 0.0, "Psi": np.eye(H) * 1.0}
+        Y = model.generate_data(gen, N)["y"]
+        model.check_params(gen)
+        my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+        theta = model.check_params(model.standard_init(my_data))
+        suff = init_states(N, S, H, "fit", "randflip", 10, 1, 1)
+        Fs = []
+        for _ in range(3):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            Fs.append(F)
+        out[algo + "_F"] = np.array(Fs)
+        out[algo + "_ss_sha1"] = np.array(hashlib.sha1(pack(suff["ss"]).tobytes()).hexdigest())
+        out[algo + "_Y_sha1"] = np.array(hashlib.sha1(Y.tobytes()).hexdigest())
+        print(algo, Fs)
+    np.savez_compressed(os.path.join(HERE, "kat_bars.npz"), **out)
+
+
+def learned_like_sssc_theta(D, H, rng):
+    """A Theta that looks like one after a few M-steps: dense NON-symmetric Psi."""
+    A = rng.normal(size=(H, H)) * 0.15
+    Psi = np.eye(H) + A @ A.T * 0.5 + rng.normal(size=(H, H)) * 0.03
+    return {"W": rng.normal(size=(D, H)), "pies": rng.uniform(0.05, 0.4, H), "mus": rng.normal(size=H),
+            "Psi": Psi, "sigma2": np.float64(0.7)}
+
+
+def make_lpj_fixtures():
+    rng = np.random.RandomState(7)
+    # --- BSC
+    D, H, C = 20, 70, 40
+    model = BSC(D, H, C)
+    theta = {"W": rng.normal(size=(D, H)), "pi": 0.07, "sigma": 1.3}
+    states = rng.random_sample((C, H)) < rng.uniform(0, 0.3, size=(C, 1))
+    states[0] = False  # k = 0
+    states[1] = True   # k = H
+    Y = rng.normal(size=(3, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    suff = {}
+    model.E_step_precompute(theta, suff, my_data)
+    lpj = np.zeros((3, C))
+    for n in range(3):
+        my_data["this_y"] = Y[n]
+        my_data["this_x_infr"] = my_data["x_infr"][n]
+        suff["this_states"] = states
+        lpj[n] = model.log_pseudo_joint(theta, suff, my_data)
+    np.savez_compressed(os.path.join(HERE, "lpj_bsc.npz"), W=theta["W"], pi=np.float64(theta["pi"]),
+                        sigma=np.float64(theta["sigma"]), states=pack(states), H=np.int64(H), Y=Y, lpj=lpj,
+                        ljc=np.float64(theta["ljc"]))
+    # --- SSSC, learned-like Theta, k from 0 to 24
+    D, H, C = 24, 70, 48
+    model = SSSC(D, H, C, use_storage=False)
+    theta = learned_like_sssc_theta(D, H, rng)
+    ks = [0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 6, 7, 8, 9, 12, 16, 20, 24] + list(rng.randint(0, 7, size=C - 18))
+    states = np.zeros((C, H), dtype=bool)
+    for c, k in enumerate(ks):
+        states[c, rng.choice(H, size=k, replace=False)] = True
+    Y = rng.normal(size=(3, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    suff = {}
+    model.E_step_precompute(theta, suff, my_data)
+    lpj = np.zeros((3, C))
+    for n in range(3):
+        my_data["this_y"] = Y[n]
+        my_data["this_x_infr"] = my_data["x_infr"][n]
+        suff["this_states"] = states
+        lpj[n] = model.log_pseudo_joint(theta, suff, my_data)
+        suff["storage"] = {"storagekeys": (), "counts_norm": 0, "counts": 0}
+    np.savez_compressed(os.path.join(HERE, "lpj_sssc.npz"), H=np.int64(H), states=pack(states), Y=Y, lpj=lpj,
+                        ljc=np.float64(theta["ljc"]), **theta_arrays("", theta, SSSC_KEYS))
+    # --- clamp behaviour (_models.py:567-596)
+    model = BSC(4, 4, 4)
+    cases = [np.array([1.0, np.nan, -np.inf, np.inf]), np.array([-np.inf, 2.0, -3.0]), np.array([np.inf, 1.0]),
+             np.array([0.5, -0.5])]
+    res = {}
+    for i, c in enumerate(cases):
+        cnt = {"reset_lpj_isnan": 0, "reset_lpj_smaller_eps_lpj": 0, "reset_lpj_isinf": 0}
+        res["in%d" % i] = c.copy()
+        with np.errstate(all="ignore"):
+            res["out%d" % i] = model.lpj_reset_check(c.copy(), cnt)
+        res["cnt%d" % i] = np.array([cnt["reset_lpj_isnan"], cnt["reset_lpj_smaller_eps_lpj"], cnt["reset_lpj_isinf"]])
+    np.savez_compressed(os.path.join(HERE, "lpj_clamp.npz"), **res)
+
+
+def make_vary_kn():
+    out = {}
+    cases = []
+    # SURVEY 8c(i) known answers
+    H, S = 6, 4
+    old = np.eye(H, dtype=bool)[:3]
+    old = np.concatenate((old, np.array([[1, 1, 0, 0, 0, 0]], dtype=bool)))
+    new = np.concatenate((np.eye(H, dtype=bool)[3:], np.eye(H, dtype=bool)[:1]))
+    for Mp in (4, 1):
+        cases.append((H, S, Mp, old.copy(), np.array([-5.0, -1.0, -9.0, -3.0]), new.copy(), np.array([-2.0, -20.0, -0.5, -5.0])))
+    cases.append((H, S, 4, old.copy(), np.array([-5.0, -1.0, -9.0, -3.0]), np.zeros((0, H), dtype=bool), np.zeros(0)))
+    rng = np.random.RandomState(3)
+    for (H, S, C, Mp) in [(9, 6, 5, 6), (70, 12, 10, 12), (70, 12, 10, 3), (130, 40, 30, 40), (33, 8, 20, 8)]:
+        for rep in range(3):
+            o = np.zeros((0, H), dtype=bool)
+            while o.shape[0] < S:
+                o = np.unique(np.concatenate((o, rng.random_sample((S, H)) < 2.0 / H)), axis=0)
+            o = o[rng.permutation(o.shape[0])[:S]]
+            nw = rng.random_sample((C, H)) < 2.0 / H
+            nw[0] = o[1]  # duplicate of an old state
+            if C > 3:
+                nw[3] = nw[2]  # duplicate inside the new batch
+            cases.append((H, S, Mp, o, rng.normal(size=S) * 5, nw, rng.normal(size=C) * 5))
+    out["n_cases"] = np.int64(len(cases))
+    for i, (H, S, Mp, o, lo, nw, ln) in enumerate(cases):
+        states = o.copy()
+        lpj_old = lo.copy()
+        lpj_out = np.zeros(S)
+        a, b = vary_Kn(lpj_old, ln.copy(), lpj_out, states, nw.copy(), H, S, 0, np.zeros((0, H), dtype=bool), Mp)
+        out.update({"c%d_H" % i: np.int64(H), "c%d_S" % i: np.int64(S), "c%d_Mprime" % i: np.int64(Mp),
+                    "c%d_old" % i: pack(o), "c%d_lpj_old" % i: lo, "c%d_new" % i: pack(nw), "c%d_lpj_new" % i: ln,
+                    "c%d_states_out" % i: pack(states), "c%d_lpj_out" % i: lpj_out,
+                    "c%d_ret" % i: np.array([a, b], dtype=np.int64)})
+    np.savez_compressed(os.path.join(HERE, "vary_kn.npz"), **out)
+    print("vary_kn cases:", len(cases))
+
+
+def make_full_F():
+    out = {}
+    for algo in ("ebsc", "es3c"):
+        np.random.seed(11)
+        H, D, N, S = 8, 16, 30, 10
+        if algo == "ebsc":
+            model = BSC(D, H, S)
+            gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
+            keys = BSC_KEYS
+        else:
+            model = SSSC(D, H, S)
+            gen = {"W": 10.0 * bars(H), "pies": np.ones(H) * 2.0 / H, "sigma2": np.array(1.0),
+                   "mus": np.ones(H) * 0.3, "Psi": np.eye(H) * 1.0}
+            keys = SSSC_KEYS
+        Y = model.generate_data(gen, N)["y"]
+        gen = model.check_params(gen)
+        my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+        suff = init_states(N, S, H, "fit", "randflip", 5, 1, 1)
+        L = model.free_energy(my_data, dict(gen), suff, full=True)
+        out[algo + "_Y"] = Y
+        out[algo + "_L"] = np.float64(L)
+        out.update(theta_arrays(algo + "_", gen, keys))
+        print(algo, "L_gen", L)
+    np.savez_compressed(os.path.join(HERE, "full_F.npz"), **out)
+
+
+if __name__ == "__main__":
+    make_kat_bars()
+    make_lpj_fixtures()
+    make_vary_kn()
+    make_full_F()
+    make_step_fixture("ebsc_bars", "ebsc", 25, 10, 8, 24, seed=1, n_steps=3, data="bars", ea=("fit", "randflip", 5, 1, 1))
+    make_step_fixture("es3c_bars", "es3c", 25, 10, 8, 24, seed=2, n_steps=3, data="bars", ea=("fit", "randflip", 5, 1, 1))
+    make_step_fixture("ebsc_mid", "ebsc", 48, 100, 40, 60, seed=3, n_steps=2)
+    make_step_fixture("es3c_mid", "es3c", 24, 72, 30, 40, seed=4, n_steps=2)
+    make_step_fixture("es3c_dense", "es3c", 32, 40, 24, 12, seed=5, n_steps=2, p_init=6.0 / 40, use_storage=False)
+    make_step_fixture("ebsc_dense", "ebsc", 32, 130, 24, 20, seed=6, n_steps=2, p_init=8.0 / 130)
+    make_step_fixture("ebsc_sparseflip", "ebsc", 20, 24, 12, 30, seed=7, n_steps=2, ea=("rand", "sparseflip", 4, 2, 1), bitflip_prob=0.1)
+    make_step_fixture("es3c_cross", "es3c", 20, 24, 12, 30, seed=8, n_steps=2, ea=("fit", "cross_randflip", 4, 1, 1))
+    make_step_fixture("ebsc_gen2", "ebsc", 20, 24, 12, 30, seed=9, n_steps=2, ea=("fit", "randflip", 4, 2, 2), Mprime=5)

@@ -1,0 +1,165 @@
+"""Pins the CPU oracle (oracle/evo_oracle.py) against fixtures generated FROM THE REFERENCE
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_bits
+from oracle import evo_oracle as orc
+
+STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2"]
+BSC_KEYS = ("W", "pi", "sigma")
+SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
+
+
+def suff_from_fixture(g, ss_bool):
+    N, S, H = ss_bool.shape
+    bf = float(g["ea_bitflip_prob"])
+    return {
+        "ss": ss_bool.copy(), "lpj": np.empty((N, S)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool),
+        "permanent": {"background": False, "allzero": False, "singletons": False}, "sm": None,
+        "n_parents": int(g["ea_n_parents"]), "n_children": int(g["ea_n_children"]),
+        "n_generations": int(g["ea_n_generations"]),
+        "parent_selection": orc.PARENT_SELECTION[str(g["ea_parent_selection"])],
+        "mutation_algorithm": orc.MUTATION[str(g["ea_mutation"])],
+        "bitflip_prob": None if np.isnan(bf) else bf, "Mprime": int(g["ea_Mprime"]),
+    }
+
+
+def theta_in(g, t, keys):
+    th = {k: np.array(g["t%d_in_%s" % (t, k)]) for k in keys}
+    for k in ("pi", "sigma", "sigma2"):
+        if k in th:
+            th[k] = np.float64(th[k])
+    return th
+
+
+@pytest.mark.parametrize("name", STEP_FIXTURES)
+def test_step_replay(name):
+    g = load_golden("step_%s.npz" % name)
+    algo = str(g["algo"])
+    H, N, S = int(g["H"]), int(g["N"]), int(g["S"])
+    Y = g["Y"]
+    for t in range(int(g["n_steps"])):
+        keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+        theta = theta_in(g, t, keys)
+        suff = suff_from_fixture(g, unpack_bits(g["t%d_ss_in" % t], H))
+        trace = []
+        np.random.seed(1000 + int(g["seed"]) + t)
+        if algo == "ebsc":
+            F, nu, nsub, theta, sums = orc.bsc_step(theta, suff, Y, trace=trace)
+            sum_names = ("Wp", "Wq", "pies", "sigma", "Fs")
+        else:
+            F, nu, nsub, theta, sums = orc.sssc_step(theta, suff, Y, use_storage=bool(g["use_storage"]), trace=trace)
+            sum_names = ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag", "Fs")
+        # candidate stream: bit-exact states, lpj to rounding
+        counts = np.array([c[1].shape[0] for c in trace])
+        assert np.array_equal(counts, g["t%d_cand_counts" % t])
+        if counts.sum():
+            got = np.concatenate([c[1] for c in trace], axis=0)
+            assert np.array_equal(np.packbits(got, axis=-1), g["t%d_cand_states" % t])
+            np.testing.assert_allclose(np.concatenate([c[2] for c in trace]), g["t%d_cand_lpj" % t], rtol=1e-12)
+        # selection: bit-exact
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t])
+        np.testing.assert_allclose(suff["lpj"], g["t%d_lpj_out" % t], rtol=1e-12)
+        assert nu == float(g["t%d_S_nunique" % t]) and nsub == float(g["t%d_S_sub" % t])
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-13)
+        for nm in sum_names:
+            np.testing.assert_allclose(sums[nm], g["t%d_sum_%s" % (t, nm)], rtol=1e-11, atol=1e-13, err_msg=nm)
+        for k in keys:
+            np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+def test_kat_bars_from_seed():
+    """Whole pipeline (generate -> standard_init -> init_states -> 3 EM steps) from seed 42;
+    numbers also quoted in BASELINE.md section 2."""
+    g = load_golden("kat_bars.npz")
+    H, D, N, S = 10, 25, 500, 32
+    for algo in ("ebsc", "es3c"):
+        np.random.seed(42)
+        W = 10.0 * orc.bars_dictionary(H)
+        if algo == "ebsc":
+            Y, _ = orc.bsc_generate({"W": W, "pi": 2.0 / H, "sigma": 1.0}, N)
+            theta = orc.check_params(orc.bsc_standard_init(Y, H), orc.BSC_POLICY)
+        else:
+            Y, _, _ = orc.sssc_generate({"W": W, "pies": np.ones(H) * 2.0 / H, "sigma2": np.array(1.0),
+                                         "mus": np.zeros(H), "Psi": np.eye(H)}, N)
+            theta = orc.check_params(orc.sssc_standard_init(Y, H), orc.SSSC_POLICY)
+        assert hashlib.sha1(Y.tobytes()).hexdigest() == str(g[algo + "_Y_sha1"])
+        suff = orc.init_states(N, S, H, "fit", "randflip", 10, 1, 1)
+        Fs = []
+        for _ in range(3):
+            if algo == "ebsc":
+                F, _, _, theta, _ = orc.bsc_step(theta, suff, Y)
+            else:
+                F, _, _, theta, _ = orc.sssc_step(theta, suff, Y)
+            Fs.append(F)
+        np.testing.assert_allclose(Fs, g[algo + "_F"], rtol=1e-12)
+        assert hashlib.sha1(np.packbits(suff["ss"], axis=-1).tobytes()).hexdigest() == str(g[algo + "_ss_sha1"])
+    np.testing.assert_allclose(g["ebsc_F"], [-78.7824265109, -76.6595629116, -74.1714405461], rtol=1e-11)
+    np.testing.assert_allclose(g["es3c_F"], [-83.4044473038, -78.1001689500, -73.7140907703], rtol=1e-11)
+
+
+def test_lpj_bsc():
+    g = load_golden("lpj_bsc.npz")
+    H = int(g["H"])
+    theta = {"W": g["W"], "pi": float(g["pi"]), "sigma": float(g["sigma"])}
+    cnt = orc.bsc_precompute(theta, g["Y"].shape[1], H)
+    states = unpack_bits(g["states"], H)
+    for n in range(g["Y"].shape[0]):
+        np.testing.assert_allclose(orc.bsc_lpj(theta, states, g["Y"][n], cnt), g["lpj"][n], rtol=1e-14)
+    np.testing.assert_allclose(theta["ljc"], float(g["ljc"]), rtol=1e-15)
+
+
+def test_lpj_sssc():
+    g = load_golden("lpj_sssc.npz")
+    H = int(g["H"])
+    theta = {k: g[k] for k in SSSC_KEYS}
+    theta["sigma2"] = np.float64(theta["sigma2"])
+    cnt = orc.sssc_precompute(theta, g["Y"].shape[1])
+    states = unpack_bits(g["states"], H)
+    for n in range(g["Y"].shape[0]):
+        np.testing.assert_allclose(orc.sssc_lpj(theta, states, g["Y"][n], cnt, {}), g["lpj"][n], rtol=1e-13)
+    np.testing.assert_allclose(theta["ljc"], float(g["ljc"]), rtol=1e-15)
+
+
+def test_lpj_clamp():
+    g = load_golden("lpj_clamp.npz")
+    for i in range(4):
+        cnt = orc.new_counters()
+        with np.errstate(all="ignore"):
+            out = orc.lpj_clamp(g["in%d" % i].copy(), cnt)
+        assert np.array_equal(out, g["out%d" % i])
+        assert [cnt["isnan"], cnt["smaller_eps"], cnt["isinf"]] == list(g["cnt%d" % i])
+
+
+def test_vary_kn():
+    g = load_golden("vary_kn.npz")
+    for i in range(int(g["n_cases"])):
+        H, S, Mp = int(g["c%d_H" % i]), int(g["c%d_S" % i]), int(g["c%d_Mprime" % i])
+        states = unpack_bits(g["c%d_old" % i], H).copy()
+        new = unpack_bits(g["c%d_new" % i], H).reshape(-1, H)
+        lpj_out = np.zeros(S)
+        ret = orc.vary_Kn(g["c%d_lpj_old" % i].copy(), g["c%d_lpj_new" % i].copy(), lpj_out, states, new, H, S, 0,
+                          np.zeros((0, H), dtype=bool), Mp)
+        assert list(ret) == list(g["c%d_ret" % i])
+        assert np.array_equal(np.packbits(states, axis=-1), g["c%d_states_out" % i])
+        assert np.array_equal(lpj_out, g["c%d_lpj_out" % i])
+    # SURVEY 8c(i) known answers, stated independently of the fixture file
+    assert list(g["c0_ret"]) == [3, 2] and list(g["c0_lpj_out"]) == [-2.0, -1.0, -0.5, -3.0]
+    assert list(g["c1_ret"]) == [3, 1] and list(g["c1_lpj_out"]) == [-5.0, -1.0, -0.5, -3.0]
+    assert list(g["c2_ret"]) == [0, 0]
+
+
+def test_full_free_energy():
+    g = load_golden("full_F.npz")
+    H, S = 8, 10
+    suff = {"sm": orc.all_states_matrix(H)}
+    th = {k: g["ebsc_" + k] for k in BSC_KEYS}
+    th["pi"], th["sigma"] = float(th["pi"]), float(th["sigma"])
+    np.testing.assert_allclose(orc.bsc_free_energy_full(th, suff, g["ebsc_Y"]), float(g["ebsc_L"]), rtol=1e-13)
+    th = {k: g["es3c_" + k] for k in SSSC_KEYS}
+    th["sigma2"] = np.float64(th["sigma2"])
+    np.testing.assert_allclose(orc.sssc_free_energy_full(th, suff, g["es3c_Y"]), float(g["es3c_L"]), rtol=1e-13)
