@@ -1,0 +1,58 @@
+// Shared device helpers for libevo_amd (gfx950 / CDNA4 only; wavefront = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+#define EVO_F64_MIN (-1.7976931348623157e308)  // np.finfo(float64).min == eps_lpj (bsc.py:23)
+#define EVO_F64_TINY (2.2250738585072014e-308) // np.finfo(float64).tiny == eps_pjc_sum (sssc.py:36)
+#define EVO_WAVE 64
+
+// clamp flag bits (per datapoint, per lpj call): _models.py:581-594
+#define EVO_FLAG_NAN 1u
+#define EVO_FLAG_NEGINF 2u
+#define EVO_FLAG_POSINF 4u
+
+__device__ __forceinline__ int wave_id_uniform() {
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Model.lpj_reset_check (_models.py:567-596): NaN -> finfo.min; -inf -> finfo.min -> (is inf) 0.0;
+// +inf -> 0.0.  Returns the clamped value and ORs the case into *flags.
+__device__ __forceinline__ double clamp_lpj(double v, unsigned &flags) {
+  if (v != v) {
+    flags |= EVO_FLAG_NAN;
+    return EVO_F64_MIN;
+  }
+  if (isinf(v)) {
+    flags |= (v < 0.0) ? EVO_FLAG_NEGINF : EVO_FLAG_POSINF;
+    return 0.0;  // B_max
+  }
+  return v;
+}
+
+// MSB-first bit helpers: latent h <-> word h>>6, bit 63-(h&63).
+__device__ __forceinline__ int pop_msb(u64 &bits) {
+  int b = __clzll((long long)bits);
+  bits &= ~(0x8000000000000000ull >> b);
+  return b;
+}

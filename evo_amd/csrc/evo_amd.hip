@@ -1,0 +1,1052 @@
+// libevo_amd.so -- C ABI (include/evo_amd.h) over the gfx950 kernels.
+// Host side of the library: context, device memory, launch geometry, RCCL, timing.
+#include "../../include/evo_amd.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "gemm_f64.hpp"
+#include "kernels_bsc.hpp"
+#include "kernels_common.hpp"
+#include "kernels_evolve.hpp"
+#include "kernels_sssc.hpp"
+
+// ---------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(EVOAMD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                   \
+  } while (0)
+
+#define REQUIRE(cond, msg)                                   \
+  do {                                                       \
+    if (!(cond)) return fail(EVOAMD_E_INVALID, "%s", msg);   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// RCCL through dlopen (so the library loads on hosts without librccl)
+// ---------------------------------------------------------------------------------------
+struct RcclId {
+  char internal[128];
+};
+struct RcclApi {
+  void *handle = nullptr;
+  int (*GetUniqueId)(RcclId *) = nullptr;
+  int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+  if (g_rccl.handle) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) return fail(EVOAMD_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+  g_rccl.GetUniqueId = (int (*)(RcclId *))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void **, int, RcclId, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllReduce =
+      (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail(EVOAMD_E_RCCL, "librccl is missing a required symbol");
+  g_rccl.handle = h;
+  return 0;
+}
+#define RCCL_TRY(expr)                                                                         \
+  do {                                                                                         \
+    int _r = (expr);                                                                           \
+    if (_r != 0)                                                                               \
+      return fail(EVOAMD_E_RCCL, "%s failed: %s", #expr,                                       \
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+enum {  // internal kernel ids (see evoamd_kernel_name)
+  KID_LPJ_RES = 0,
+  KID_LPJ_CAND,
+  KID_LPJ_OVF,
+  KID_ROW_LSE,
+  KID_VARY_KN,
+  KID_STATS,
+  KID_STATS_OVF,
+  KID_GEMM,
+  KID_EVOLVE,
+  KID_MISC,
+  KID_COUNT
+};
+
+struct TimedSpan {
+  hipEvent_t a, b;
+  int kid;
+};
+
+struct evoamd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool configured = false, have_data = false, have_params = false, have_cand = false;
+  int model = 0;
+  i64 N = 0;
+  int D = 0, H = 0, S = 0, S_perm = 0, Cmax = 0, HW = 0, L = 0;
+  // data
+  double *Y = nullptr, *yy = nullptr, *y2sum = nullptr;
+  // variational state
+  u64 *states = nullptr, *cand = nullptr;
+  double *lpj = nullptr, *cand_lpj = nullptr;
+  int *cand_counts = nullptr;
+  unsigned *flags = nullptr;  // 3 x N: resident | candidates | permanent
+  double *rowmax = nullptr, *rowsum = nullptr, *partial = nullptr;
+  i64 n_partial = 0;
+  uint8_t *stage = nullptr;  // bool staging for (N, max(S,Cmax), H)
+  size_t stage_bytes = 0;
+  // parameters
+  double *W = nullptr, *Wt = nullptr, *G = nullptr, *Psi = nullptr, *Bm = nullptr, *mus = nullptr,
+         *pilbar_v = nullptr;
+  double2 *GP = nullptr;
+  double pre1 = 0, pil_bar = 0, s2inv = 0, ljc = 0;
+  // statistics
+  double *acc = nullptr;
+  i64 acc_n = 0;
+  double *Es = nullptr, *Ez = nullptr;
+  int *list1 = nullptr, *list2 = nullptr, *list_n = nullptr, *err = nullptr;
+  // scratch for single / shared evaluations
+  double *tmp_y = nullptr, *tmp_lpj = nullptr;
+  u64 *tmp_states = nullptr;
+  size_t tmp_states_words = 0, tmp_lpj_n = 0;
+  // rccl
+  void *comm = nullptr;
+  int rank = 0, world = 1;
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> pool;
+  double t_ms[KID_COUNT] = {0};
+  i64 t_n[KID_COUNT] = {0};
+};
+
+struct SpanGuard {
+  evoamd_ctx *c;
+  int kid;
+  hipEvent_t a = nullptr, b = nullptr;
+  SpanGuard(evoamd_ctx *ctx, int k) : c(ctx), kid(k) {
+    if (!c->timing) return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!c->pool.empty()) {
+        e = c->pool.back();
+        c->pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~SpanGuard() {
+    if (!c->timing || !a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->spans.push_back({a, b, kid});
+  }
+};
+
+static int resolve_spans(evoamd_ctx *c) {
+  for (auto &s : c->spans) {
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(s.b));
+    HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+    c->t_ms[s.kid] += ms;
+    c->t_n[s.kid] += 1;
+    c->pool.push_back(s.a);
+    c->pool.push_back(s.b);
+  }
+  c->spans.clear();
+  return 0;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t n) {
+  if (*p) {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (n == 0) n = 1;
+  HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+  return 0;
+}
+#define ALLOC(p, n)                 \
+  do {                              \
+    int _r = dev_alloc(&(p), (n));  \
+    if (_r) return _r;              \
+  } while (0)
+
+static inline unsigned cdiv(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// library / context
+// ---------------------------------------------------------------------------------------
+extern "C" int evoamd_abi_version(void) { return EVOAMD_ABI_VERSION; }
+extern "C" const char *evoamd_last_error(void) { return g_err; }
+
+extern "C" int evoamd_device_count(int *count) {
+  REQUIRE(count, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(EVOAMD_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
+  REQUIRE(out, "out is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(EVOAMD_E_NODEVICE, "no HIP device visible (libevo_amd needs an MI355X / gfx950 GPU)");
+  REQUIRE(device >= 0 && device < n, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(EVOAMD_E_NODEVICE, "device %d is %s; libevo_amd is built for gfx950 only", device,
+                prop.gcnArchName);
+  evoamd_ctx *c = new evoamd_ctx();
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              96 * 1024));
+  *out = c;
+  return 0;
+}
+
+static void free_all(evoamd_ctx *c) {
+  void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
+                  c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->stage,    c->W,
+                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
+                  c->acc,    c->Es,     c->Ez,      c->list1,   c->list2,    c->list_n,    c->err,
+                  c->tmp_y,  c->tmp_lpj, c->tmp_states};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+}
+
+extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  for (auto &s : c->spans) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  free_all(c);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int evoamd_synchronize(evoamd_ctx *c) {
+  REQUIRE(c, "ctx is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------
+static i64 acc_len(const evoamd_ctx *c) {
+  const i64 H = c->H, D = c->D;
+  return (c->model == EVOAMD_MODEL_BSC) ? H * D + H * H + H + 1 + 8 : 2 * H + 4 * H * H + D * H + D + 8;
+}
+// offsets into the packed accumulator
+struct AccLayout {
+  i64 Wp, Wq, pies, sigma;                                              // BSC
+  i64 xs, xss, xsz, xszsz, s_sz, sz_sz, sWp, y2;                        // SSSC
+  i64 tail;
+};
+static AccLayout acc_layout(const evoamd_ctx *c) {
+  AccLayout a = {};
+  const i64 H = c->H, D = c->D;
+  if (c->model == EVOAMD_MODEL_BSC) {
+    a.Wp = 0;
+    a.Wq = H * D;
+    a.pies = a.Wq + H * H;
+    a.sigma = a.pies + H;
+    a.tail = a.sigma + 1;
+  } else {
+    a.xs = 0;
+    a.xss = H;
+    a.xsz = a.xss + H * H;
+    a.xszsz = a.xsz + H;
+    a.s_sz = a.xszsz + H * H;
+    a.sz_sz = a.s_sz + H * H;
+    a.sWp = a.sz_sz + H * H;
+    a.y2 = a.sWp + D * H;
+    a.tail = a.y2 + D;
+  }
+  return a;
+}
+
+extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int H, int S, int S_perm,
+                                int Cmax) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(model == EVOAMD_MODEL_BSC || model == EVOAMD_MODEL_SSSC, "unknown model");
+  REQUIRE(N > 0 && D > 0 && H > 0 && S > 0, "N, D, H, S must be positive");
+  REQUIRE(S_perm == 0 || S_perm == 1, "S_perm must be 0 or 1");
+  REQUIRE(Cmax >= 1 && Cmax <= 64 * VK_MAX_C_PER_LANE, "Cmax must be in [1, 256]");
+  REQUIRE(S <= 64 * VK_MAX_S_PER_LANE, "S must be <= 1024");
+  REQUIRE((i64)N * (S > Cmax ? S : Cmax) < 2147483647LL, "N * max(S, Cmax) must fit in int32");
+  HIP_TRY(hipSetDevice(c->device));
+  c->model = model;
+  c->N = N;
+  c->D = D;
+  c->H = H;
+  c->S = S;
+  c->S_perm = S_perm;
+  c->Cmax = Cmax;
+  c->HW = (H + 63) / 64;
+  c->L = S + S_perm;
+  const i64 HW = c->HW;
+  ALLOC(c->Y, (size_t)N * D);
+  ALLOC(c->yy, (size_t)N);
+  ALLOC(c->y2sum, (size_t)D);
+  ALLOC(c->states, (size_t)N * S * HW);
+  ALLOC(c->cand, (size_t)N * Cmax * HW);
+  ALLOC(c->lpj, (size_t)N * c->L);
+  ALLOC(c->cand_lpj, (size_t)N * Cmax);
+  ALLOC(c->cand_counts, (size_t)N);
+  ALLOC(c->flags, (size_t)3 * N);
+  ALLOC(c->rowmax, (size_t)N);
+  ALLOC(c->rowsum, (size_t)N);
+  c->n_partial = cdiv(N, 4);
+  ALLOC(c->partial, (size_t)c->n_partial);
+  const int SC = S > Cmax ? S : Cmax;
+  c->stage_bytes = (size_t)N * SC * H;
+  ALLOC(c->stage, c->stage_bytes);
+  ALLOC(c->W, (size_t)D * H);
+  ALLOC(c->Es, (size_t)N * H);
+  c->acc_n = acc_len(c);
+  ALLOC(c->acc, (size_t)c->acc_n);
+  ALLOC(c->err, 4);
+  if (model == EVOAMD_MODEL_BSC) {
+    ALLOC(c->Wt, (size_t)H * D);
+  } else {
+    ALLOC(c->G, (size_t)H * H);
+    ALLOC(c->Psi, (size_t)H * H);
+    ALLOC(c->GP, (size_t)H * H);
+    ALLOC(c->Bm, (size_t)N * H);
+    ALLOC(c->mus, (size_t)H);
+    ALLOC(c->pilbar_v, (size_t)H);
+    ALLOC(c->Ez, (size_t)N * H);
+    ALLOC(c->list1, (size_t)N * SC);
+    ALLOC(c->list2, (size_t)N * SC);
+    ALLOC(c->list_n, 4);
+  }
+  HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
+  HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->configured = true;
+  c->have_data = c->have_params = c->have_cand = false;
+  return 0;
+}
+
+extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(Y, "Y is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->Y, Y, (size_t)c->N * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  row_sqnorm_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->Y, c->N, c->D, c->yy);
+  HIP_TRY(hipMemsetAsync(c->y2sum, 0, (size_t)c->D * sizeof(double), c->stream));
+  {
+    const i64 rpb = 2048;
+    dim3 grid(cdiv(c->D, 256), cdiv(c->N, rpb));
+    colsum_f64<true><<<grid, 256, 0, c->stream>>>(c->Y, c->D, c->N, c->D, rpb, c->y2sum);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_data = true;
+  return 0;
+}
+
+static int pack_to_device(evoamd_ctx *c, const uint8_t *host_bool, i64 nstates, u64 *dst) {
+  const size_t bytes = (size_t)nstates * c->H;
+  if (bytes > c->stage_bytes) return fail(EVOAMD_E_INVALID, "state batch larger than staging buffer");
+  HIP_TRY(hipMemcpyAsync(c->stage, host_bool, bytes, hipMemcpyHostToDevice, c->stream));
+  pack_states_kernel<<<cdiv(nstates * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, nstates, c->H, c->HW);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int evoamd_upload_states(evoamd_ctx *c, const uint8_t *ss_bool) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(ss_bool, "ss is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = pack_to_device(c, ss_bool, c->N * (i64)c->S, c->states);
+  if (r) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_download_states(evoamd_ctx *c, uint8_t *ss_bool) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(ss_bool, "ss is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  const i64 ns = c->N * (i64)c->S;
+  unpack_states_kernel<<<cdiv(ns * c->H, 256), 256, 0, c->stream>>>(c->states, c->stage, ns, c->H, c->HW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ss_bool, c->stage, (size_t)ns * c->H, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_upload_lpj(evoamd_ctx *c, const double *lpj) {
+  REQUIRE(c && c->configured, "configure first");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->lpj, lpj, (size_t)c->N * c->L * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_download_lpj(evoamd_ctx *c, double *lpj) {
+  REQUIRE(c && c->configured, "configure first");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(lpj, c->lpj, (size_t)c->N * c->L * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense helpers
+// ---------------------------------------------------------------------------------------
+// C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
+static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                          int M, int Nc, i64 K) {
+  const unsigned gx = cdiv(Nc, GEMM_BN), gy = cdiv(M, GEMM_BM);
+  i64 splits = 1;
+  const i64 tiles = (i64)gx * gy;
+  if (K > 4096) {
+    splits = (1024 + tiles - 1) / tiles;  // aim for ~1024 workgroups
+    const i64 maxs = (K + 511) / 512;     // at least 512 rows per split
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  i64 kps = (K + splits - 1) / splits;
+  kps = ((kps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+  splits = (K + kps - 1) / kps;
+  if (splits > 1) HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
+  SpanGuard g(c, KID_GEMM);
+  gemm_tn_f64<<<dim3(gx, gy, (unsigned)splits), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_gemm_nn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                          i64 M, int Nc, int K) {
+  SpanGuard g(c, KID_GEMM);
+  gemm_nn_f64<<<dim3(cdiv(Nc, GEMM_BN), cdiv(M, GEMM_BM)), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------
+extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, double sigma, double *ljc) {
+  REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC, "context is not configured for BSC");
+  REQUIRE(W, "W is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  // bsc.py:111-121 (complete data)
+  c->pre1 = -1.0 / 2.0 / sigma / sigma;
+  c->pil_bar = log(pi / (1.0 - pi));
+  c->ljc = c->H * log(1.0 - pi) - c->D / 2.0 * log(2 * M_PI * sigma * sigma);
+  if (ljc) *ljc = c->ljc;
+  // W^T on the host (H x D); tiny
+  std::vector<double> wt((size_t)c->H * c->D);
+  for (int d = 0; d < c->D; d++)
+    for (int h = 0; h < c->H; h++) wt[(size_t)h * c->D + d] = W[(size_t)d * c->H + h];
+  HIP_TRY(hipMemcpyAsync(c->W, W, (size_t)c->D * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->Wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_params = true;
+  return 0;
+}
+
+extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const double *pies, const double *mus,
+                                      const double *Psi, double sigma2, double *ljc) {
+  REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_SSSC, "context is not configured for SSSC");
+  REQUIRE(W && pies && mus && Psi, "NULL parameter array");
+  REQUIRE(c->have_data, "upload_data before set_params_sssc (B = Y W is part of the precompute)");
+  HIP_TRY(hipSetDevice(c->device));
+  const int H = c->H, D = c->D;
+  // sssc.py:340-353: sigma2 through long double, rounded back to double
+  const long double s2 = (long double)sigma2;
+  c->s2inv = (double)(1.0L / s2);
+  double l = 0.0;
+  std::vector<double> pb(H);
+  {
+    // np.log(1.0 - pies).sum(): NumPy's pairwise summation differs from a left-to-right loop by
+    // rounding only (|ljc| ~ H * 0.4); keep a compensated sum to stay below 1 ulp of the result
+    long double acc = 0.0L;
+    for (int h = 0; h < H; h++) {
+      acc += (long double)log(1.0 - pies[h]);
+      pb[h] = log(pies[h] / (1.0 - pies[h]));
+    }
+    l = (double)acc;
+  }
+  l -= D / 2.0 * log(2 * M_PI);
+  l -= 0.5 * (D * (double)logl(s2));
+  c->ljc = l;
+  if (ljc) *ljc = l;
+  HIP_TRY(hipMemcpyAsync(c->W, W, (size_t)D * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mus, mus, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->pilbar_v, pb.data(), (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->Psi, Psi, (size_t)H * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // pb is a host temporary
+  int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
+  if (r) return r;
+  interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP);
+  HIP_TRY(hipGetLastError());
+  r = launch_gemm_nn(c, c->Y, D, c->W, H, c->Bm, H, c->N, H, D);  // B = Y W
+  if (r) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_params = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// lpj launches
+// ---------------------------------------------------------------------------------------
+struct Batch {
+  const u64 *states;
+  const int *counts;
+  const double *Y;   // BSC: datapoints (N rows)
+  const double *Bm;  // SSSC
+  const double *yy;
+  i64 N;
+  int C, shared;
+  double *out;
+  int ldo, col0;
+  unsigned *flags;
+  int kid;
+};
+
+static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
+  const int nchunk = (b.C + BSC_CHUNK - 1) / BSC_CHUNK;
+  const unsigned grid = cdiv(b.N * nchunk, 4);
+  SpanGuard g(c, b.kid);
+#define BSC_LAUNCH(R)                                                                                     \
+  bsc_lpj_kernel<R><<<grid, 256, 0, c->stream>>>(b.Y, c->Wt, b.states, b.counts, b.N, b.C, b.C, b.shared, \
+                                                  c->D, c->HW, c->pre1, c->pil_bar, b.out, b.ldo, b.col0, b.flags)
+  if (c->D <= 64)
+    BSC_LAUNCH(1);
+  else if (c->D <= 128)
+    BSC_LAUNCH(2);
+  else
+    BSC_LAUNCH(4);
+#undef BSC_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
+  SsscArgs a = {};
+  a.states = b.states;
+  a.counts = b.counts;
+  a.Bm = b.Bm;
+  a.yy = b.yy;
+  a.GP = c->GP;
+  a.mus = c->mus;
+  a.pil_bar = c->pilbar_v;
+  a.s2inv = c->s2inv;
+  a.N = b.N;
+  a.C = b.C;
+  a.shared = b.shared;
+  a.H = c->H;
+  a.HW = c->HW;
+  a.lpj_out = b.out;
+  a.ldo = b.ldo;
+  a.col0 = b.col0;
+  a.flags = b.flags;
+  a.err = c->err;
+  return a;
+}
+
+static const size_t SSSC_BIG_LDS = (size_t)(2 * SSSC_KCAP * SSSC_KCAP + 5 * SSSC_KCAP) * sizeof(double) +
+                                   SSSC_KCAP * sizeof(int);
+
+template <int MODE>
+static int launch_sssc(evoamd_ctx *c, const SsscArgs &a, int kid_main, int kid_ovf) {
+  const i64 total = a.N * (i64)a.C;
+  HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * sizeof(int), c->stream));
+  {
+    SpanGuard g(c, kid_main);
+    unsigned grid = cdiv(total, 256);
+    sssc_small_kernel<4, MODE><<<grid, 256, 0, c->stream>>>(a, nullptr, nullptr, c->list1, c->list_n + 0);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    SpanGuard g(c, kid_ovf);
+    unsigned grid = cdiv(total, 256);
+    if (grid > 1024) grid = 1024;
+    sssc_small_kernel<8, MODE><<<grid, 256, 0, c->stream>>>(a, c->list1, c->list_n + 0, c->list2, c->list_n + 1);
+    HIP_TRY(hipGetLastError());
+    unsigned gridb = (unsigned)(total < 2048 ? total : 2048);
+    sssc_big_kernel<MODE><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, c->list2, c->list_n + 1);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+static int launch_lpj(evoamd_ctx *c, const Batch &b) {
+  if (c->model == EVOAMD_MODEL_BSC) return launch_bsc_lpj(c, b);
+  SsscArgs a = sssc_args(c, b);
+  return launch_sssc<0>(c, a, b.kid, KID_LPJ_OVF);
+}
+
+static int check_err(evoamd_ctx *c) {
+  int e[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(e, c->err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (e[0]) {
+    HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
+    if (e[0] & 1) return fail(EVOAMD_E_KLIMIT, "ES3C: a state has more than %d active latents", SSSC_KCAP);
+    return fail(EVOAMD_E_SINGULAR, "ES3C: exactly singular k x k system (the reference takes pinv here)");
+  }
+  return 0;
+}
+
+extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
+  if (c->S_perm) {
+    const double pre = (c->model == EVOAMD_MODEL_BSC) ? c->pre1 : -0.5 * c->s2inv;
+    allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, pre, c->lpj, c->L, c->flags + 2 * c->N);
+    HIP_TRY(hipGetLastError());
+  }
+  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES};
+  int r = launch_lpj(c, b);
+  if (r) return r;
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int eval_candidates(evoamd_ctx *c) {
+  Batch b = {c->cand, c->cand_counts, c->Y, c->Bm, c->yy, c->N, c->Cmax, 0, c->cand_lpj, c->Cmax, 0,
+             c->flags + c->N, KID_LPJ_CAND};
+  return launch_lpj(c, b);
+}
+
+extern "C" int evoamd_lpj_candidates(evoamd_ctx *c, const uint8_t *cand_bool, const int32_t *counts, int Cmax,
+                                     double *lpj_out) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(cand_bool && counts, "NULL candidate batch");
+  REQUIRE(Cmax == c->Cmax, "Cmax differs from the configured value");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = pack_to_device(c, cand_bool, c->N * (i64)Cmax, c->cand);
+  if (r) return r;
+  HIP_TRY(hipMemcpyAsync(c->cand_counts, counts, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  r = eval_candidates(c);
+  if (r) return r;
+  if (lpj_out)
+    HIP_TRY(hipMemcpyAsync(lpj_out, c->cand_lpj, (size_t)c->N * Cmax * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+  c->have_cand = true;
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_set_candidates(evoamd_ctx *c, const uint8_t *cand_bool, const int32_t *counts, int Cmax,
+                                     const double *lpj) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(cand_bool && counts && lpj, "NULL argument");
+  REQUIRE(Cmax == c->Cmax, "Cmax differs from the configured value");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = pack_to_device(c, cand_bool, c->N * (i64)Cmax, c->cand);
+  if (r) return r;
+  HIP_TRY(hipMemcpyAsync(c->cand_counts, counts, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->cand_lpj, lpj, (size_t)c->N * Cmax * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->have_cand = true;
+  return 0;
+}
+
+static int ensure_tmp(evoamd_ctx *c, size_t state_words, size_t lpj_n) {
+  if (state_words > c->tmp_states_words) {
+    ALLOC(c->tmp_states, state_words);
+    c->tmp_states_words = state_words;
+  }
+  if (lpj_n > c->tmp_lpj_n) {
+    ALLOC(c->tmp_lpj, lpj_n);
+    c->tmp_lpj_n = lpj_n;
+  }
+  return 0;
+}
+
+extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int C, double *lpj_out) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(states_bool && lpj_out && C > 0, "bad arguments");
+  REQUIRE((i64)c->N * C < 2147483647LL, "N * C must fit in int32");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)c->N * C);
+  if (r) return r;
+  // stage through a private buffer (C*H may exceed the configured staging area)
+  uint8_t *st = nullptr;
+  HIP_TRY(hipMalloc((void **)&st, (size_t)C * c->H));
+  HIP_TRY(hipMemcpyAsync(st, states_bool, (size_t)C * c->H, hipMemcpyHostToDevice, c->stream));
+  pack_states_kernel<<<cdiv((i64)C * c->HW, 256), 256, 0, c->stream>>>(st, c->tmp_states, C, c->H, c->HW);
+  int *lists = nullptr;
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    // overflow lists sized for this batch
+    HIP_TRY(hipMalloc((void **)&lists, (size_t)2 * c->N * C * sizeof(int)));
+  }
+  int *l1 = c->list1, *l2 = c->list2;
+  if (lists) {
+    c->list1 = lists;
+    c->list2 = lists + (size_t)c->N * C;
+  }
+  Batch b = {c->tmp_states, nullptr, c->Y, c->Bm, c->yy, c->N, C, 1, c->tmp_lpj, C, 0, c->flags + c->N, KID_MISC};
+  r = launch_lpj(c, b);
+  c->list1 = l1;
+  c->list2 = l2;
+  if (!r) {
+    hipError_t e = hipMemcpyAsync(lpj_out, c->tmp_lpj, (size_t)c->N * C * sizeof(double), hipMemcpyDeviceToHost,
+                                  c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) r = fail(EVOAMD_E_HIP, "lpj_shared copy back: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(st);
+  if (lists) (void)hipFree(lists);
+  if (r) return r;
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  return 0;
+}
+
+extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *states_bool, int C,
+                                 double *lpj_out, int32_t *flags_out) {
+  REQUIRE(c && c->configured && c->have_params, "configure and set_params first");
+  REQUIRE(y && states_bool && lpj_out && C > 0, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)C + 2);
+  if (r) return r;
+  if (!c->tmp_y) ALLOC(c->tmp_y, (size_t)c->D + c->H + 2);
+  if ((size_t)C * c->H > c->stage_bytes) return fail(EVOAMD_E_INVALID, "too many states for lpj_single");
+  double *dy = c->tmp_y, *db = c->tmp_y + c->D, *dyy = c->tmp_y + c->D + c->H;
+  unsigned *dfl = (unsigned *)(c->tmp_lpj + C);
+  HIP_TRY(hipMemcpyAsync(dy, y, (size_t)c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->stage, states_bool, (size_t)C * c->H, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(dfl, 0, sizeof(unsigned), c->stream));
+  pack_states_kernel<<<cdiv((i64)C * c->HW, 256), 256, 0, c->stream>>>(c->stage, c->tmp_states, C, c->H, c->HW);
+  row_sqnorm_kernel<<<1, 256, 0, c->stream>>>(dy, 1, c->D, dyy);
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    r = launch_gemm_nn(c, dy, c->D, c->W, c->H, db, c->H, 1, c->H, c->D);
+    if (r) return r;
+  }
+  Batch b = {c->tmp_states, nullptr, dy, db, dyy, 1, C, 1, c->tmp_lpj, C, 0, dfl, KID_MISC};
+  r = launch_lpj(c, b);
+  if (r) return r;
+  unsigned fl = 0;
+  HIP_TRY(hipMemcpyAsync(lpj_out, c->tmp_lpj, (size_t)C * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&fl, dfl, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (flags_out) {
+    flags_out[0] = (fl & EVO_FLAG_NAN) ? 1 : 0;
+    flags_out[1] = (fl & EVO_FLAG_NEGINF) ? 1 : 0;
+    flags_out[2] = (fl & (EVO_FLAG_NEGINF | EVO_FLAG_POSINF)) ? 1 : 0;
+  }
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// selection
+// ---------------------------------------------------------------------------------------
+extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
+  REQUIRE(c && c->configured && c->have_cand, "no resident candidate batch (call lpj_candidates / evolve first)");
+  REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
+  HIP_TRY(hipSetDevice(c->device));
+  const AccLayout a = acc_layout(c);
+  {
+    SpanGuard g(c, KID_VARY_KN);
+    vary_kn_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->cand, c->cand_lpj, c->cand_counts,
+                                                         c->N, c->S, c->S_perm, c->HW, c->Cmax, Mprime,
+                                                         c->acc + a.tail + 1);
+    HIP_TRY(hipGetLastError());
+  }
+  if (sums_out) {
+    HIP_TRY(hipMemcpyAsync(sums_out, c->acc + a.tail + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+extern "C" int evoamd_set_estep_counts(evoamd_ctx *c, double sum_nunique, double sum_sub) {
+  REQUIRE(c && c->configured, "configure first");
+  HIP_TRY(hipSetDevice(c->device));
+  const AccLayout a = acc_layout(c);
+  double v[2] = {sum_nunique, sum_sub};
+  HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 1, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_children, uint64_t seed, int fit_parents) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(n_parents >= 1 && n_parents <= c->S && n_parents <= 64, "n_parents must be in [1, min(S, 64)]");
+  REQUIRE(n_children >= 1 && n_children <= EV_MAX_CHILDREN && n_children <= c->H, "n_children must be in [1, min(8, H)]");
+  REQUIRE(n_parents * n_children <= c->Cmax, "n_parents * n_children exceeds the configured Cmax");
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    SpanGuard g(c, KID_EVOLVE);
+    evolve_randflip_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H,
+                                                                 c->HW, n_parents, n_children, c->Cmax, seed,
+                                                                 fit_parents, c->cand, c->cand_counts);
+    HIP_TRY(hipGetLastError());
+  }
+  int r = eval_candidates(c);
+  if (r) return r;
+  c->have_cand = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// statistics
+// ---------------------------------------------------------------------------------------
+extern "C" int64_t evoamd_acc_size(evoamd_ctx *c) { return (c && c->configured) ? c->acc_n : -1; }
+
+static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowmax, double *rowsum, double *out_slot) {
+  const unsigned nb = cdiv(N, 4);
+  if ((i64)nb > c->n_partial) {
+    ALLOC(c->partial, (size_t)nb);
+    c->n_partial = nb;
+  }
+  SpanGuard g(c, KID_ROW_LSE);
+  row_lse_kernel<<<nb, 256, 0, c->stream>>>(lpj, N, L, rowmax, rowsum, c->partial);
+  reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, nb, out_slot, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(acc_out, "acc_out is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  const AccLayout a = acc_layout(c);
+  const i64 N = c->N;
+  const int H = c->H, D = c->D;
+  // keep tail[1..2] (E-step counts written by vary_kn / set_estep_counts); zero everything else
+  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)(a.tail + 1) * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 3, 0, 5 * sizeof(double), c->stream));
+  int r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
+  if (r) return r;
+  if (c->model == EVOAMD_MODEL_BSC) {
+    {
+      SpanGuard g(c, KID_STATS);
+      bsc_stats_kernel<<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(
+          c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->pre1, c->pil_bar, c->Es,
+          c->acc + a.Wq, c->partial);
+      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.sigma, 0);
+      const i64 rpb = 1024;
+      colsum_f64<false><<<dim3(cdiv(H, 256), cdiv(N, rpb)), 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->acc + a.pies);
+      HIP_TRY(hipGetLastError());
+    }
+    r = launch_gemm_tn(c, c->Es, H, c->Y, D, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
+    if (r) return r;
+  } else {
+    HIP_TRY(hipMemsetAsync(c->Es, 0, (size_t)N * H * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->Ez, 0, (size_t)N * H * sizeof(double), c->stream));
+    Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS};
+    SsscArgs sa = sssc_args(c, b);
+    sa.lpj_in = c->lpj;
+    sa.rowmax = c->rowmax;
+    sa.rowsum = c->rowsum;
+    sa.Es = c->Es;
+    sa.Ez = c->Ez;
+    sa.xss = c->acc + a.xss;
+    sa.xszsz = c->acc + a.xszsz;
+    r = launch_sssc<1>(c, sa, KID_STATS, KID_STATS_OVF);
+    if (r) return r;
+    {
+      SpanGuard g(c, KID_MISC);
+      const i64 rpb = 1024;
+      dim3 grid(cdiv(H, 256), cdiv(N, rpb));
+      colsum_f64<false><<<grid, 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->acc + a.xs);
+      colsum_f64<false><<<grid, 256, 0, c->stream>>>(c->Ez, H, N, H, rpb, c->acc + a.xsz);
+      HIP_TRY(hipMemcpyAsync(c->acc + a.y2, c->y2sum, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(hipGetLastError());
+    }
+    r = launch_gemm_tn(c, c->Y, D, c->Ez, H, c->acc + a.sWp, H, D, H, N);  // Wp = Y^T Ez (D,H)
+    if (r) return r;
+    r = launch_gemm_tn(c, c->Es, H, c->Ez, H, c->acc + a.s_sz, H, H, H, N);  // sum_n xpt_s (x) xpt_sz
+    if (r) return r;
+    r = launch_gemm_tn(c, c->Ez, H, c->Ez, H, c->acc + a.sz_sz, H, H, H, N);  // sum_n xpt_sz (x) xpt_sz
+    if (r) return r;
+  }
+  // tail: N and the reset counters (per-call priority semantics)
+  {
+    const double nval = (double)N;
+    HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 3, &nval, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 3; k++)
+      count_flags_kernel<<<64, 256, 0, c->stream>>>(c->flags + (size_t)k * N, N, c->acc + a.tail + 4);
+    HIP_TRY(hipGetLastError());
+  }
+  if (c->comm) {
+    RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(acc_out, c->acc, (size_t)c->acc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // the E-step counts have been consumed
+  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_free_energy(evoamd_ctx *c, const double *lpj, int64_t N, int C, double *Fs_out) {
+  REQUIRE(c && lpj && Fs_out && N > 0 && C > 0, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  double *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, ((size_t)N * C + 1) * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d, lpj, (size_t)N * C * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  int r = 0;
+  if (e != hipSuccess) r = fail(EVOAMD_E_HIP, "free_energy upload: %s", hipGetErrorString(e));
+  if (!r) r = row_lse(c, d, N, C, nullptr, nullptr, d + (size_t)N * C);
+  if (!r) {
+    e = hipMemcpyAsync(Fs_out, d + (size_t)N * C, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) r = fail(EVOAMD_E_HIP, "free_energy copy back: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// RCCL
+// ---------------------------------------------------------------------------------------
+extern "C" int evoamd_comm_unique_id(uint8_t id_out[128]) {
+  int r = rccl_load();
+  if (r) return r;
+  RcclId id;
+  RCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, id.internal, 128);
+  return 0;
+}
+
+extern "C" int evoamd_comm_init(evoamd_ctx *c, const uint8_t id_in[128], int rank, int world) {
+  REQUIRE(c, "ctx is NULL");
+  REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+  int r = rccl_load();
+  if (r) return r;
+  HIP_TRY(hipSetDevice(c->device));
+  RcclId id;
+  memcpy(id.internal, id_in, 128);
+  RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, id, rank));
+  c->rank = rank;
+  c->world = world;
+  return 0;
+}
+
+extern "C" int evoamd_comm_allreduce_host(evoamd_ctx *c, double *buf, int64_t n, int op) {
+  REQUIRE(c && buf && n > 0, "bad arguments");
+  if (!c->comm) return 0;  // single rank: identity
+  HIP_TRY(hipSetDevice(c->device));
+  double *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, (size_t)n * sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(d, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = g_rccl.AllReduce(d, d, (size_t)n, 8, op == 1 ? 2 : 0, c->comm, c->stream);
+  if (rc != 0) {
+    (void)hipFree(d);
+    return fail(EVOAMD_E_RCCL, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+  }
+  HIP_TRY(hipMemcpyAsync(buf, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return 0;
+}
+
+extern "C" int evoamd_comm_destroy(evoamd_ctx *c) {
+  REQUIRE(c, "ctx is NULL");
+  if (c->comm) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    RCCL_TRY(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr;
+    c->world = 1;
+    c->rank = 0;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------------------
+extern "C" int evoamd_timing_enable(evoamd_ctx *c, int on) {
+  REQUIRE(c, "ctx is NULL");
+  if (!on && c->timing) {
+    int r = resolve_spans(c);
+    if (r) return r;
+  }
+  c->timing = on != 0;
+  return 0;
+}
+
+extern "C" int evoamd_timing_reset(evoamd_ctx *c) {
+  REQUIRE(c, "ctx is NULL");
+  int r = resolve_spans(c);
+  if (r) return r;
+  for (int i = 0; i < KID_COUNT; i++) {
+    c->t_ms[i] = 0;
+    c->t_n[i] = 0;
+  }
+  return 0;
+}
+
+extern "C" int evoamd_kernel_time_ms(evoamd_ctx *c, int kid, double *avg_ms, int64_t *launches) {
+  REQUIRE(c && kid >= 0 && kid < KID_COUNT, "bad kernel id");
+  int r = resolve_spans(c);
+  if (r) return r;
+  if (avg_ms) *avg_ms = c->t_n[kid] ? c->t_ms[kid] / (double)c->t_n[kid] : 0.0;
+  if (launches) *launches = c->t_n[kid];
+  return 0;
+}
+
+extern "C" const char *evoamd_kernel_name(int kid) {
+  static const char *names[KID_COUNT] = {"lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse",  "vary_kn",
+                                         "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc"};
+  return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
+}

@@ -1,0 +1,186 @@
+// EBSC kernels: log-pseudo-joint (bsc.py:78-97, direct residual form) and the M-step
+// sufficient statistics (bsc.py:176-223).
+#pragma once
+#include "common.hpp"
+
+#define BSC_CHUNK 8  // states handled by one wavefront before it moves on (y_n stays in registers)
+
+// lpj_c = pil_bar*|s_c| + pre1 * sum_d (sum_{h in s_c} W_dh - y_d)^2          (bsc.py:89-95)
+//
+// One wavefront per (datapoint n, chunk of BSC_CHUNK states).  Lanes own observables
+// d = lane + 64 r; y_n lives in registers; the state words are wave-uniform, so the set-bit
+// walk runs on the scalar unit and every active latent costs R coalesced 512-byte reads of a
+// row of W^T (H,D) (L2-resident: H*D*8 <= 2 MiB for every BASELINE config).  The residual is
+// formed exactly as the reference does -- superposition first, then (Wbar - y)^2 -- so there
+// is no Gram-form cancellation; only the order of the final sum over d differs (wave tree
+// instead of NumPy's pairwise blocks).
+//
+// states: (shared ? 1 : N) x Cstride x HW packed; counts (N) or nullptr (= C for every n).
+template <int R>
+__global__ __launch_bounds__(256) void bsc_lpj_kernel(
+    const double *__restrict__ Y, const double *__restrict__ Wt, const u64 *__restrict__ states,
+    const int *__restrict__ counts, i64 N, int C, int Cstride, int shared, int D, int HW, double pre1,
+    double pil_bar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int nchunk = (C + BSC_CHUNK - 1) / BSC_CHUNK;
+  const i64 g = (i64)blockIdx.x * 4 + wave;
+  const i64 n = g / nchunk;
+  if (n >= N) return;
+  const int chunk = (int)(g - n * nchunk);
+  int cnt = counts ? counts[n] : C;
+  if (cnt > C) cnt = C;
+  const int c0 = chunk * BSC_CHUNK;
+  const int c1 = (c0 + BSC_CHUNK < cnt) ? c0 + BSC_CHUNK : cnt;
+  if (c0 >= c1) return;
+  const double *y = Y + n * D;
+  const u64 *sbase = states + (shared ? 0 : n * (i64)Cstride * HW);
+  unsigned fl = 0;
+  double part[BSC_CHUNK];
+  int kk[BSC_CHUNK];
+#pragma unroll
+  for (int i = 0; i < BSC_CHUNK; i++) {
+    part[i] = 0.0;
+    kk[i] = 0;
+  }
+  // observables are processed in slabs of 64*R so any D works with R registers per lane
+  for (int d0 = 0; d0 < D; d0 += 64 * R) {
+    double yv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      int d = d0 + lane + 64 * r;
+      yv[r] = (d < D) ? y[d] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < BSC_CHUNK; i++) {
+      const int c = c0 + i;
+      if (c < c1) {  // wave-uniform
+        const u64 *sp = sbase + (i64)c * HW;
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.0;
+        int k = 0;
+        for (int w = 0; w < HW; w++) {
+          u64 bits = sp[w];  // uniform address -> scalar load
+          k += __popcll(bits);
+          while (bits) {
+            const int h = w * 64 + pop_msb(bits);
+            const double *wr = Wt + (i64)h * D + d0 + lane;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+              if (d0 + lane + 64 * r < D) acc[r] += wr[64 * r];
+          }
+        }
+        double p = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          double t = acc[r] - yv[r];
+          p += t * t;
+        }
+        part[i] += p;
+        kk[i] = k;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BSC_CHUNK; i++) {
+    const int c = c0 + i;
+    if (c < c1) {
+      double tot = wave_sum(part[i]);
+      if (lane == 0) {
+        double v = pre1 * tot + pil_bar * (double)kk[i];
+        lpj_out[n * ldo + col0 + c] = clamp_lpj(v, fl);
+      }
+    }
+  }
+  if (lane == 0 && fl) atomicOr(&flags[n], fl);
+}
+
+// Permanent all-zero state: lpj = pre * ||y_n||^2 (bsc.py:72 with pre = pre1; sssc.py:237 with
+// pre = -0.5*sigma2_inv).  yy (N) is the precomputed squared norm.  One thread per n.
+__global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N, double pre,
+                                                          double *__restrict__ lpj_out, int ldo,
+                                                          unsigned *__restrict__ flags) {
+  i64 n = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  unsigned fl = 0;
+  lpj_out[n * ldo] = clamp_lpj(pre * yy[n], fl);
+  if (fl) atomicOr(&flags[n], fl);
+}
+
+// yy_n = sum_d y_nd^2, one wavefront per n.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restrict__ Y, i64 N, int D,
+                                                         double *__restrict__ yy) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const i64 n = (i64)blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  double s = 0.0;
+  for (int d = lane; d < D; d += 64) {
+    double v = Y[n * D + d];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) yy[n] = s;
+}
+
+// EBSC M-step sums for one rank (bsc.py:176-223), one wavefront per datapoint:
+//   q_s = exp(lpj_s + B_n) / sum_s' exp(lpj_s' + B_n)
+//   Es[n][h]  = sum_s q_s s_h                      -> written to the (N,H) matrix Es; the dense
+//                                                     Wp = Es^T Y and pies = colsum(Es) follow
+//   Wq[h][h'] += sum_s q_s s_h s_h'                -> f64 hardware atomics on the (H,H) matrix
+//   sigma     += sum_s q_s ||y - W s||^2, with ||y - W s||^2 = (lpj_s - pil_bar |s|)/pre1
+//                (exact inverse of the lpj kernel's last line; no second pass over W)
+//   plus the all-zero permanent state's q_0 ||y||^2 (bsc.py:206-207).
+// States with q_s == 0 contribute exact zeros and are skipped.
+__global__ __launch_bounds__(256) void bsc_stats_kernel(
+    const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
+    const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H,
+    int HW, double pre1, double pil_bar, double *__restrict__ Es, double *__restrict__ Wq,
+    double *__restrict__ sig_partial) {
+  extern __shared__ double es_lds[];  // 4 waves x H
+  __shared__ double wsig[4];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const i64 n = (i64)blockIdx.x * 4 + wave;
+  double *es = es_lds + wave * H;
+  double sig = 0.0;
+  if (n < N) {
+    for (int h = lane; h < H; h += 64) es[h] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int L = S + S_perm;
+    const double B = 0.0 - rowmax[n];
+    const double inv = 1.0 / rowsum[n];
+    const double *row = lpj + n * L;
+    if (S_perm && lane == 0) sig += exp(row[0] + B) * yy[n];
+    for (int s = lane; s < S; s += 64) {
+      const double l = row[S_perm + s];
+      const double q = exp(l + B);
+      if (q == 0.0) continue;
+      const u64 *sp = states + (n * (i64)S + s) * HW;
+      const double qn = q * inv;
+      int k = 0;
+      for (int w = 0; w < HW; w++) {
+        u64 bits = sp[w];
+        k += __popcll(bits);
+        while (bits) {
+          const int h = w * 64 + pop_msb(bits);
+          unsafeAtomicAdd(&es[h], q);
+          // row h of Wq gets q_n at every active column
+          for (int w2 = 0; w2 < HW; w2++) {
+            u64 b2 = sp[w2];
+            while (b2) {
+              const int h2 = w2 * 64 + pop_msb(b2);
+              unsafeAtomicAdd(&Wq[(i64)h * H + h2], qn);
+            }
+          }
+        }
+      }
+      sig += q * ((l - pil_bar * (double)k) / pre1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int h = lane; h < H; h += 64) Es[n * H + h] = es[h] * inv;
+    sig = wave_sum(sig) * inv;
+  }
+  if (lane == 0) wsig[wave] = (n < N) ? sig : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) sig_partial[blockIdx.x] = ((wsig[0] + wsig[1]) + wsig[2]) + wsig[3];
+}

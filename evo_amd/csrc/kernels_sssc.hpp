@@ -1,0 +1,436 @@
+// ES3C kernels: spike-and-slab log-pseudo-joint (sssc.py:241-326) and sufficient statistics
+// (sssc.py:553-611) in Gram form.
+//
+// With G = W^T W, b_n = W^T y_n, yy_n = |y_n|^2 (dense f64 MFMA precompute) and, for a state
+// with active set A (k = |A|):   mu = mus_A, Psi = Psi[A,A] (dense, NOT symmetric after the
+// first M-step), G_A = G[A,A], b = b_n[A]:
+//     v   = b - G_A mu                      ( = W_s^T (y - W_s mu) )
+//     rr  = yy - sum_i mu_i (b_i + v_i)     ( = |y - W_s mu|^2 )
+//     T   = I + Psi G_A / sigma2            ( det T = det(M_s) det(Psi_s),  M_s of sssc.py:289 )
+//     Lam = T^-1 Psi                        ( = M_s^-1 = lambda_s, push-through identity )
+//     C_det = log|det T|                    ( = log|det M_s| + log|det Psi_s|, sssc.py:305 )
+//     r^T C_inv r = rr/sigma2 - v^T Lam v / sigma2^2          (sssc.py:307-309,322)
+//     lpj = sum_{h in A} pil_bar_h - 0.5 (C_det + r^T C_inv r)
+//     kappa = Lam v / sigma2 + mu           (sssc.py:574-575)
+// The reference forms Psi_s^-1, M_s, M_s^-1 and a D x D C_inv per state; this form needs one
+// k x k LU with partial pivoting (LAPACK getrf order: first max |pivot|, multiply by the
+// reciprocal) and never touches D.  Checked against the reference's fixtures to ~1e-13.
+//
+// Work mapping: states are overwhelmingly sparse (k <= 4 for the BASELINE initialisation), so
+// the main kernel gives every *thread* one (n, state) pair and keeps the whole k x k system in
+// registers (template K = 4, then K = 8 for the overflow list); the rare k > 8 pairs go to a
+// second overflow list handled by one wavefront per pair with the system in LDS (k <= 64).
+#pragma once
+#include "common.hpp"
+
+struct SsscArgs {
+  const u64 *states;     // (shared ? 1 : N) x C x HW
+  const int *counts;     // (N) or nullptr
+  const double *Bm;      // (N,H)  b_n = W^T y_n
+  const double *yy;      // (N)
+  const double2 *GP;     // (H,H) interleaved {G_ij, Psi_ij}
+  const double *mus;     // (H)
+  const double *pil_bar; // (H)
+  double s2inv;
+  i64 N;
+  int C;       // states per datapoint in this batch (row stride of `states`)
+  int shared;  // one state set for every n
+  int H, HW;
+  // LPJ mode
+  double *lpj_out;  // element (n, col0 + c), row stride ldo
+  int ldo, col0;
+  unsigned *flags;  // (N)
+  // STATS mode
+  const double *lpj_in;  // (N, ldo) rows incl. permanent column
+  const double *rowmax, *rowsum;
+  double *Es, *Ez;        // (N,H) zero-initialised
+  double *xss, *xszsz;    // (H,H) zero-initialised
+  int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
+};
+
+#define SSSC_KCAP 64
+
+template <int K>
+__device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K], double (*P)[K], bool with_P,
+                                              double &logdet, bool &singular) {
+  logdet = 0.0;
+#pragma unroll
+  for (int p = 0; p < K; p++) {
+    int piv = p;
+    double best = fabs(T[p][p]);
+#pragma unroll
+    for (int i = p + 1; i < K; i++) {
+      double a = fabs(T[i][p]);
+      if (a > best) {
+        best = a;
+        piv = i;
+      }
+    }
+#pragma unroll
+    for (int i = p + 1; i < K; i++) {
+      if (piv == i) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          double t = T[p][j];
+          T[p][j] = T[i][j];
+          T[i][j] = t;
+        }
+        double t = w[p];
+        w[p] = w[i];
+        w[i] = t;
+        if (with_P) {
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            double t2 = P[p][j];
+            P[p][j] = P[i][j];
+            P[i][j] = t2;
+          }
+        }
+      }
+    }
+    const double d = T[p][p];
+    if (d == 0.0) singular = true;
+    logdet += log(fabs(d));
+    const double r = 1.0 / d;
+#pragma unroll
+    for (int i = p + 1; i < K; i++) {
+      const double f = T[i][p] * r;
+#pragma unroll
+      for (int j = p + 1; j < K; j++) T[i][j] -= f * T[p][j];
+      w[i] -= f * w[p];
+      if (with_P) {
+#pragma unroll
+        for (int j = 0; j < K; j++) P[i][j] -= f * P[p][j];
+      }
+    }
+  }
+  // back substitution (in place: w -> x, P -> Lam)
+#pragma unroll
+  for (int p = K - 1; p >= 0; p--) {
+    const double r = 1.0 / T[p][p];
+    double s = w[p];
+#pragma unroll
+    for (int j = p + 1; j < K; j++) s -= T[p][j] * w[j];
+    w[p] = s * r;
+    if (with_P) {
+#pragma unroll
+      for (int c = 0; c < K; c++) {
+        double s2 = P[p][c];
+#pragma unroll
+        for (int j = p + 1; j < K; j++) s2 -= T[p][j] * P[j][c];
+        P[p][c] = s2 * r;
+      }
+    }
+  }
+}
+
+// MODE 0: lpj, MODE 1: statistics.  list_in == nullptr: natural order over N*C pairs.
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *__restrict__ list_in,
+                                                         const int *__restrict__ n_in,
+                                                         int *__restrict__ list_out,
+                                                         int *__restrict__ n_out) {
+  const i64 total = list_in ? (i64)(*n_in) : a.N * (i64)a.C;
+  for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
+    const i64 e = list_in ? (i64)list_in[t] : t;
+    const i64 n = e / a.C;
+    const int c = (int)(e - n * a.C);
+    if (a.counts && c >= a.counts[n]) continue;
+    const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
+    int ktot = 0;
+    for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+    if (ktot > K) {
+      int pos = atomicAdd(n_out, 1);
+      list_out[pos] = (int)e;
+      continue;
+    }
+    double qn = 0.0;
+    if (MODE == 1) {
+      const double l = a.lpj_in[n * a.ldo + a.col0 + c];
+      const double q = exp(l + (0.0 - a.rowmax[n]));
+      if (q == 0.0) continue;
+      qn = q / (a.rowsum[n] + EVO_F64_TINY);
+    }
+    int idx[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) idx[i] = 0;
+    int k = 0;
+    for (int w = 0; w < a.HW; w++) {
+      u64 bits = sp[w];
+      while (bits) {
+        const int h = w * 64 + pop_msb(bits);
+#pragma unroll
+        for (int i = 0; i < K; i++)
+          if (i == k) idx[i] = h;
+        k++;
+      }
+    }
+    double b[K], mu[K], v[K], wv[K];
+    double G[K][K], P[K][K], T[K][K];
+    double pb = 0.0;
+    const double *Bn = a.Bm + n * a.H;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      const bool on = i < k;
+      b[i] = on ? Bn[idx[i]] : 0.0;
+      mu[i] = on ? a.mus[idx[i]] : 0.0;
+      pb += on ? a.pil_bar[idx[i]] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        if (i < k && j < k) {
+          const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
+          G[i][j] = gp.x;
+          P[i][j] = gp.y;
+        } else {
+          G[i][j] = 0.0;
+          P[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+      }
+    double rr = a.yy[n];
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      double s = b[i];
+#pragma unroll
+      for (int j = 0; j < K; j++) s -= G[i][j] * mu[j];
+      v[i] = s;
+      rr -= mu[i] * (b[i] + s);
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < K; j++) s += P[i][j] * v[j];
+      wv[i] = s;
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        double tt = 0.0;
+#pragma unroll
+        for (int l = 0; l < K; l++) tt += P[i][l] * G[l][j];
+        T[i][j] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+      }
+    }
+    double logdet;
+    bool singular = false;
+    lu_solve_regs<K>(T, wv, P, MODE == 1, logdet, singular);
+    if (singular) atomicOr(a.err, 2);
+    if (MODE == 0) {
+      double quad = 0.0;
+#pragma unroll
+      for (int i = 0; i < K; i++) quad += v[i] * wv[i];
+      const double val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
+      unsigned fl = 0;
+      a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
+      if (fl) atomicOr(&a.flags[n], fl);
+    } else {
+      double kap[K];
+#pragma unroll
+      for (int i = 0; i < K; i++) kap[i] = wv[i] * a.s2inv + mu[i];
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        if (i < k) {
+          unsafeAtomicAdd(&a.Es[n * a.H + idx[i]], qn);
+          unsafeAtomicAdd(&a.Ez[n * a.H + idx[i]], qn * kap[i]);
+#pragma unroll
+          for (int j = 0; j < K; j++) {
+            if (j < k) {
+              const i64 o = (i64)idx[i] * a.H + idx[j];
+              unsafeAtomicAdd(&a.xss[o], qn);
+              unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// One wavefront (64-thread workgroup) per listed pair; k <= SSSC_KCAP; system in LDS.
+// LDS: Tm[k*k] | Pm[k*k] | idx[KCAP] ints | vectors b, mu, v, w, f  (dynamic shared memory
+// sized for KCAP by the launcher).
+template <int MODE>
+__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, const int *__restrict__ list_in,
+                                                      const int *__restrict__ n_in) {
+  extern __shared__ double lds[];
+  double *Tm = lds;
+  double *Pm = Tm + SSSC_KCAP * SSSC_KCAP;
+  double *bv = Pm + SSSC_KCAP * SSSC_KCAP;
+  double *muv = bv + SSSC_KCAP;
+  double *vv = muv + SSSC_KCAP;
+  double *wv = vv + SSSC_KCAP;
+  double *fv = wv + SSSC_KCAP;
+  int *idx = (int *)(fv + SSSC_KCAP);
+  const int lane = threadIdx.x;
+  const i64 total = list_in ? (i64)(*n_in) : a.N * (i64)a.C;
+  for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
+    const i64 e = list_in ? (i64)list_in[t] : t;
+    const i64 n = e / a.C;
+    const int c = (int)(e - n * a.C);
+    if (a.counts && c >= a.counts[n]) continue;  // uniform
+    const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
+    __syncthreads();
+    int k = 0;
+    for (int w = 0; w < a.HW; w++) {
+      const u64 bits = sp[w];
+      const bool on = (bits >> (63 - lane)) & 1ull;
+      const u64 m = __ballot(on);
+      const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
+      if (on && pos < SSSC_KCAP) idx[pos] = w * 64 + lane;
+      k += __popcll(m);
+    }
+    if (k > SSSC_KCAP) {
+      if (lane == 0) {
+        atomicOr(a.err, 1);
+        if (MODE == 0) a.lpj_out[n * a.ldo + a.col0 + c] = EVO_F64_MIN;
+      }
+      continue;
+    }
+    double qn = 0.0;
+    if (MODE == 1) {
+      const double l = a.lpj_in[n * a.ldo + a.col0 + c];
+      const double q = exp(l + (0.0 - a.rowmax[n]));
+      if (q == 0.0) continue;  // uniform
+      qn = q / (a.rowsum[n] + EVO_F64_TINY);
+    }
+    __syncthreads();
+    const double *Bn = a.Bm + n * a.H;
+    double pb = 0.0;
+    if (lane < k) {
+      const int h = idx[lane];
+      bv[lane] = Bn[h];
+      muv[lane] = a.mus[h];
+      pb = a.pil_bar[h];
+    }
+    pb = wave_sum(pb);
+    for (int q = lane; q < k * k; q += 64) {
+      const int i = q / k, j = q - i * k;
+      Pm[q] = a.GP[(i64)idx[i] * a.H + idx[j]].y;
+    }
+    __syncthreads();
+    double rr_part = 0.0;
+    if (lane < k) {
+      double s = bv[lane];
+      const i64 ro = (i64)idx[lane] * a.H;
+      for (int j = 0; j < k; j++) s -= a.GP[ro + idx[j]].x * muv[j];
+      vv[lane] = s;
+      rr_part = muv[lane] * (bv[lane] + s);
+    }
+    const double rr = a.yy[n] - wave_sum(rr_part);
+    __syncthreads();
+    if (lane < k) {
+      double s = 0.0;
+      for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+      wv[lane] = s;
+    }
+    for (int q = lane; q < k * k; q += 64) {
+      const int i = q / k, j = q - i * k;
+      double tt = 0.0;
+      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * a.GP[(i64)idx[l] * a.H + idx[j]].x;
+      Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+    }
+    __syncthreads();
+    // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
+    bool singular = false;
+    for (int p = 0; p < k; p++) {
+      double av = (lane >= p && lane < k) ? fabs(Tm[lane * k + p]) : -1.0;
+      int ai = lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(av, o, 64);
+        const int i2 = __shfl_xor(ai, o, 64);
+        if (v2 > av || (v2 == av && i2 < ai)) {
+          av = v2;
+          ai = i2;
+        }
+      }
+      const int piv = ai;
+      if (piv != p) {
+        if (lane < k) {
+          const double t1 = Tm[p * k + lane];
+          Tm[p * k + lane] = Tm[piv * k + lane];
+          Tm[piv * k + lane] = t1;
+          if (MODE == 1) {
+            const double t2 = Pm[p * k + lane];
+            Pm[p * k + lane] = Pm[piv * k + lane];
+            Pm[piv * k + lane] = t2;
+          }
+        }
+        if (lane == 0) {
+          const double t3 = wv[p];
+          wv[p] = wv[piv];
+          wv[piv] = t3;
+        }
+      }
+      __syncthreads();
+      const double d = Tm[p * k + p];
+      if (d == 0.0) singular = true;
+      const double r = 1.0 / d;
+      if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
+      __syncthreads();
+      const int m = k - p - 1;
+      for (int q = lane; q < m * m; q += 64) {
+        const int i = p + 1 + q / m, j = p + 1 + q % m;
+        Tm[i * k + j] -= fv[i] * Tm[p * k + j];
+      }
+      if (MODE == 1) {
+        for (int q = lane; q < m * k; q += 64) {
+          const int i = p + 1 + q / k, j = q % k;
+          Pm[i * k + j] -= fv[i] * Pm[p * k + j];
+        }
+      }
+      if (lane > p && lane < k) wv[lane] -= fv[lane] * wv[p];
+      __syncthreads();
+    }
+    double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
+    const double logdet = wave_sum(ld);
+    // ---- back substitution, column oriented
+    for (int p = k - 1; p >= 0; p--) {
+      const double r = 1.0 / Tm[p * k + p];
+      if (lane == 0) wv[p] *= r;
+      if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
+      __syncthreads();
+      if (lane < p) wv[lane] -= Tm[lane * k + p] * wv[p];
+      if (MODE == 1) {
+        for (int q = lane; q < p * k; q += 64) {
+          const int i = q / k, j = q % k;
+          Pm[i * k + j] -= Tm[i * k + p] * Pm[p * k + j];
+        }
+      }
+      __syncthreads();
+    }
+    if (singular && lane == 0) atomicOr(a.err, 2);
+    if (MODE == 0) {
+      const double quad = wave_sum((lane < k) ? vv[lane] * wv[lane] : 0.0);
+      if (lane == 0) {
+        const double val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
+        unsigned fl = 0;
+        a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
+        if (fl) atomicOr(&a.flags[n], fl);
+      }
+    } else {
+      if (lane < k) {
+        const double kap = wv[lane] * a.s2inv + muv[lane];
+        fv[lane] = kap;
+        unsafeAtomicAdd(&a.Es[n * a.H + idx[lane]], qn);
+        unsafeAtomicAdd(&a.Ez[n * a.H + idx[lane]], qn * kap);
+      }
+      __syncthreads();
+      for (int q = lane; q < k * k; q += 64) {
+        const int i = q / k, j = q - i * k;
+        const i64 o = (i64)idx[i] * a.H + idx[j];
+        unsafeAtomicAdd(&a.xss[o], qn);
+        unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
+      }
+    }
+  }
+}
+
+// GP[i][j] = {G[i][j], Psi[i][j]}
+__global__ __launch_bounds__(256) void interleave_gp_kernel(const double *__restrict__ G,
+                                                            const double *__restrict__ Psi, i64 n,
+                                                            double2 *__restrict__ GP) {
+  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) GP[i] = make_double2(G[i], Psi[i]);
+}

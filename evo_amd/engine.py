@@ -1,0 +1,264 @@
+"""Engine: one GPU context of libevo_amd.so, NumPy in / NumPy out.
+
+The engine owns the device-resident copies of the three state bags of the reference
+(SURVEY.md 8b): ``my_data["y"]``, ``my_suff_stat["ss"]`` / ``["lpj"]`` (bit-packed K^n), and
+``model_params``.  The model classes in ``evo_amd.models`` drive it; ``bench.py`` drives it
+directly so that nothing but device work sits in the timed region.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODEL_BSC, MODEL_SSSC, as_bool_bytes, as_f64, check, dptr, i32ptr, u8ptr
+
+
+def default_device():
+    """LOCAL_RANK under torchrun / one process per GPU, else 0."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class Engine:
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        self.device = default_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        check(self.lib.evoamd_ctx_create(self.device, ctypes.byref(h)))
+        self._h = h
+        self.model = None
+        self.N = self.D = self.H = self.S = self.S_perm = self.Cmax = 0
+        self.ljc = None
+        self.world = 1
+        self.rank = 0
+
+    # ---- lifetime ------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.evoamd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.evoamd_synchronize(self._h))
+
+    # ---- geometry / uploads --------------------------------------------------------------
+    def configure(self, model, N, D, H, S, S_perm=0, Cmax=16):
+        self.model = MODEL_BSC if model in (MODEL_BSC, "bsc", "BSC") else MODEL_SSSC
+        check(self.lib.evoamd_configure(self._h, self.model, int(N), int(D), int(H), int(S), int(S_perm), int(Cmax)))
+        self.N, self.D, self.H, self.S, self.S_perm, self.Cmax = int(N), int(D), int(H), int(S), int(S_perm), int(Cmax)
+        self.L = self.S + self.S_perm
+
+    def same_geometry(self, model, N, D, H, S, S_perm, Cmax):
+        m = MODEL_BSC if model in (MODEL_BSC, "bsc", "BSC") else MODEL_SSSC
+        return (self.model, self.N, self.D, self.H, self.S, self.S_perm, self.Cmax) == (m, N, D, H, S, S_perm, Cmax)
+
+    def upload_data(self, Y):
+        Y = as_f64(Y)
+        assert Y.shape == (self.N, self.D), (Y.shape, self.N, self.D)
+        check(self.lib.evoamd_upload_data(self._h, dptr(Y)))
+
+    def upload_states(self, ss):
+        b = as_bool_bytes(ss)
+        assert b.shape == (self.N, self.S, self.H), (b.shape, (self.N, self.S, self.H))
+        check(self.lib.evoamd_upload_states(self._h, u8ptr(b)))
+
+    def download_states(self, out=None):
+        """K^n as bool (N,S,H).  ``out`` may be the caller's my_suff_stat["ss"] (written in place)."""
+        if out is None:
+            out = np.empty((self.N, self.S, self.H), dtype=np.bool_)
+        assert out.shape == (self.N, self.S, self.H) and out.dtype == np.bool_ and out.flags.c_contiguous
+        check(self.lib.evoamd_download_states(self._h, u8ptr(out.view(np.uint8))))
+        return out
+
+    def upload_lpj(self, lpj):
+        lpj = as_f64(lpj)
+        assert lpj.shape == (self.N, self.L)
+        check(self.lib.evoamd_upload_lpj(self._h, dptr(lpj)))
+
+    def download_lpj(self, out=None):
+        if out is None:
+            out = np.empty((self.N, self.L), dtype=np.float64)
+        assert out.shape == (self.N, self.L) and out.dtype == np.float64 and out.flags.c_contiguous
+        check(self.lib.evoamd_download_lpj(self._h, dptr(out)))
+        return out
+
+    # ---- parameters ----------------------------------------------------------------------
+    def set_params_bsc(self, W, pi, sigma):
+        W = as_f64(W)
+        assert W.shape == (self.D, self.H)
+        ljc = ctypes.c_double()
+        check(self.lib.evoamd_set_params_bsc(self._h, dptr(W), float(pi), float(sigma), ctypes.byref(ljc)))
+        self.ljc = ljc.value
+        return self.ljc
+
+    def set_params_sssc(self, W, pies, mus, Psi, sigma2):
+        W, pies, mus, Psi = as_f64(W), as_f64(pies), as_f64(mus), as_f64(Psi)
+        assert W.shape == (self.D, self.H) and pies.shape == (self.H,) and mus.shape == (self.H,)
+        assert Psi.shape == (self.H, self.H)
+        ljc = ctypes.c_double()
+        check(self.lib.evoamd_set_params_sssc(self._h, dptr(W), dptr(pies), dptr(mus), dptr(Psi), float(sigma2),
+                                              ctypes.byref(ljc)))
+        self.ljc = ljc.value
+        return self.ljc
+
+    # ---- E-step --------------------------------------------------------------------------
+    def lpj_resident(self):
+        check(self.lib.evoamd_lpj_resident(self._h))
+
+    def lpj_candidates(self, cand, counts, want_lpj=True):
+        b = as_bool_bytes(cand)
+        assert b.shape == (self.N, self.Cmax, self.H), (b.shape, (self.N, self.Cmax, self.H))
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        assert counts.shape == (self.N,)
+        out = np.empty((self.N, self.Cmax), dtype=np.float64) if want_lpj else None
+        check(self.lib.evoamd_lpj_candidates(self._h, u8ptr(b), i32ptr(counts), self.Cmax,
+                                             dptr(out) if want_lpj else None))
+        return out
+
+    def set_candidates(self, cand, counts, lpj):
+        b = as_bool_bytes(cand)
+        assert b.shape == (self.N, self.Cmax, self.H)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        lpj = as_f64(lpj)
+        assert lpj.shape == (self.N, self.Cmax)
+        check(self.lib.evoamd_set_candidates(self._h, u8ptr(b), i32ptr(counts), self.Cmax, dptr(lpj)))
+
+    def lpj_shared(self, states):
+        b = as_bool_bytes(states)
+        assert b.ndim == 2 and b.shape[1] == self.H
+        out = np.empty((self.N, b.shape[0]), dtype=np.float64)
+        check(self.lib.evoamd_lpj_shared(self._h, u8ptr(b), b.shape[0], dptr(out)))
+        return out
+
+    def lpj_single(self, y, states):
+        y = as_f64(y)
+        b = as_bool_bytes(states)
+        assert y.shape == (self.D,) and b.ndim == 2 and b.shape[1] == self.H
+        out = np.empty(b.shape[0], dtype=np.float64)
+        flags = np.zeros(3, dtype=np.int32)
+        check(self.lib.evoamd_lpj_single(self._h, dptr(y), u8ptr(b), b.shape[0], dptr(out), i32ptr(flags)))
+        return out, flags
+
+    def vary_kn(self, Mprime, want_sums=True):
+        sums = np.zeros(2, dtype=np.float64)
+        check(self.lib.evoamd_vary_kn(self._h, int(Mprime), dptr(sums) if want_sums else None))
+        return sums
+
+    def evolve_randflip(self, n_parents, n_children, seed, fit_parents=True):
+        check(self.lib.evoamd_evolve_randflip(self._h, int(n_parents), int(n_children), int(seed) & (2 ** 64 - 1),
+                                              1 if fit_parents else 0))
+
+    def set_estep_counts(self, sum_nunique, sum_sub):
+        check(self.lib.evoamd_set_estep_counts(self._h, float(sum_nunique), float(sum_sub)))
+
+    # ---- statistics ----------------------------------------------------------------------
+    def acc_size(self):
+        return int(self.lib.evoamd_acc_size(self._h))
+
+    def stats(self):
+        """Packed accumulator (already all-reduced over RCCL when a communicator is attached)."""
+        acc = np.empty(self.acc_size(), dtype=np.float64)
+        check(self.lib.evoamd_stats(self._h, dptr(acc)))
+        return acc
+
+    def free_energy_sum(self, lpj):
+        lpj = as_f64(lpj)
+        out = ctypes.c_double()
+        check(self.lib.evoamd_free_energy(self._h, dptr(lpj), lpj.shape[0], lpj.shape[1], ctypes.byref(out)))
+        return out.value
+
+    def acc_views(self, acc):
+        return acc_views(acc, self.model, self.D, self.H)
+
+    # ---- RCCL ----------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = _lib.load()
+        buf = np.zeros(128, dtype=np.uint8)
+        check(lib.evoamd_comm_unique_id(u8ptr(buf)))
+        return buf.tobytes()
+
+    def comm_init(self, uid, rank, world):
+        buf = np.frombuffer(uid, dtype=np.uint8).copy()
+        assert buf.size == 128
+        check(self.lib.evoamd_comm_init(self._h, u8ptr(buf), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_allreduce(self, values, op="sum"):
+        a = np.atleast_1d(as_f64(values)).copy()
+        check(self.lib.evoamd_comm_allreduce_host(self._h, dptr(a), a.size, 1 if op == "max" else 0))
+        return a
+
+    def comm_destroy(self):
+        check(self.lib.evoamd_comm_destroy(self._h))
+        self.world, self.rank = 1, 0
+
+    # ---- timing --------------------------------------------------------------------------
+    def timing(self, on=True):
+        check(self.lib.evoamd_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        check(self.lib.evoamd_timing_reset(self._h))
+
+    def kernel_time_ms(self, name):
+        avg = ctypes.c_double()
+        n = ctypes.c_int64()
+        check(self.lib.evoamd_kernel_time_ms(self._h, _lib.KERNEL_IDS[name], ctypes.byref(avg), ctypes.byref(n)))
+        return avg.value, n.value
+
+
+TAIL = ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf", "pad")
+
+
+def acc_layout(model, D, H):
+    """Offsets (name -> (start, shape)) of the packed accumulator documented in evo_amd.h."""
+    out = {}
+    o = 0
+
+    def put(name, shape):
+        nonlocal o
+        n = int(np.prod(shape)) if shape else 1
+        out[name] = (o, shape)
+        o += n
+
+    if model in (MODEL_BSC, "bsc", "BSC"):
+        put("Wp", (H, D))
+        put("Wq", (H, H))
+        put("pies", (H,))
+        put("sigma", ())
+    else:
+        put("xpt_s", (H,))
+        put("xpt_ss", (H, H))
+        put("xpt_sz", (H,))
+        put("xpt_szsz", (H, H))
+        put("s_sz_outer", (H, H))
+        put("sz_sz_outer", (H, H))
+        put("Wp", (D, H))
+        put("y_outer_diag", (D,))
+    for t in TAIL:
+        put(t, ())
+    out["_size"] = (o, ())
+    return out
+
+
+def acc_size(model, D, H):
+    return acc_layout(model, D, H)["_size"][0]
+
+
+def acc_views(acc, model, D, H):
+    """dict name -> view into the packed accumulator (scalars as 0-d views)."""
+    lay = acc_layout(model, D, H)
+    assert acc.size == lay["_size"][0], (acc.size, lay["_size"][0])
+    views = {}
+    for name, (start, shape) in lay.items():
+        if name == "_size":
+            continue
+        n = int(np.prod(shape)) if shape else 1
+        views[name] = acc[start:start + n].reshape(shape)
+    return views

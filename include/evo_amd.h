@@ -1,0 +1,187 @@
+/*
+ * evo_amd.h -- C ABI of libevo_amd.so: the MI355X (gfx950) implementation of the EVO
+ * evolutionary-variational E-step / M-step hot path (EBSC and ES3C).
+ *
+ * The reference (tvlearn/evo) has no FFI: its "operator API" is the Python method set of
+ * evo.models.Model / evo.variational.* operating on three dicts of NumPy arrays
+ * (SURVEY.md 8b).  This header is what the reference-side binding (a ctypes stub inside
+ * evo/models/{_models,bsc,sssc}.py, shown in INTEGRATION.md) binds; evo_amd/_lib.py is
+ * that stub for our own host-side mirror.  Each entry point names the reference lines it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions: plain C, no exceptions.  Every function returns 0 on success and a
+ * negative EVOAMD_E_* code on failure; evoamd_last_error() then returns a message.
+ * Host pointers are borrowed for the duration of the call only.  Calls are synchronous on
+ * return unless the name ends in _async.  One context per GPU per process; a context is
+ * not thread-safe.  All floating point is IEEE binary64 (the reference is float64-only).
+ *
+ * State encoding on the device: a binary state s in {0,1}^H is HW = ceil(H/64) 64-bit
+ * words; latent h lives in word h/64 at bit 63-(h%64) (MSB first), so that comparing the
+ * words as unsigned integers, word 0 first, is the lexicographic order np.unique applies
+ * to the reference's int rows (evo/variational/utils.py:279-282).  Host-facing calls take
+ * the reference's own layout: C-contiguous bool (1 byte per latent).
+ */
+#ifndef EVO_AMD_H
+#define EVO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVOAMD_ABI_VERSION 1
+
+enum {
+  EVOAMD_OK = 0,
+  EVOAMD_E_INVALID = -1, /* bad argument / call order                               */
+  EVOAMD_E_HIP = -2,     /* a HIP runtime call failed (message has the HIP error)    */
+  EVOAMD_E_NODEVICE = -3,/* no gfx950 device visible                                 */
+  EVOAMD_E_RCCL = -4,    /* RCCL missing or a collective failed                      */
+  EVOAMD_E_KLIMIT = -5,  /* ES3C: a state has more active latents than EVOAMD_KCAP   */
+  EVOAMD_E_SINGULAR = -6 /* ES3C: exactly singular k x k system (reference: pinv path)*/
+};
+
+enum { EVOAMD_MODEL_BSC = 0, EVOAMD_MODEL_SSSC = 1 };
+
+/* ES3C: largest |s| the k x k solver handles (LDS-resident, one wavefront per state). */
+#define EVOAMD_KCAP 64
+
+typedef struct evoamd_ctx evoamd_ctx;
+
+/* ---- library / context ------------------------------------------------------------- */
+int evoamd_abi_version(void);
+const char *evoamd_last_error(void);
+int evoamd_device_count(int *count);
+/* Creates a context on HIP device `device` (one non-default stream, workspace allocated
+ * lazily by evoamd_configure). */
+int evoamd_ctx_create(int device, evoamd_ctx **out);
+void evoamd_ctx_destroy(evoamd_ctx *ctx);
+int evoamd_synchronize(evoamd_ctx *ctx);
+
+/* ---- problem geometry -------------------------------------------------------------- */
+/* Allocates device storage for N datapoints on this rank: Y (N,D), K^n (N,S,HW) packed,
+ * lpj (N,S_perm+S), candidate batch (N,Cmax,HW) + lpj, parameters and accumulators.
+ * S_perm is 0 or 1 (permanent all-zero state; evo/variational/utils.py:39-54).
+ * Replaces the array allocation of _init_lpj_and_state_arrays (variational/utils.py:94-95). */
+int evoamd_configure(evoamd_ctx *ctx, int model, int64_t N, int D, int H, int S, int S_perm,
+                     int Cmax);
+
+/* my_data["y"] (N,D) float64, complete data (x_infr all True; SURVEY 8 scope). */
+int evoamd_upload_data(evoamd_ctx *ctx, const double *Y);
+/* my_suff_stat["ss"] (N,S,H) bool <-> device K^n (bit-packed on the device). */
+int evoamd_upload_states(evoamd_ctx *ctx, const uint8_t *ss_bool);
+int evoamd_download_states(evoamd_ctx *ctx, uint8_t *ss_bool);
+/* my_suff_stat["lpj"] (N,S_perm+S) float64. */
+int evoamd_upload_lpj(evoamd_ctx *ctx, const double *lpj);
+int evoamd_download_lpj(evoamd_ctx *ctx, double *lpj);
+
+/* ---- parameters Theta -------------------------------------------------------------- */
+/* BSC: W (D,H) row-major, pi, sigma.  Performs E_step_precompute on the host side of the
+ * library (bsc.py:99-125: pre1, pil_bar, ljc) and uploads W^T. ljc is returned. */
+int evoamd_set_params_bsc(evoamd_ctx *ctx, const double *W, double pi, double sigma, double *ljc);
+/* SSSC: W (D,H), pies (H), mus (H), Psi (H,H) row-major, sigma2.  pil_bar / ljc follow
+ * sssc.py:328-366 (sigma2 through long double).  Launches the dense precompute
+ * G = W^T W and B = Y W on the f64 matrix cores. */
+int evoamd_set_params_sssc(evoamd_ctx *ctx, const double *W, const double *pies, const double *mus,
+                           const double *Psi, double sigma2, double *ljc);
+
+/* ---- E-step ------------------------------------------------------------------------ */
+/* lpj of every resident state K^n under the current Theta -> device lpj[:, S_perm:]
+ * (and the permanent all-zero column when S_perm = 1).  Includes the clamp of
+ * Model.lpj_reset_check (_models.py:567-596).  Replaces the per-datapoint calls at
+ * _models.py:508-512 / sssc.py:521-525 (BSC.log_pseudo_joint bsc.py:78-97,
+ * SSSC.log_pseudo_joint sssc.py:241-326, *_permanent_states bsc.py:59-76, sssc.py:224-239). */
+int evoamd_lpj_resident(evoamd_ctx *ctx);
+
+/* Ragged candidate batch: cand_bool (N,Cmax,H) bool, counts (N,) int32 (counts[n] <= Cmax
+ * rows of datapoint n are valid).  Evaluates lpj of every valid candidate against y_n and
+ * keeps the batch + its lpj on the device for evoamd_vary_kn.  lpj_out (N,Cmax) may be
+ * NULL.  Replaces the eval_lpj closure (_models.py:517-519, sssc.py:530-532). */
+int evoamd_lpj_candidates(evoamd_ctx *ctx, const uint8_t *cand_bool, const int32_t *counts,
+                          int Cmax, double *lpj_out);
+
+/* Same batch layout, but with lpj values supplied by the caller (N,Cmax) instead of being
+ * evaluated: installs the resident candidate batch for evoamd_vary_kn.  This is vary_Kn's own
+ * calling shape (lpj_new, states_new given; variational/utils.py:231-244). */
+int evoamd_set_candidates(evoamd_ctx *ctx, const uint8_t *cand_bool, const int32_t *counts,
+                          int Cmax, const double *lpj);
+
+/* One state set shared by ALL datapoints (the exact-likelihood path, _models.py:385-394):
+ * states_bool (C,H); lpj_out (N,C) host. */
+int evoamd_lpj_shared(evoamd_ctx *ctx, const uint8_t *states_bool, int C, double *lpj_out);
+
+/* Single-datapoint operator with the reference's calling shape
+ * (log_pseudo_joint(model_params, my_suff_stat, my_data): this_y (D,), this_states (C,H)
+ * -> (C,)).  flags_out[3] receives {any NaN, any < finfo.min, any inf} for the caller's
+ * reset counters. */
+int evoamd_lpj_single(evoamd_ctx *ctx, const double *y, const uint8_t *states_bool, int C,
+                      double *lpj_out, int32_t *flags_out);
+
+/* K^n update on the device: de-duplicate the resident candidate batch against K^n (and
+ * within itself, first occurrence wins), then swap the best accepted new states for the
+ * worst evicted old ones exactly as vary_Kn does (variational/utils.py:231-337,
+ * unification branch), writing K^n and lpj in place.  sums_out[2] += {#new unique,
+ * #swapped} over this rank's datapoints (_models.py:537-538). */
+int evoamd_vary_kn(evoamd_ctx *ctx, int Mprime, double *sums_out);
+
+/* Device-side evolutionary candidate generation (fitness-proportional parents + random
+ * bit flips, eas.py:10-43,138-146,153-313 for n_generations = 1), counter-based RNG:
+ * statistically equivalent to, not stream-identical with, np.random.  Fills the resident
+ * candidate batch (de-duplicated) and evaluates it. */
+int evoamd_evolve_randflip(evoamd_ctx *ctx, int n_parents, int n_children, uint64_t seed,
+                           int fit_parents);
+
+/* ---- M-step sufficient statistics + free energy ------------------------------------- */
+/* Number of doubles in the packed accumulator for the configured model:
+ *   BSC : Wp (H,D) | Wq (H,H) | pies (H) | sigma | tail[8]
+ *   SSSC: xpt_s (H) | xpt_ss (H,H) | xpt_sz (H) | xpt_szsz (H,H) | s_sz_outer (H,H) |
+ *         sz_sz_outer (H,H) | Wp (D,H) | y_outer_diag (D) | tail[8]
+ *   tail = { Fs, sum_nunique, sum_sub, N, reset_isnan, reset_smaller_eps, reset_isinf, 0 } */
+int64_t evoamd_acc_size(evoamd_ctx *ctx);
+/* Computes the per-rank sums from the resident K^n / lpj (bsc.py:176-223;
+ * sssc.py:553-646,761; free energy _models.py:544-546), all-reduces them over the RCCL
+ * communicator if one is attached (bsc.py:230-231,257,274; sssc.py:671-691,763,773-780),
+ * and copies the packed result to acc_out (host). */
+int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
+/* Fs only (sum_n logsumexp) of an arbitrary host lpj matrix (N,C) -- exact-likelihood path. */
+int evoamd_free_energy(evoamd_ctx *ctx, const double *lpj, int64_t N, int C, double *Fs_out);
+/* Adds the E-step scalars produced outside evoamd_stats (e.g. host-side vary_Kn counts)
+ * into the accumulator tail before the all-reduce. */
+int evoamd_set_estep_counts(evoamd_ctx *ctx, double sum_nunique, double sum_sub);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------- */
+/* 128-byte opaque id made by rank 0 and distributed by the caller (file / socket / MPI). */
+int evoamd_comm_unique_id(uint8_t id_out[128]);
+int evoamd_comm_init(evoamd_ctx *ctx, const uint8_t id[128], int rank, int world);
+/* In-place sum / max all-reduce of a small host double vector through the device
+ * (used for barriers and max-over-ranks timing). op: 0 sum, 1 max. */
+int evoamd_comm_allreduce_host(evoamd_ctx *ctx, double *buf, int64_t n, int op);
+int evoamd_comm_destroy(evoamd_ctx *ctx);
+
+/* ---- timing (HIP events on the context's stream) ------------------------------------ */
+/* Kernel-class ids for evoamd_kernel_time_ms: average device time per launch since the last
+ * evoamd_timing_reset, measured with hipEvents recorded on the stream the kernels run on. */
+enum {
+  EVOAMD_K_LPJ_RESIDENT = 0,   /* bsc_lpj_kernel / sssc_small_kernel<4,0> on K^n (N x S)   */
+  EVOAMD_K_LPJ_CANDIDATES = 1, /* the same kernels on the candidate batch                  */
+  EVOAMD_K_LPJ_OVERFLOW = 2,   /* ES3C states with k > 4 (register K=8 + LDS wave kernels)  */
+  EVOAMD_K_ROW_LSE = 3,        /* free energy / posterior normalisers                      */
+  EVOAMD_K_VARY_KN = 4,
+  EVOAMD_K_STATS = 5,          /* bsc_stats_kernel / sssc_small_kernel<4,1>                 */
+  EVOAMD_K_STATS_OVERFLOW = 6,
+  EVOAMD_K_GEMM = 7,           /* f64 MFMA contractions                                     */
+  EVOAMD_K_EVOLVE = 8,
+  EVOAMD_K_MISC = 9,
+  EVOAMD_K_COUNT = 10
+};
+int evoamd_timing_enable(evoamd_ctx *ctx, int on);
+int evoamd_timing_reset(evoamd_ctx *ctx);
+int evoamd_kernel_time_ms(evoamd_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
+const char *evoamd_kernel_name(int kernel_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVO_AMD_H */
