@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- EM-iteration throughput of the EVO hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one full EM iteration of the product path (evo_amd.models, rng="device", K^n resident
+on the GPU): upload Theta + dense precompute, lpj of all N x S resident states, device candidate
+generation + their lpj, vary_Kn, sufficient statistics + free energy, ONE RCCL all-reduce of the
+packed accumulator when N > 1, and the (tiny) host Theta update that feeds the next step.
+Metric = candidate-state evaluations per second counted as N x S per step (the BASELINE.json
+headline; the extra candidate evaluations are done but not counted), whole job, all ranks.
+
+Default workload (N=1): BASELINE.json configs[1], "ES3C synthetic Gaussian D=256, H=128, S=64,
+N=10k, float64".  With more GPUs every rank keeps that shard size (weak scaling).
+
+One JSON line is printed by rank 0; it also carries
+  roofline      the dominant kernel (lpj over K^n) against the HBM roof, duration from HIP events on
+                the library's stream inside the timed region
+  cpu_baseline  the loop-faithful NumPy restatement of the reference (oracle/, "port") timed on
+                this box's host cores on a bounded sample of the same workload (N=1 only)
+No PyTorch anywhere: ranks find each other through RANK/WORLD_SIZE/LOCAL_RANK set by the launcher
+and share the RCCL id through a file (evo_amd.utils.parallel).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {  # BASELINE.json "configs", per-GPU shard sizes
+    "c1": dict(algo="ebsc", D=25, H=10, S=32, N=500, name="bars-test EBSC D=25 H=10 S=32 N=500"),
+    "c2": dict(algo="es3c", D=256, H=128, S=64, N=10000, name="ES3C synthetic Gaussian D=256 H=128 S=64 N=10k f64"),
+    "c3": dict(algo="ebsc", D=64, H=256, S=128, N=50000, name="EBSC 8x8 patches D=64 H=256 S=128 N=50k f64"),
+    "c4": dict(algo="es3c", D=256, H=512, S=200, N=12500, name="ES3C D=256 H=512 S=200 N=100k/8 per GPU f64"),
+    "c4full": dict(algo="es3c", D=256, H=512, S=200, N=100000, name="ES3C D=256 H=512 S=200 N=100k on one GPU f64"),
+    "c5": dict(algo="ebsc", D=256, H=1024, S=256, N=25000, name="EBSC D=256 H=1024 S=256 N=200k/8 per GPU (f64)"),
+}
+EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes_lpj(cfg, N):
+    """lpj pass, per datapoint D*w + C*(ceil(H/8) + w) with w = 8, C = S."""
+    return N * (cfg["D"] * 8 + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
+
+
+def make_problem(cfg, seed, model):
+    from evo_amd.variational import init_states
+    np.random.seed(seed)
+    Y = np.random.randn(cfg["N"], cfg["D"])
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(cfg["N"], cfg["S"], cfg["H"], EA["parent_selection"], EA["mutation"], EA["n_parents"],
+                       EA["n_children"], EA["n_generations"])
+    return my_data, theta, suff
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (NumPy restatement of the reference loops), one process per core
+# ---------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    algo, D, H, S, n, seed, reps = args
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    import numpy as np  # noqa: F811
+    from oracle import evo_oracle as orc
+    np.random.seed(seed)
+    Y = np.random.randn(n, D)
+    if algo == "ebsc":
+        theta = orc.check_params(orc.bsc_standard_init(Y, H), orc.BSC_POLICY)
+    else:
+        theta = orc.check_params(orc.sssc_standard_init(Y, H), orc.SSSC_POLICY)
+    suff = orc.init_states(n, S, H, "fit", "randflip", 10, 1, 1)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        # the per-datapoint loops only (E-step + sufficient statistics); the Theta solve is left out
+        # because a small sample (N < H) makes it singular -- it is O(H^3) once per step, negligible
+        if algo == "ebsc":
+            orc.bsc_E_step(theta, suff, Y)
+            orc.bsc_accumulate(theta, suff, Y)
+        else:
+            # use_storage=False: the reference's only memory-scalable mode
+            orc.sssc_EM_accumulate(theta, suff, Y, use_storage=False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Time the oracle on a bounded sample (about budget_s seconds of wall time): every core runs
+    the reference-style per-datapoint loop on its own shard, like one MPI rank per core."""
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 16)
+    # probe one datapoint-step cost on one core, then size the sample
+    t_probe = _cpu_worker((cfg["algo"], cfg["D"], cfg["H"], cfg["S"], 2, 99, 1)) / 2
+    per_core = int(max(2, min(64, (budget_s / 2.0) / max(t_probe, 1e-4))))
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    ctx = mp.get_context("spawn")
+    jobs = [(cfg["algo"], cfg["D"], cfg["H"], cfg["S"], per_core, 1234 + i, 2) for i in range(cores)]
+    with ctx.Pool(cores) as pool:
+        times = pool.map(_cpu_worker, jobs)
+    t = max(times)
+    n_sub = per_core * cores
+    return {
+        "value": n_sub * cfg["S"] / t, "unit": "N*S state evals/s", "cores": cores, "kind": "port",
+        "sample": "oracle EM step (reference loop structure, use_storage=False) on %d datapoints (%d per core, "
+                  "%d processes, OPENBLAS_NUM_THREADS=1), best of 2, %.2f s; cost is linear in N" % (n_sub, per_core, cores, t),
+        "ms_per_datapoint_per_core": 1e3 * t / per_core,
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with one process per GPU "
+                     "(python -m torch.distributed.run --nproc-per-node %d bench.py ...)" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    # CPU baseline first: it forks worker processes and must run before HIP is initialised
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.cpu_seconds)
+
+    from evo_amd.engine import Engine
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.utils import parallel
+
+    eng = Engine()  # LOCAL_RANK selects the GPU
+    comm = parallel.init_rccl_from_env(eng)
+    cls = BSC if cfg["algo"] == "ebsc" else SSSC
+    model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17)
+    my_data, theta, suff = make_problem(cfg, 1234 + 2 + 1000 * rank, model)
+    if world > 1:  # every rank must start from the same Theta (the reference broadcasts rank 0's)
+        theta = {k: comm.bcast(v) for k, v in theta.items()}
+
+    def barrier():
+        eng.synchronize()
+        comm.Barrier()
+        eng.synchronize()
+
+    F = None
+    for _ in range(args.warmup):
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+    eng.timing(True)
+    eng.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = comm.allreduce_max(dt)
+    kernel_ms = {}
+    for name in ("lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse", "vary_kn", "stats", "stats_overflow",
+                 "gemm_f64", "evolve", "misc"):
+        avg, n = eng.kernel_time_ms(name)
+        if n:
+            kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_step": n / max(1, args.steps)}
+    eng.timing(False)
+
+    if rank == 0:
+        N_tot = cfg["N"] * world
+        evals = N_tot * cfg["S"] * args.steps
+        lpj_ms = kernel_ms.get("lpj_resident", {}).get("avg_ms", 0.0)
+        alg_bytes = algorithmic_bytes_lpj(cfg, cfg["N"])
+        achieved = (alg_bytes / (lpj_ms * 1e-3) / 1e9) if lpj_ms > 0 else 0.0
+        out = {
+            "metric": "E-step candidate-state evals/sec (NxS), full EM iteration", "value": evals / dt,
+            "unit": "state evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_per_gpu": cfg["N"], "N_total": N_tot,
+                       "D": cfg["D"], "H": cfg["H"], "S": cfg["S"], "ea": "fit/randflip 10 parents x 1 child x 1 gen",
+                       "rng": "device", "parallelism": "dp%d" % world, "free_energy_last": F,
+                       "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms},
+            "roofline": {"bound": "hbm", "kernel": "sssc_small_kernel<4,0> (lpj over K^n)" if cfg["algo"] == "es3c"
+                         else "bsc_lpj_kernel (lpj over K^n)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        comm.Barrier()
+        comm.close()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,12 +113,16 @@ struct TimedSpan {
 struct evoamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool configured = false, have_data = false, have_params = false, have_cand = false;
+  bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
   int model = 0;
   i64 N = 0;
   int D = 0, H = 0, S = 0, S_perm = 0, Cmax = 0, HW = 0, L = 0;
   // data
-  double *Y = nullptr, *yy = nullptr, *y2sum = nullptr;
+  double *Y = nullptr, *yy = nullptr, *y2sum = nullptr;  // SSSC: Y is the left block of [Y | Es | Ez], row stride ldY
+  int ldY = 0;
+  double *h_acc = nullptr, *h_par = nullptr;  // pinned host staging (accumulator D2H, Theta H2D)
+  size_t h_par_n = 0;
+  int *h_err = nullptr;
   // variational state
   u64 *states = nullptr, *cand = nullptr;
   double *lpj = nullptr, *cand_lpj = nullptr;
@@ -136,7 +140,7 @@ struct evoamd_ctx {
   // statistics
   double *acc = nullptr;
   i64 acc_n = 0;
-  double *Es = nullptr, *Ez = nullptr;
+  double *Es = nullptr;  // BSC: (N,H); SSSC: columns D..D+H of c->Y (Ez follows)
   int *list1 = nullptr, *list2 = nullptr, *list_n = nullptr, *err = nullptr;
   // scratch for single / shared evaluations
   double *tmp_y = nullptr, *tmp_lpj = nullptr;
@@ -212,6 +216,15 @@ static int dev_alloc(T **p, size_t n) {
 
 static inline unsigned cdiv(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
 
+// out[c] += sum_r X[r][c] (out must be zeroed by the caller); SQUARE sums squares.
+template <bool SQUARE>
+static void launch_colsum(evoamd_ctx *c, const double *X, int ldx, i64 R, int Cn, double *out) {
+  const i64 rpb = 256;
+  dim3 grid(cdiv(Cn, 64), cdiv(R, rpb));
+  colsum_f64<SQUARE><<<grid, 256, 0, c->stream>>>(X, ldx, R, Cn, rpb, out);
+}
+
+
 // ---------------------------------------------------------------------------------------
 // library / context
 // ---------------------------------------------------------------------------------------
@@ -257,10 +270,13 @@ static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
-                  c->acc,    c->Es,     c->Ez,      c->list1,   c->list2,    c->list_n,    c->err,
+                  c->acc,    c->Es,     c->list1,   c->list2,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->h_acc) (void)hipHostFree(c->h_acc);
+  if (c->h_par) (void)hipHostFree(c->h_par);
+  if (c->h_err) (void)hipHostFree(c->h_err);
 }
 
 extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
@@ -311,10 +327,10 @@ static AccLayout acc_layout(const evoamd_ctx *c) {
     a.xss = H;
     a.xsz = a.xss + H * H;
     a.xszsz = a.xsz + H;
-    a.s_sz = a.xszsz + H * H;
+    a.sWp = a.xszsz + H * H;  // Wp | s_sz_outer | sz_sz_outer are one (D+2H) x H GEMM output
+    a.s_sz = a.sWp + D * H;
     a.sz_sz = a.s_sz + H * H;
-    a.sWp = a.sz_sz + H * H;
-    a.y2 = a.sWp + D * H;
+    a.y2 = a.sz_sz + H * H;
     a.tail = a.y2 + D;
   }
   return a;
@@ -340,7 +356,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->HW = (H + 63) / 64;
   c->L = S + S_perm;
   const i64 HW = c->HW;
-  ALLOC(c->Y, (size_t)N * D);
+  c->ldY = (model == EVOAMD_MODEL_SSSC) ? D + 2 * H : D;
+  ALLOC(c->Y, (size_t)N * c->ldY);
   ALLOC(c->yy, (size_t)N);
   ALLOC(c->y2sum, (size_t)D);
   ALLOC(c->states, (size_t)N * S * HW);
@@ -357,7 +374,12 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->stage_bytes = (size_t)N * SC * H;
   ALLOC(c->stage, c->stage_bytes);
   ALLOC(c->W, (size_t)D * H);
-  ALLOC(c->Es, (size_t)N * H);
+  if (model == EVOAMD_MODEL_BSC) {
+    ALLOC(c->Es, (size_t)N * H);
+  } else {
+    if (c->Es) { (void)hipFree(c->Es); }
+    c->Es = nullptr;  // lives inside c->Y for SSSC
+  }
   c->acc_n = acc_len(c);
   ALLOC(c->acc, (size_t)c->acc_n);
   ALLOC(c->err, 4);
@@ -370,11 +392,17 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->Bm, (size_t)N * H);
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
-    ALLOC(c->Ez, (size_t)N * H);
     ALLOC(c->list1, (size_t)N * SC);
     ALLOC(c->list2, (size_t)N * SC);
     ALLOC(c->list_n, 4);
   }
+  if (c->h_acc) (void)hipHostFree(c->h_acc);
+  if (c->h_par) (void)hipHostFree(c->h_par);
+  if (!c->h_err) HIP_TRY(hipHostMalloc((void **)&c->h_err, 4 * sizeof(int), hipHostMallocDefault));
+  c->h_par_n = (size_t)D * H + (size_t)H * H + 2 * (size_t)H;
+  HIP_TRY(hipHostMalloc((void **)&c->h_acc, (size_t)c->acc_n * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_par, c->h_par_n * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipMemsetAsync(c->Y, 0, (size_t)N * c->ldY * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
   HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
@@ -389,17 +417,17 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
   REQUIRE(c && c->configured, "configure first");
   REQUIRE(Y, "Y is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpyAsync(c->Y, Y, (size_t)c->N * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  row_sqnorm_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->Y, c->N, c->D, c->yy);
+  HIP_TRY(hipMemcpy2DAsync(c->Y, (size_t)c->ldY * sizeof(double), Y, (size_t)c->D * sizeof(double),
+                           (size_t)c->D * sizeof(double), (size_t)c->N, hipMemcpyHostToDevice, c->stream));
+  row_sqnorm_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->yy);
   HIP_TRY(hipMemsetAsync(c->y2sum, 0, (size_t)c->D * sizeof(double), c->stream));
   {
-    const i64 rpb = 2048;
-    dim3 grid(cdiv(c->D, 256), cdiv(c->N, rpb));
-    colsum_f64<true><<<grid, 256, 0, c->stream>>>(c->Y, c->D, c->N, c->D, rpb, c->y2sum);
+    launch_colsum<true>(c, c->Y, c->ldY, c->N, c->D, c->y2sum);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_data = true;
+  c->B_valid = false;
   return 0;
 }
 
@@ -496,11 +524,14 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   c->ljc = c->H * log(1.0 - pi) - c->D / 2.0 * log(2 * M_PI * sigma * sigma);
   if (ljc) *ljc = c->ljc;
   // W^T on the host (H x D); tiny
-  std::vector<double> wt((size_t)c->H * c->D);
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned staging area may still be in flight
+  double *wt = c->h_par;                      // D*H doubles
   for (int d = 0; d < c->D; d++)
     for (int h = 0; h < c->H; h++) wt[(size_t)h * c->D + d] = W[(size_t)d * c->H + h];
-  HIP_TRY(hipMemcpyAsync(c->W, W, (size_t)c->D * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->Wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->Wt, wt, (size_t)c->H * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(wt, W, (size_t)c->D * c->H * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(c->W, wt, (size_t)c->D * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_params = true;
   return 0;
@@ -510,7 +541,6 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
                                       const double *Psi, double sigma2, double *ljc) {
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_SSSC, "context is not configured for SSSC");
   REQUIRE(W && pies && mus && Psi, "NULL parameter array");
-  REQUIRE(c->have_data, "upload_data before set_params_sssc (B = Y W is part of the precompute)");
   HIP_TRY(hipSetDevice(c->device));
   const int H = c->H, D = c->D;
   // sssc.py:340-353: sigma2 through long double, rounded back to double
@@ -532,19 +562,38 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   l -= 0.5 * (D * (double)logl(s2));
   c->ljc = l;
   if (ljc) *ljc = l;
-  HIP_TRY(hipMemcpyAsync(c->W, W, (size_t)D * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->mus, mus, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->pilbar_v, pb.data(), (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->Psi, Psi, (size_t)H * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // pb is a host temporary
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned staging area may still be in flight
+  {
+    double *hw = c->h_par, *hpsi = hw + (size_t)D * H, *hmu = hpsi + (size_t)H * H, *hpb = hmu + H;
+    memcpy(hw, W, (size_t)D * H * sizeof(double));
+    memcpy(hpsi, Psi, (size_t)H * H * sizeof(double));
+    memcpy(hmu, mus, (size_t)H * sizeof(double));
+    memcpy(hpb, pb.data(), (size_t)H * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c->W, hw, (size_t)D * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->Psi, hpsi, (size_t)H * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->mus, hmu, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pilbar_v, hpb, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
   int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
   if (r) return r;
   interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP);
   HIP_TRY(hipGetLastError());
-  r = launch_gemm_nn(c, c->Y, D, c->W, H, c->Bm, H, c->N, H, D);  // B = Y W
-  if (r) return r;
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->B_valid = false;
+  if (c->have_data) {
+    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);  // B = Y W
+    if (r) return r;
+    c->B_valid = true;
+  }
   c->have_params = true;
+  return 0;
+}
+
+// B = Y W depends on both the data and Theta; recompute it if either arrived later.
+static int ensure_B(evoamd_ctx *c) {
+  if (c->model != EVOAMD_MODEL_SSSC || c->B_valid) return 0;
+  int r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
+  if (r) return r;
+  c->B_valid = true;
   return 0;
 }
 
@@ -639,8 +688,8 @@ static int launch_lpj(evoamd_ctx *c, const Batch &b) {
 }
 
 static int check_err(evoamd_ctx *c) {
-  int e[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(e, c->err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+  int *e = c->h_err;
+  HIP_TRY(hipMemcpyAsync(e, c->err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (e[0]) {
     HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
@@ -653,6 +702,10 @@ static int check_err(evoamd_ctx *c) {
 extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int rb = ensure_B(c);
+    if (rb) return rb;
+  }
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
   if (c->S_perm) {
     const double pre = (c->model == EVOAMD_MODEL_BSC) ? c->pre1 : -0.5 * c->s2inv;
@@ -660,14 +713,14 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
     HIP_TRY(hipGetLastError());
   }
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES};
-  int r = launch_lpj(c, b);
-  if (r) return r;
-  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  return launch_lpj(c, b);  // stream-ordered; device-side errors surface at the next host-returning call
 }
 
 static int eval_candidates(evoamd_ctx *c) {
+  {
+    int rb = ensure_B(c);
+    if (rb) return rb;
+  }
   Batch b = {c->cand, c->cand_counts, c->Y, c->Bm, c->yy, c->N, c->Cmax, 0, c->cand_lpj, c->Cmax, 0,
              c->flags + c->N, KID_LPJ_CAND};
   return launch_lpj(c, b);
@@ -708,6 +761,15 @@ extern "C" int evoamd_set_candidates(evoamd_ctx *c, const uint8_t *cand_bool, co
   return 0;
 }
 
+static int ensure_stage(evoamd_ctx *c, size_t bytes) {
+  if (bytes > c->stage_bytes) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ALLOC(c->stage, bytes);
+    c->stage_bytes = bytes;
+  }
+  return 0;
+}
+
 static int ensure_tmp(evoamd_ctx *c, size_t state_words, size_t lpj_n) {
   if (state_words > c->tmp_states_words) {
     ALLOC(c->tmp_states, state_words);
@@ -726,6 +788,8 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
   REQUIRE((i64)c->N * C < 2147483647LL, "N * C must fit in int32");
   HIP_TRY(hipSetDevice(c->device));
   int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)c->N * C);
+  if (r) return r;
+  r = ensure_B(c);
   if (r) return r;
   // stage through a private buffer (C*H may exceed the configured staging area)
   uint8_t *st = nullptr;
@@ -767,14 +831,15 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
   int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)C + 2);
   if (r) return r;
   if (!c->tmp_y) ALLOC(c->tmp_y, (size_t)c->D + c->H + 2);
-  if ((size_t)C * c->H > c->stage_bytes) return fail(EVOAMD_E_INVALID, "too many states for lpj_single");
+  r = ensure_stage(c, (size_t)C * c->H);
+  if (r) return r;
   double *dy = c->tmp_y, *db = c->tmp_y + c->D, *dyy = c->tmp_y + c->D + c->H;
   unsigned *dfl = (unsigned *)(c->tmp_lpj + C);
   HIP_TRY(hipMemcpyAsync(dy, y, (size_t)c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->stage, states_bool, (size_t)C * c->H, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(dfl, 0, sizeof(unsigned), c->stream));
   pack_states_kernel<<<cdiv((i64)C * c->HW, 256), 256, 0, c->stream>>>(c->stage, c->tmp_states, C, c->H, c->HW);
-  row_sqnorm_kernel<<<1, 256, 0, c->stream>>>(dy, 1, c->D, dyy);
+  row_sqnorm_kernel<<<1, 256, 0, c->stream>>>(dy, c->D, 1, c->D, dyy);
   if (c->model == EVOAMD_MODEL_SSSC) {
     r = launch_gemm_nn(c, dy, c->D, c->W, c->H, db, c->H, 1, c->H, c->D);
     if (r) return r;
@@ -874,7 +939,9 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   // keep tail[1..2] (E-step counts written by vary_kn / set_estep_counts); zero everything else
   HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)(a.tail + 1) * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->acc + a.tail + 3, 0, 5 * sizeof(double), c->stream));
-  int r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
+  int r = ensure_B(c);
+  if (r) return r;
+  r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
   if (r) return r;
   if (c->model == EVOAMD_MODEL_BSC) {
     {
@@ -882,47 +949,67 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
       bsc_stats_kernel<<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(
           c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->pre1, c->pil_bar, c->Es,
           c->acc + a.Wq, c->partial);
-      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.sigma, 0);
-      const i64 rpb = 1024;
-      colsum_f64<false><<<dim3(cdiv(H, 256), cdiv(N, rpb)), 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->acc + a.pies);
       HIP_TRY(hipGetLastError());
     }
-    r = launch_gemm_tn(c, c->Es, H, c->Y, D, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
+    {
+      SpanGuard g(c, KID_MISC);
+      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.sigma, 0);
+      launch_colsum<false>(c, c->Es, H, N, H, c->acc + a.pies);
+      finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, H);
+      HIP_TRY(hipGetLastError());
+    }
+    r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
     if (r) return r;
   } else {
-    HIP_TRY(hipMemsetAsync(c->Es, 0, (size_t)N * H * sizeof(double), c->stream));
-    HIP_TRY(hipMemsetAsync(c->Ez, 0, (size_t)N * H * sizeof(double), c->stream));
+    double *Es = c->Y + D, *Ez = c->Y + D + H;  // columns of [Y | Es | Ez]
     Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS};
     SsscArgs sa = sssc_args(c, b);
     sa.lpj_in = c->lpj;
     sa.rowmax = c->rowmax;
     sa.rowsum = c->rowsum;
-    sa.Es = c->Es;
-    sa.Ez = c->Ez;
+    sa.Es = Es;
+    sa.Ez = Ez;
+    sa.ldE = c->ldY;
     sa.xss = c->acc + a.xss;
     sa.xszsz = c->acc + a.xszsz;
-    r = launch_sssc<1>(c, sa, KID_STATS, KID_STATS_OVF);
-    if (r) return r;
+    HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * sizeof(int), c->stream));
+    {
+      // workgroups own whole datapoints; rows of Es / Ez staged in LDS (<= 64 KiB)
+      int npb = 256 / c->S;
+      if (npb < 1) npb = 1;
+      const int cap = (int)(65536 / ((size_t)16 * H));
+      if (npb > cap) npb = cap < 1 ? 1 : cap;
+      const size_t lds = (size_t)npb * 2 * H * sizeof(double);
+      SpanGuard g(c, KID_STATS);
+      sssc_stats_kernel<4><<<cdiv(N, npb), 256, lds, c->stream>>>(sa, npb, c->list1, c->list_n + 0);
+      HIP_TRY(hipGetLastError());
+    }
+    {
+      SpanGuard g(c, KID_STATS_OVF);
+      const i64 total = N * (i64)c->S;
+      unsigned grid = cdiv(total, 256);
+      if (grid > 1024) grid = 1024;
+      sssc_small_kernel<8, 1><<<grid, 256, 0, c->stream>>>(sa, c->list1, c->list_n + 0, c->list2, c->list_n + 1);
+      unsigned gridb = (unsigned)(total < 2048 ? total : 2048);
+      sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, c->list2, c->list_n + 1);
+      HIP_TRY(hipGetLastError());
+    }
     {
       SpanGuard g(c, KID_MISC);
-      const i64 rpb = 1024;
-      dim3 grid(cdiv(H, 256), cdiv(N, rpb));
-      colsum_f64<false><<<grid, 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->acc + a.xs);
-      colsum_f64<false><<<grid, 256, 0, c->stream>>>(c->Ez, H, N, H, rpb, c->acc + a.xsz);
+      launch_colsum<false>(c, Es, c->ldY, N, H, c->acc + a.xs);
+      launch_colsum<false>(c, Ez, c->ldY, N, H, c->acc + a.xsz);
+      finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xs, H);
       HIP_TRY(hipMemcpyAsync(c->acc + a.y2, c->y2sum, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       HIP_TRY(hipGetLastError());
     }
-    r = launch_gemm_tn(c, c->Y, D, c->Ez, H, c->acc + a.sWp, H, D, H, N);  // Wp = Y^T Ez (D,H)
-    if (r) return r;
-    r = launch_gemm_tn(c, c->Es, H, c->Ez, H, c->acc + a.s_sz, H, H, H, N);  // sum_n xpt_s (x) xpt_sz
-    if (r) return r;
-    r = launch_gemm_tn(c, c->Ez, H, c->Ez, H, c->acc + a.sz_sz, H, H, H, N);  // sum_n xpt_sz (x) xpt_sz
+    // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
+    r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N);
     if (r) return r;
   }
   // tail: N and the reset counters (per-call priority semantics)
   {
-    const double nval = (double)N;
-    HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 3, &nval, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->h_acc[0] = (double)N;
+    HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 3, c->h_acc, sizeof(double), hipMemcpyHostToDevice, c->stream));
     for (int k = 0; k < 3; k++)
       count_flags_kernel<<<64, 256, 0, c->stream>>>(c->flags + (size_t)k * N, N, c->acc + a.tail + 4);
     HIP_TRY(hipGetLastError());
@@ -930,12 +1017,12 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
-  HIP_TRY(hipMemcpyAsync(acc_out, c->acc, (size_t)c->acc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc, (size_t)c->acc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   // the E-step counts have been consumed
   HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
-  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  return 0;
+  r = check_err(c);  // synchronises the stream
+  memcpy(acc_out, c->h_acc, (size_t)c->acc_n * sizeof(double));
+  return r;
 }
 
 extern "C" int evoamd_free_energy(evoamd_ctx *c, const double *lpj, int64_t N, int C, double *Fs_out) {

@@ -140,18 +140,23 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
       }
 }
 
-// out[c] = sum_r X[r][c]   (column sums of an (R x Cn) row-major matrix; optional square)
+// out[c] += sum_r X[r][c]   (column sums of an (R x Cn) row-major matrix; optional square).
+// Block = 4 row-lanes x 64 columns over a slab of rows_per_block rows; one atomic per column per block.
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void colsum_f64(const double *__restrict__ X, int ldx, i64 R, int Cn,
                                                   i64 rows_per_block, double *__restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const i64 r0 = (i64)blockIdx.y * rows_per_block;
   const i64 r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-  if (c >= Cn) return;
   double s = 0.0;
-  for (i64 r = r0; r < r1; r++) {
-    double v = X[r * ldx + c];
-    s += SQUARE ? v * v : v;
-  }
-  unsafeAtomicAdd(&out[c], s);
+  if (c < Cn)
+    for (i64 r = r0 + rl; r < r1; r += 4) {
+      const double v = X[r * ldx + c];
+      s += SQUARE ? v * v : v;
+    }
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < Cn) unsafeAtomicAdd(&out[c], ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]);
 }

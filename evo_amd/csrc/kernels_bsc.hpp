@@ -108,14 +108,14 @@ __global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restri
 }
 
 // yy_n = sum_d y_nd^2, one wavefront per n.
-__global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restrict__ Y, i64 N, int D,
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restrict__ Y, int ldy, i64 N, int D,
                                                          double *__restrict__ yy) {
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;
   if (n >= N) return;
   double s = 0.0;
   for (int d = lane; d < D; d += 64) {
-    double v = Y[n * D + d];
+    double v = Y[n * ldy + d];
     s += v * v;
   }
   s = wave_sum(s);
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restric
 //   q_s = exp(lpj_s + B_n) / sum_s' exp(lpj_s' + B_n)
 //   Es[n][h]  = sum_s q_s s_h                      -> written to the (N,H) matrix Es; the dense
 //                                                     Wp = Es^T Y and pies = colsum(Es) follow
-//   Wq[h][h'] += sum_s q_s s_h s_h'                -> f64 hardware atomics on the (H,H) matrix
+//   Wq[h][h'] += sum_s q_s s_h s_h'  (h < h')       -> f64 hardware atomics, strict upper triangle;
+//                                                     Wq[h][h] = pies[h] and the mirror are filled afterwards
 //   sigma     += sum_s q_s ||y - W s||^2, with ||y - W s||^2 = (lpj_s - pil_bar |s|)/pre1
 //                (exact inverse of the lpj kernel's last line; no second pass over W)
 //   plus the all-zero permanent state's q_0 ||y||^2 (bsc.py:206-207).
@@ -163,12 +164,18 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
         while (bits) {
           const int h = w * 64 + pop_msb(bits);
           unsafeAtomicAdd(&es[h], q);
-          // row h of Wq gets q_n at every active column
-          for (int w2 = 0; w2 < HW; w2++) {
-            u64 b2 = sp[w2];
-            while (b2) {
-              const int h2 = w2 * 64 + pop_msb(b2);
-              unsafeAtomicAdd(&Wq[(i64)h * H + h2], qn);
+          // strict upper triangle only: Wq is symmetric and Wq[h][h] = pies[h]
+          // (finish_sym_kernel mirrors it and fills the diagonal)
+          {
+            u64 b2 = bits;  // the not-yet-visited (higher) latents of this word ...
+            int w2 = w;
+            for (;;) {
+              while (b2) {
+                const int h2 = w2 * 64 + pop_msb(b2);
+                unsafeAtomicAdd(&Wq[(i64)h * H + h2], qn);
+              }
+              if (++w2 >= HW) break;
+              b2 = sp[w2];  // ... and all of the following words
             }
           }
         }

@@ -43,7 +43,8 @@ struct SsscArgs {
   // STATS mode
   const double *lpj_in;  // (N, ldo) rows incl. permanent column
   const double *rowmax, *rowsum;
-  double *Es, *Ez;        // (N,H) zero-initialised
+  double *Es, *Ez;        // (N, ldE) rows of first moments xpt_s / xpt_sz per datapoint
+  int ldE;
   double *xss, *xszsz;    // (H,H) zero-initialised
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
 };
@@ -124,7 +125,110 @@ __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K],
   }
 }
 
-// MODE 0: lpj, MODE 1: statistics.  list_in == nullptr: natural order over N*C pairs.
+// Per-(datapoint, state) evaluation with the k x k system in registers (k <= K).
+// MODE 0: returns lpj in `val`.  MODE 1: also leaves kappa in `kap` and Lam = T^-1 Psi in `P`.
+template <int K, int MODE>
+__device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u64 *sp, int (&idx)[K], int &k,
+                                               double &val, double (&kap)[K], double (&P)[K][K], bool &singular) {
+#pragma unroll
+  for (int i = 0; i < K; i++) idx[i] = 0;
+  k = 0;
+  for (int w = 0; w < a.HW; w++) {
+    u64 bits = sp[w];
+    while (bits) {
+      const int h = w * 64 + pop_msb(bits);
+#pragma unroll
+      for (int i = 0; i < K; i++)
+        if (i == k) idx[i] = h;
+      k++;
+    }
+  }
+  double b[K], mu[K], v[K], wv[K];
+  double G[K][K], T[K][K];
+  double pb = 0.0;
+  const double *Bn = a.Bm + n * a.H;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    const bool on = i < k;
+    b[i] = on ? Bn[idx[i]] : 0.0;
+    mu[i] = on ? a.mus[idx[i]] : 0.0;
+    pb += on ? a.pil_bar[idx[i]] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < K; i++)
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (i < k && j < k) {
+        const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
+        G[i][j] = gp.x;
+        P[i][j] = gp.y;
+      } else {
+        G[i][j] = 0.0;
+        P[i][j] = (i == j) ? 1.0 : 0.0;
+      }
+    }
+  double rr = a.yy[n];
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int j = 0; j < K; j++) s -= G[i][j] * mu[j];
+    v[i] = s;
+    rr -= mu[i] * (b[i] + s);
+  }
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; j++) s += P[i][j] * v[j];
+    wv[i] = s;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      double tt = 0.0;
+#pragma unroll
+      for (int l = 0; l < K; l++) tt += P[i][l] * G[l][j];
+      T[i][j] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+    }
+  }
+  double logdet;
+  lu_solve_regs<K>(T, wv, P, MODE == 1, logdet, singular);
+  if (MODE == 0) {
+    double quad = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) quad += v[i] * wv[i];
+    val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; i++) kap[i] = wv[i] * a.s2inv + mu[i];
+  }
+}
+
+// Scatter of the second moments of one state (sssc.py:576-595).  xpt_ss is symmetric with
+// diagonal xpt_ss[h][h] = xpt_s[h], so only the strict upper triangle is accumulated here and
+// finish_sym_kernel mirrors it and fills the diagonal from xpt_s; xpt_szsz needs every entry
+// (Lam is not symmetric once Psi is not).
+template <int K>
+__device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&idx)[K], int k, double qn,
+                                                const double (&kap)[K], const double (&P)[K][K]) {
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    if (i < k) {
+#pragma unroll
+      for (int j = 0; j < K; j++) {
+        if (j < k) {
+          const i64 o = (i64)idx[i] * a.H + idx[j];
+          if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
+          unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
+        }
+      }
+    }
+  }
+}
+
+// lpj (MODE 0) or statistics (MODE 1) of the pairs in natural order (list_in == nullptr, N*C
+// pairs) or of an overflow list.  Pairs with more than K active latents are appended to list_out.
+// In MODE 1 this kernel adds into Es / Ez with global atomics (used for the overflow lists only;
+// the main statistics pass is sssc_stats_kernel below).
 template <int K, int MODE>
 __global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *__restrict__ list_in,
                                                          const int *__restrict__ n_in,
@@ -151,100 +255,91 @@ __global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *
       if (q == 0.0) continue;
       qn = q / (a.rowsum[n] + EVO_F64_TINY);
     }
-    int idx[K];
-#pragma unroll
-    for (int i = 0; i < K; i++) idx[i] = 0;
-    int k = 0;
-    for (int w = 0; w < a.HW; w++) {
-      u64 bits = sp[w];
-      while (bits) {
-        const int h = w * 64 + pop_msb(bits);
-#pragma unroll
-        for (int i = 0; i < K; i++)
-          if (i == k) idx[i] = h;
-        k++;
-      }
-    }
-    double b[K], mu[K], v[K], wv[K];
-    double G[K][K], P[K][K], T[K][K];
-    double pb = 0.0;
-    const double *Bn = a.Bm + n * a.H;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      const bool on = i < k;
-      b[i] = on ? Bn[idx[i]] : 0.0;
-      mu[i] = on ? a.mus[idx[i]] : 0.0;
-      pb += on ? a.pil_bar[idx[i]] : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < K; i++)
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (i < k && j < k) {
-          const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
-          G[i][j] = gp.x;
-          P[i][j] = gp.y;
-        } else {
-          G[i][j] = 0.0;
-          P[i][j] = (i == j) ? 1.0 : 0.0;
-        }
-      }
-    double rr = a.yy[n];
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      double s = b[i];
-#pragma unroll
-      for (int j = 0; j < K; j++) s -= G[i][j] * mu[j];
-      v[i] = s;
-      rr -= mu[i] * (b[i] + s);
-    }
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < K; j++) s += P[i][j] * v[j];
-      wv[i] = s;
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        double tt = 0.0;
-#pragma unroll
-        for (int l = 0; l < K; l++) tt += P[i][l] * G[l][j];
-        T[i][j] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
-      }
-    }
-    double logdet;
+    int idx[K], k;
+    double val = 0.0, kap[K], P[K][K];
     bool singular = false;
-    lu_solve_regs<K>(T, wv, P, MODE == 1, logdet, singular);
+    sssc_eval_regs<K, MODE>(a, n, sp, idx, k, val, kap, P, singular);
     if (singular) atomicOr(a.err, 2);
     if (MODE == 0) {
-      double quad = 0.0;
-#pragma unroll
-      for (int i = 0; i < K; i++) quad += v[i] * wv[i];
-      const double val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
       unsigned fl = 0;
       a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
       if (fl) atomicOr(&a.flags[n], fl);
     } else {
-      double kap[K];
-#pragma unroll
-      for (int i = 0; i < K; i++) kap[i] = wv[i] * a.s2inv + mu[i];
 #pragma unroll
       for (int i = 0; i < K; i++) {
         if (i < k) {
-          unsafeAtomicAdd(&a.Es[n * a.H + idx[i]], qn);
-          unsafeAtomicAdd(&a.Ez[n * a.H + idx[i]], qn * kap[i]);
-#pragma unroll
-          for (int j = 0; j < K; j++) {
-            if (j < k) {
-              const i64 o = (i64)idx[i] * a.H + idx[j];
-              unsafeAtomicAdd(&a.xss[o], qn);
-              unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
-            }
-          }
+          unsafeAtomicAdd(&a.Es[n * a.ldE + idx[i]], qn);
+          unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[i]], qn * kap[i]);
         }
       }
+      sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
     }
   }
+}
+
+// Main statistics pass over the resident K^n (sssc.py:553-611): workgroups own whole datapoints
+// (npb = max(1, 256 / S) per workgroup), so the first moments xpt_s / xpt_sz of a datapoint are
+// accumulated in LDS and written as complete rows of Es / Ez with plain coalesced stores -- no
+// memset, no global atomics; only the H x H second moments use global f64 atomics.  States with
+// more than K active latents go to list_out and are added by the overflow kernels afterwards
+// (stream order guarantees their atomics land after the row stores).
+template <int K>
+__global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, int *__restrict__ list_out,
+                                                         int *__restrict__ n_out) {
+  extern __shared__ double rows[];  // npb x 2 x H
+  const i64 n0 = (i64)blockIdx.x * npb;
+  const int nrows = (int)((n0 + npb <= a.N) ? npb : (a.N - n0));
+  for (int i = threadIdx.x; i < nrows * 2 * a.H; i += 256) rows[i] = 0.0;
+  __syncthreads();
+  const int work = nrows * a.C;
+  for (int t = threadIdx.x; t < work; t += 256) {
+    const int r = t / a.C, c = t - r * a.C;
+    const i64 n = n0 + r;
+    const u64 *sp = a.states + (n * (i64)a.C + c) * a.HW;
+    int ktot = 0;
+    for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+    if (ktot > K) {
+      int pos = atomicAdd(n_out, 1);
+      list_out[pos] = (int)(n * a.C + c);
+      continue;
+    }
+    const double l = a.lpj_in[n * a.ldo + a.col0 + c];
+    const double q = exp(l + (0.0 - a.rowmax[n]));
+    if (q == 0.0) continue;
+    const double qn = q / (a.rowsum[n] + EVO_F64_TINY);
+    int idx[K], k;
+    double val = 0.0, kap[K], P[K][K];
+    bool singular = false;
+    sssc_eval_regs<K, 1>(a, n, sp, idx, k, val, kap, P, singular);
+    if (singular) atomicOr(a.err, 2);
+    double *es = rows + (size_t)r * 2 * a.H, *ez = es + a.H;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      if (i < k) {
+        unsafeAtomicAdd(&es[idx[i]], qn);
+        unsafeAtomicAdd(&ez[idx[i]], qn * kap[i]);
+      }
+    }
+    sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrows * a.H; i += 256) {
+    const int r = i / a.H, h = i - r * a.H;
+    a.Es[(n0 + r) * a.ldE + h] = rows[(size_t)r * 2 * a.H + h];
+    a.Ez[(n0 + r) * a.ldE + h] = rows[(size_t)r * 2 * a.H + a.H + h];
+  }
+}
+
+// xpt_ss: mirror the strict upper triangle and put xpt_s on the diagonal.
+__global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xss,
+                                                              const double *__restrict__ xs, int H) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)H * H) return;
+  const int i = (int)(t / H), j = (int)(t - (i64)i * H);
+  if (i == j)
+    xss[t] = xs[i];
+  else if (i > j)
+    xss[t] = xss[(i64)j * H + i];
 }
 
 // One wavefront (64-thread workgroup) per listed pair; k <= SSSC_KCAP; system in LDS.
@@ -413,14 +508,14 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, const int *__r
       if (lane < k) {
         const double kap = wv[lane] * a.s2inv + muv[lane];
         fv[lane] = kap;
-        unsafeAtomicAdd(&a.Es[n * a.H + idx[lane]], qn);
-        unsafeAtomicAdd(&a.Ez[n * a.H + idx[lane]], qn * kap);
+        unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
+        unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
       }
       __syncthreads();
       for (int q = lane; q < k * k; q += 64) {
         const int i = q / k, j = q - i * k;
         const i64 o = (i64)idx[i] * a.H + idx[j];
-        unsafeAtomicAdd(&a.xss[o], qn);
+        if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
         unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
       }
     }

@@ -237,9 +237,9 @@ def acc_layout(model, D, H):
         put("xpt_ss", (H, H))
         put("xpt_sz", (H,))
         put("xpt_szsz", (H, H))
+        put("Wp", (D, H))
         put("s_sz_outer", (H, H))
         put("sz_sz_outer", (H, H))
-        put("Wp", (D, H))
         put("y_outer_diag", (D,))
     for t in TAIL:
         put(t, ())

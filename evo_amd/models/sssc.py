@@ -1,0 +1,181 @@
+"""ES3C = evolutionary E-step + Spike-and-Slab Sparse Coding (reference: evo/models/sssc.py)."""
+import numpy as np
+
+from ._models import Model, small_blas
+from ..utils import parallel
+
+
+class SSSC(Model):
+    model_name = "sssc"
+
+    def __init__(self, D, H, S, use_storage=True, precision=np.float64,
+                 to_learn=("W", "pies", "mus", "sigma2", "Psi"), comm=None, **kwargs):
+        """Same arguments as the reference (sssc.py:18-27).  ``use_storage`` is accepted and ignored:
+        the reference's per-state cache is a pure memo (SURVEY 7 "hard parts"), the kernels
+        recompute the k x k system per (datapoint, state).  ``precision`` must be float64."""
+        if np.dtype(precision) != np.float64:
+            raise NotImplementedError("the reference computes in float64; only float64 is implemented")
+        Model.__init__(self, D, H, S, to_learn, comm, **kwargs)
+        tol = 1e-5
+        self.eps_pjc_sum = np.finfo(np.float64).tiny
+        self.eps_W = 5e-5
+        self.eps_pies = 5e-5
+        self.eps_mus = np.finfo(np.float64).eps
+        self.eps_Psi = tol
+        self.eps_sigma2 = tol
+        self.dtype_precision = np.float64
+        self.use_storage = use_storage
+        self.noise_policy = {  # sssc.py:51-58
+            "W": (-np.inf, +np.inf, False, None),
+            "pies": (tol, 1.0 - tol, False, None),
+            "mus": (-np.inf, +np.inf, False, None),
+            "Psi": (-np.inf, +np.inf, False, tol),
+            "sigma2": (tol, +np.inf, False, None),
+        }
+
+    # ---- generative model (host, off the hot path) -------------------------------------------
+    def generate_from_hidden(self, model_params, my_hdata):
+        """z_A ~ N(mus_A, Psi_AA), y = W_A z_A + N(0, sigma2) (sssc.py:65-102); RNG per datapoint:
+        one multivariate_normal (if any latent is on) then one randn(D)."""
+        W = model_params["W"]
+        D, H = W.shape
+        s = my_hdata["s"]
+        N = s.shape[0]
+        y, y_mean, z = np.zeros((N, D)), np.zeros((N, D)), np.zeros((N, H))
+        sd = np.sqrt(model_params["sigma2"]) * np.ones(D)
+        for n in range(N):
+            on = s[n]
+            if on.sum() > 0:
+                z_n = np.random.multivariate_normal(model_params["mus"][on], model_params["Psi"][on][:, on], 1).ravel()
+                z[n, on] = z_n
+                y_mean[n] = np.dot(np.array(W[:, on], order="C"), z_n[:, None]).ravel()
+            y[n] = y_mean[n] + sd * np.random.randn(D)
+        return {"y": y, "s": s, "z": z, "y_mean": y_mean}
+
+    def standard_init(self, my_data, W_init=None, pi_init=None, sigma_init=None):
+        """Theta^init (sssc.py:104-197, complete data): pies ~ U(0.1,0.5), mus ~ N(0,1) (ones when not
+        learned), Psi = I, sigma2 = mean diag cov + 1e-3, W = data mean + N(0, sigma2/16).  RNG call
+        order as in the reference; the ``"random_uniform"`` choice is overwritten by the
+        following branch there too."""
+        if not my_data["x_infr"].all():
+            raise NotImplementedError("missing data is outside the accelerated path")
+        comm, H, D = self.comm, self.H, self.D
+        Y = my_data["y"]
+        theta = {"pies": comm.bcast(np.random.uniform(low=0.1, high=0.5, size=[H]))}
+        theta["mus"] = comm.bcast(np.random.normal(0, 1, [H])) if "mus" in self.to_learn else comm.bcast(np.ones(H))
+        theta["Psi"] = np.diag(comm.bcast(np.ones(H)))
+        y_mean, _, _ = self._data_moments(my_data)
+        theta["sigma2"] = np.mean(np.diag(np.cov(Y.T))) + 0.001 if sigma_init is None else sigma_init
+        if type(W_init) is not np.ndarray:
+            if W_init == "random_uniform":
+                theta["W"] = comm.bcast(np.random.random((D, H)))
+            if W_init == "normal":
+                theta["W"] = comm.bcast(np.random.normal(0, 5, [D, H]))
+            else:
+                theta["W"] = y_mean[:, None] + np.random.normal(scale=np.sqrt(theta["sigma2"]) / 4.0, size=[D, H])
+        else:
+            theta["W"] = W_init
+        return {k: comm.bcast(v) for k, v in theta.items()} if comm.size > 1 else theta
+
+    def check_params(self, model_params):
+        """Clamp + finiteness asserts (sssc.py:199-222)."""
+        model_params = Model.check_params(self, model_params)
+        if self.comm.rank == 0:
+            for key in ("W", "mus", "pies", "Psi"):
+                assert np.isfinite(model_params[key]).all(), key
+            assert np.isfinite(model_params["sigma2"]) and model_params["sigma2"] > 0
+        return model_params
+
+    # ---- E-step ------------------------------------------------------------------------------
+    def _push_params(self, model_params):
+        self.engine.set_params_sssc(model_params["W"], model_params["pies"], model_params["mus"],
+                                    model_params["Psi"], float(model_params["sigma2"]))
+
+    def E_step_precompute(self, model_params, my_suff_stat, my_data):
+        """State-independent terms (sssc.py:328-366, complete data): ljc, piH, pil_bar, sigma2_inv
+        (through long double like the reference), stored under the reference's keys."""
+        pies, D = model_params["pies"], self.D
+        s2 = np.asarray(model_params["sigma2"]).astype("longdouble")
+        ljc = np.log(1.0 - pies).sum() - D / 2 * np.log(2 * np.pi)
+        model_params["piH"] = pies.sum()
+        model_params["pil_bar"] = np.log(pies / (1.0 - pies))
+        model_params["sigma2_inv"] = (1.0 / s2).astype(np.float64)
+        model_params["ljc"] = ljc - 0.5 * (D * np.log(s2).astype(np.float64))
+        for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf", "Psi_s_pinv"):
+            my_suff_stat[key] = 0
+        if self._engine_matches():
+            self._push_params(model_params)
+
+    def _allzero_lpj(self, model_params, yy):
+        return -0.5 * yy * model_params["sigma2_inv"]  # sssc.py:237
+
+    def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
+        """check_params -> fused EM_step (sssc.py:407-417)."""
+        model_params = self.check_params(model_params)
+        return self.EM_step(model_params, my_suff_stat, my_data, do_reconstruction)
+
+    # ---- M-step ------------------------------------------------------------------------------
+    def update_params(self, model_params, sums, N):
+        """Theta^new from the globally summed statistics (sssc.py:687-770), including the
+        reference's element-wise Psi product whose '+ eps*I' continuation line is a no-op
+         and the sigma2 formula built from first moments and the NEW W.
+        Mutates and returns ``model_params``."""
+        H, D = self.H, self.D
+        learn = self.to_learn
+        if "W" in learn:
+            try:
+                W_new = np.dot(sums["Wp"], np.linalg.inv(sums["xpt_szsz"]))
+            except np.linalg.LinAlgError:
+                try:
+                    noise = np.random.normal(0, self.eps_W, H)
+                    W_new = np.dot(sums["Wp"], np.linalg.pinv(sums["xpt_szsz"] + np.outer(noise, noise)))
+                    parallel.pprint("Use pinv and additional noise for W update.", self.comm)
+                except np.linalg.LinAlgError:
+                    W_new = model_params["W"] + (self.eps_W * np.random.normal(0, 1, [D, H]))
+                    parallel.pprint("Skipped W update. Added some noise to it.", self.comm)
+            model_params["W"] = W_new
+        if "pies" in learn:
+            pies_new = np.array(sums["xpt_s"]) / N
+            pies_new[pies_new <= self.eps_pies] = self.eps_pies
+            pies_new[pies_new >= (1 - self.eps_pies)] = 1 - self.eps_pies
+            model_params["pies"] = pies_new
+        if "mus" in learn:
+            model_params["mus"] = sums["xpt_sz"] * 1.0 / (sums["xpt_s"] + self.eps_mus)
+        if "Psi" in learn:
+            mus = model_params["mus"]
+            Psi = np.zeros((H, H))
+            Psi += np.outer(mus, mus) * sums["xpt_ss"]
+            Psi += sums["xpt_szsz"]
+            Psi -= 2 * mus[:, None] * sums["s_sz_outer"]
+            model_params["Psi"] = Psi * np.linalg.inv(sums["xpt_ss"] + self.eps_Psi * np.eye(H))
+        if "sigma2" in learn:
+            WtW = np.dot(model_params["W"].T, model_params["W"])
+            s2 = 0.0
+            s2 += sums["y_outer_diag"].sum()
+            s2 -= np.trace(np.dot(sums["sz_sz_outer"], WtW))
+            model_params["sigma2"] = (s2 / N / D) + self.eps_sigma2
+        return model_params
+
+    def EM_step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
+        """Fused E- and M-step (sssc.py:419-813).  Returns (F, S_nunique, S_sub, Theta_new); F uses
+        the ljc of the Theta the E-step ran with (sssc.py:472,780)."""
+        if do_reconstruction:
+            raise NotImplementedError("reconstruction is outside the accelerated path (SURVEY 8f rank 3)")
+        F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
+        v = self.engine.acc_views(self._acc)
+        self._acc = None
+        for label, key in (("reset_lpj_isnan", "reset_isnan"), ("reset_lpj_smaller_eps_lpj", "reset_smaller_eps"),
+                           ("reset_lpj_isinf", "reset_isinf")):
+            if int(v[key]) > 0:
+                parallel.pprint("no %s = %i" % (label, int(v[key])), self.comm)
+        if len(self.to_learn) > 0:
+            with small_blas(self.H):
+                model_params = self.update_params(model_params, v, float(v["N"]))
+        return F, S_nunique, S_sub, model_params
+
+    def M_step(self, model_params, my_suff_stat, my_data, _from_step=False):
+        """Statistics + Theta update from the caller's K^n / lpj (the second half of EM_step)."""
+        acc = self._stats_for_mstep(model_params, my_suff_stat, my_data, _from_step)
+        v = self.engine.acc_views(acc)
+        with small_blas(self.H):
+            return self.update_params(model_params, v, float(v["N"]))

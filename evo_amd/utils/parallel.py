@@ -1,0 +1,186 @@
+"""Communicators for the data-parallel EM step (reference: evo/utils/parallel.py + the inline
+mpi4py calls of bsc.py:230-231,257,274 / sssc.py:671-691,763,773-780 / _models.py:540-547).
+
+The reference shards the N datapoints over MPI ranks (``np.array_split`` order,
+parallel.py:102) and sums the M-step accumulators with ``comm.Allreduce``.  Here one process
+drives one GPU and the packed accumulator is summed with ONE in-place RCCL all-reduce over
+xGMI, issued inside libevo_amd on the stream that produced it (``RcclComm``).  The model
+classes only need the small duck-typed surface below, which mpi4py's ``MPI.COMM_WORLD`` also
+satisfies, so a reference user can keep passing their communicator:
+
+    comm.rank, comm.size
+    comm.allreduce(python_scalar_or_ndarray) -> summed value      (pickle path in mpi4py)
+    comm.bcast(obj, root=0)
+    comm.Barrier()
+
+``SerialComm``      one rank (default).
+``TorchDistComm``   host-side sums over a torch.distributed process group (gloo on CPU); used by
+                    the CPU multi-process tests and usable as a fallback transport.  PyTorch is
+                    imported lazily and only by this class.
+``RcclComm``        RCCL through libevo_amd: the device accumulator is reduced in place by
+                    ``evoamd_stats``; host scalars go through a tiny device bounce buffer.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def pprint(obj="", comm=None, end="\n"):
+    """Rank-0 print (parallel.py:23-42)."""
+    if comm is not None and comm.rank != 0:
+        return
+    sys.stdout.write((obj if isinstance(obj, str) else repr(obj)) + end)
+    sys.stdout.flush()
+
+
+def shard_bounds(N, size):
+    """Start offsets of np.array_split(range(N), size): the first N % size shards get one extra
+    row (parallel.py:102-112)."""
+    base, extra = divmod(int(N), int(size))
+    counts = np.full(size, base, dtype=np.int64)
+    counts[:extra] += 1
+    starts = np.concatenate(([0], np.cumsum(counts)))
+    return starts
+
+
+def shard(array, rank, size):
+    """This rank's contiguous block of ``array`` along axis 0 (what Scatterv delivers,
+    parallel.py:117-151)."""
+    b = shard_bounds(array.shape[0], size)
+    return array[b[rank]:b[rank + 1]]
+
+
+class SerialComm:
+    rank = 0
+    size = 1
+    device_reduces = False  # the packed accumulator needs no reduction
+
+    def allreduce(self, value, op=None):
+        return value
+
+    def bcast(self, value, root=0):
+        return value
+
+    def Barrier(self):
+        return None
+
+    def allreduce_array(self, a):
+        return a
+
+
+class TorchDistComm:
+    """Sums over an initialised torch.distributed group.  Host tensors (gloo)."""
+    device_reduces = False
+
+    def __init__(self, group=None):
+        import torch.distributed as dist  # lazy: PyTorch is plumbing for this transport only
+        self._dist = dist
+        self._group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def allreduce_array(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
+        return t.numpy()
+
+    def allreduce(self, value, op=None):
+        if isinstance(value, np.ndarray):
+            return self.allreduce_array(value).reshape(value.shape)
+        out = self.allreduce_array(np.array([value], dtype=np.float64))[0]
+        return type(value)(out) if isinstance(value, (int, np.integer)) else float(out)
+
+    def bcast(self, value, root=0):
+        box = [value]
+        self._dist.broadcast_object_list(box, src=root, group=self._group)
+        return box[0]
+
+    def Barrier(self):
+        self._dist.barrier(group=self._group)
+
+
+class RcclComm:
+    """RCCL communicator attached to an Engine's context (one process per GPU).
+
+    ``device_reduces`` tells the models that ``Engine.stats()`` already returns globally summed
+    accumulators.  Scalars and small host arrays use ``evoamd_comm_allreduce_host``."""
+    device_reduces = True
+
+    def __init__(self, engine, rank, size, unique_id):
+        self.engine = engine
+        self.rank = int(rank)
+        self.size = int(size)
+        engine.comm_init(unique_id, rank, size)
+
+    def allreduce_array(self, a, op="sum"):
+        a = np.asarray(a, dtype=np.float64)
+        return self.engine.comm_allreduce(a.ravel(), op).reshape(a.shape)
+
+    def allreduce(self, value, op=None):
+        if isinstance(value, np.ndarray):
+            return self.allreduce_array(value)
+        out = self.allreduce_array(np.array([value], dtype=np.float64))[0]
+        return type(value)(out) if isinstance(value, (int, np.integer)) else float(out)
+
+    def allreduce_max(self, value):
+        return float(self.allreduce_array(np.array([value], dtype=np.float64), "max")[0])
+
+    def bcast(self, value, root=0):
+        """Numeric scalars / float arrays only (everything Theta holds): the root contributes the
+        value, the others zeros, and the sum is the broadcast."""
+        a = np.asarray(value, dtype=np.float64)
+        send = a if self.rank == root else np.zeros_like(a)
+        out = self.allreduce_array(send)
+        return out if isinstance(value, np.ndarray) else type(value)(out)
+
+    def Barrier(self):
+        self.allreduce_array(np.zeros(1))
+
+    def close(self):
+        self.engine.comm_destroy()
+
+
+def rendezvous_unique_id(rank, size, make_id, tag=None, timeout_s=300.0):
+    """Share rank 0's RCCL unique id with the other local ranks through a file.
+
+    One node, one process per GPU (the bench contract): the launcher (torchrun) gives every
+    rank the same MASTER_PORT and the same parent pid, which together name the rendezvous file
+    under /tmp.  Rank 0 writes the id atomically (temp file + rename); the others poll."""
+    if size == 1:
+        return make_id()
+    if tag is None:
+        tag = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                            os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    path = os.path.join(os.environ.get("EVO_AMD_RDZV_DIR", "/tmp"), "evo_amd_rccl_%s.id" % tag)
+    if rank == 0:
+        uid = make_id()
+        tmp = path + ".tmp.%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("no RCCL unique id at %s after %.0f s" % (path, timeout_s))
+        time.sleep(0.05)
+
+
+def init_rccl_from_env(engine):
+    """RANK / WORLD_SIZE (torchrun) -> RcclComm on ``engine``; SerialComm when WORLD_SIZE is 1."""
+    size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if size == 1:
+        return SerialComm()
+    uid = rendezvous_unique_id(rank, size, engine.comm_unique_id)
+    return RcclComm(engine, rank, size, uid)

@@ -11,9 +11,12 @@
  *
  * Conventions: plain C, no exceptions.  Every function returns 0 on success and a
  * negative EVOAMD_E_* code on failure; evoamd_last_error() then returns a message.
- * Host pointers are borrowed for the duration of the call only.  Calls are synchronous on
- * return unless the name ends in _async.  One context per GPU per process; a context is
- * not thread-safe.  All floating point is IEEE binary64 (the reference is float64-only).
+ * Host pointers are borrowed for the duration of the call only.  Device work is ordered on
+ * the context's stream; every call that returns data to the host (download_*, lpj_* with an
+ * output pointer, vary_kn with sums_out, stats, free_energy) has completed it on return, the
+ * others (lpj_resident, evolve_randflip, set_params_*) may return while kernels are still
+ * queued, and device-side error conditions (EVOAMD_E_KLIMIT / _SINGULAR) are reported by the
+ * next host-returning call.  One context per GPU per process; a context is not thread-safe.  All floating point is IEEE binary64 (the reference is float64-only).
  *
  * State encoding on the device: a binary state s in {0,1}^H is HW = ceil(H/64) 64-bit
  * words; latent h lives in word h/64 at bit 63-(h%64) (MSB first), so that comparing the
@@ -136,8 +139,8 @@ int evoamd_evolve_randflip(evoamd_ctx *ctx, int n_parents, int n_children, uint6
 /* ---- M-step sufficient statistics + free energy ------------------------------------- */
 /* Number of doubles in the packed accumulator for the configured model:
  *   BSC : Wp (H,D) | Wq (H,H) | pies (H) | sigma | tail[8]
- *   SSSC: xpt_s (H) | xpt_ss (H,H) | xpt_sz (H) | xpt_szsz (H,H) | s_sz_outer (H,H) |
- *         sz_sz_outer (H,H) | Wp (D,H) | y_outer_diag (D) | tail[8]
+ *   SSSC: xpt_s (H) | xpt_ss (H,H) | xpt_sz (H) | xpt_szsz (H,H) | Wp (D,H) | s_sz_outer (H,H) |
+ *         sz_sz_outer (H,H) | y_outer_diag (D) | tail[8]
  *   tail = { Fs, sum_nunique, sum_sub, N, reset_isnan, reset_smaller_eps, reset_isinf, 0 } */
 int64_t evoamd_acc_size(evoamd_ctx *ctx);
 /* Computes the per-rank sums from the resident K^n / lpj (bsc.py:176-223;

@@ -320,7 +320,7 @@ if __name__ == "__main__":
     make_step_fixture("ebsc_mid", "ebsc", 48, 100, 40, 60, seed=3, n_steps=2)
     make_step_fixture("es3c_mid", "es3c", 24, 72, 30, 40, seed=4, n_steps=2)
     make_step_fixture("es3c_dense", "es3c", 32, 40, 24, 12, seed=5, n_steps=2, p_init=6.0 / 40, use_storage=False)
-    make_step_fixture("ebsc_dense", "ebsc", 32, 130, 24, 20, seed=6, n_steps=2, p_init=8.0 / 130)
+    make_step_fixture("ebsc_dense", "ebsc", 32, 130, 24, 160, seed=6, n_steps=2, p_init=8.0 / 130)
     make_step_fixture("ebsc_sparseflip", "ebsc", 20, 24, 12, 30, seed=7, n_steps=2, ea=("rand", "sparseflip", 4, 2, 1), bitflip_prob=0.1)
     make_step_fixture("es3c_cross", "es3c", 20, 24, 12, 30, seed=8, n_steps=2, ea=("fit", "cross_randflip", 4, 1, 1))
     make_step_fixture("ebsc_gen2", "ebsc", 20, 24, 12, 30, seed=9, n_steps=2, ea=("fit", "randflip", 4, 2, 2), Mprime=5)

@@ -1,0 +1,227 @@
+"""CPU tests of the host-side mirror (no GPU, no kernels): the evolutionary operators must consume
+np.random exactly like the reference (checked against the oracle, itself pinned to the reference by
+test_oracle_golden.py), the Theta updates must reproduce the fixtures from the reference's own
+accumulators, and the C-ABI library must load and export every symbol of include/evo_amd.h."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, unpack_bits
+from oracle import evo_oracle as orc
+
+from evo_amd import _lib
+from evo_amd import engine as eng_mod
+from evo_amd.utils import parallel
+from evo_amd.variational import eas, utils as vutils
+
+
+def rand_states(rng, R, H, p):
+    return rng.random_sample((R, H)) < p
+
+
+@pytest.mark.parametrize("H,P,C", [(10, 4, 1), (70, 10, 2), (130, 6, 3)])
+def test_mutation_ops_match_oracle_stream(H, P, C):
+    rng = np.random.RandomState(H)
+    parents = rand_states(rng, P, H, 0.2)
+    for name in ("randflip", "sparseflip", "cross", "cross_randflip", "cross_sparseflip"):
+        np.random.seed(7)
+        want = orc.MUTATION[name](parents.copy(), C, 3.0, 0.05)
+        w_state = np.random.get_state()[1][:8].copy()
+        np.random.seed(7)
+        got = vutils.MUTATION[name](parents.copy(), C, 3.0, 0.05)
+        g_state = np.random.get_state()[1][:8].copy()
+        assert np.array_equal(np.unique(got, axis=0), np.unique(want, axis=0)), name
+        assert got.shape == want.shape
+        assert np.array_equal(w_state, g_state), "RNG stream position differs for " + name
+
+
+def test_parent_selection_matches_oracle():
+    rng = np.random.RandomState(1)
+    cand = rand_states(rng, 30, 40, 0.1)
+    lpj = -np.abs(rng.normal(size=30)) * 50
+    for name in ("fit", "rand"):
+        np.random.seed(3)
+        want = orc.PARENT_SELECTION[name](cand, 7, lpj)
+        np.random.seed(3)
+        got = vutils.PARENT_SELECTION[name](cand, 7, lpj)
+        assert np.array_equal(got, want)
+
+
+def fake_eval(states):
+    """Deterministic stand-in for a model's lpj: any fixed function of the state will do."""
+    w = np.cos(np.arange(states.shape[1]) * 0.37) * 3
+    return -(states @ w) ** 2 - states.sum(axis=1) * 0.5 - 1.0
+
+
+@pytest.mark.parametrize("mutation,parent,n_par,n_child,n_gen,S_perm", [
+    ("randflip", "fit", 5, 1, 1, 0), ("randflip", "fit", 4, 2, 3, 0), ("randflip", "rand", 4, 2, 3, 1),
+    ("sparseflip", "fit", 4, 2, 2, 0), ("cross_randflip", "fit", 4, 1, 2, 1), ("cross", "rand", 3, 1, 2, 0)])
+def test_evolve_states_matches_oracle(mutation, parent, n_par, n_child, n_gen, S_perm):
+    H, S = 12, 10
+    permanent = {"background": False, "allzero": bool(S_perm), "singletons": False}
+    np.random.seed(5)
+    suff = vutils.init_states(6, S, H, parent, mutation, n_par, n_child, n_gen, bitflip_prob=0.1, permanent=permanent)
+    np.random.seed(5)
+    osuff = orc.init_states(6, S, H, parent, mutation, n_par, n_child, n_gen, bitflip_prob=0.1, permanent=permanent)
+    assert np.array_equal(suff["ss"], osuff["ss"]) and suff["S_perm"] == osuff["S_perm"] == S_perm
+    assert suff["n_children"] == osuff["n_children"] and suff["Mprime"] == osuff["Mprime"]
+    if suff["sm"] is not None:
+        assert np.array_equal(suff["sm"], osuff["sm"])
+    for n in range(6):
+        st = suff["ss"][n]
+        lpj = fake_eval(st)
+        np.random.seed(100 + n)
+        want_s, want_l = orc.evolve_states(st, lpj, osuff, 2.5, fake_eval)
+        np.random.seed(100 + n)
+        suff["this_states"], suff["this_lpj"] = st, lpj
+        got_s, got_l = eas.evolve_states(suff, {"piH": 2.5}, fake_eval)
+        assert np.array_equal(got_s, want_s) and np.array_equal(got_l, want_l)
+        if n_gen == 1:
+            np.random.seed(100 + n)
+            first = eas.first_generation_candidates(st, lpj, suff, 2.5)
+            assert np.array_equal(first, want_s)
+
+
+def test_init_states_large_H_no_enumeration():
+    np.random.seed(0)
+    s = vutils.init_states(3, 5, 40, "fit", "randflip", 3, 1, 1)
+    assert s["sm"] is None and s["ss"].shape == (3, 5, 40) and s["lpj"].shape == (3, 5)
+    for n in range(3):
+        assert np.unique(s["ss"][n], axis=0).shape[0] == 5
+
+
+def test_vary_kn_host_against_reference_fixture():
+    g = load_golden("vary_kn.npz")
+    for i in range(int(g["n_cases"])):
+        H, S, Mp = int(g["c%d_H" % i]), int(g["c%d_S" % i]), int(g["c%d_Mprime" % i])
+        states = unpack_bits(g["c%d_old" % i], H).copy()
+        new = unpack_bits(g["c%d_new" % i], H).reshape(-1, H)
+        lpj_out = np.zeros(S)
+        ret = vutils.vary_Kn(g["c%d_lpj_old" % i].copy(), g["c%d_lpj_new" % i].copy(), lpj_out, states, new, H, S, 0,
+                             np.zeros((0, H), dtype=bool), Mp)
+        assert list(ret) == list(g["c%d_ret" % i]), i
+        assert np.array_equal(np.packbits(states, axis=-1), g["c%d_states_out" % i]), i
+        assert np.array_equal(lpj_out, g["c%d_lpj_out" % i]), i
+
+
+class _NoEngine:
+    """update_params / check_params never touch the engine; make sure of it."""
+
+    def __getattr__(self, name):
+        raise AssertionError("host-only code path touched the GPU engine: " + name)
+
+
+@pytest.mark.parametrize("name", ["ebsc_mid", "ebsc_bars", "es3c_mid", "es3c_bars", "es3c_dense"])
+def test_theta_update_from_reference_sums(name):
+    """Feed the reference's own all-reduced accumulators into update_params -> the reference's Theta."""
+    from evo_amd.models import BSC, SSSC
+    g = load_golden("step_%s.npz" % name)
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    bsc = str(g["algo"]) == "ebsc"
+    model = (BSC if bsc else SSSC)(D, H, S, engine=_NoEngine())
+    keys = ("W", "pi", "sigma") if bsc else ("W", "pies", "mus", "Psi", "sigma2")
+    names = ("Wp", "Wq", "pies", "sigma") if bsc else ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer",
+                                                         "sz_sz_outer", "Wp", "y_outer_diag")
+    for t in range(int(g["n_steps"])):
+        theta = {k: np.array(g["t%d_in_%s" % (t, k)]) for k in keys}
+        sums = {nm: np.array(g["t%d_sum_%s" % (t, nm)]) for nm in names}
+        theta = model.update_params(theta, sums, float(N))
+        for k in keys:
+            np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_check_params_clamps_like_reference():
+    from evo_amd.models import BSC, SSSC
+    m = BSC(3, 4, 2, engine=_NoEngine())
+    th = m.check_params({"W": np.ones((3, 4)), "pi": 0.0, "sigma": 1e-9})
+    assert th["pi"] == 1e-5 and th["sigma"] == 1e-5
+    th = m.check_params({"W": np.ones((3, 4)), "pi": 1.0, "sigma": 2.0})
+    assert th["pi"] == 1.0 - 1e-5
+    s = SSSC(3, 4, 2, engine=_NoEngine())
+    Psi = np.eye(4)
+    Psi[1, 1] = 1e-9
+    th = s.check_params({"W": np.ones((3, 4)), "pies": np.array([0.0, 0.5, 1.0, 0.2]), "mus": np.zeros(4),
+                         "Psi": Psi, "sigma2": np.float64(0.0)})
+    assert th["pies"][0] == 1e-5 and th["pies"][2] == 1 - 1e-5 and th["Psi"][1, 1] == 1e-5 and th["sigma2"] == 1e-5
+    with pytest.raises(AssertionError):
+        s.check_params({"W": np.full((3, 4), np.nan), "pies": np.full(4, 0.2), "mus": np.zeros(4), "Psi": np.eye(4),
+                        "sigma2": np.float64(1.0)})
+
+
+def test_precompute_matches_oracle():
+    from evo_amd.models import BSC, SSSC
+    rng = np.random.RandomState(2)
+    D, H = 7, 9
+    th = {"W": rng.normal(size=(D, H)), "pi": 0.13, "sigma": 0.8}
+    oth = dict(th)
+    orc.bsc_precompute(oth, D, H)
+    m = BSC(D, H, 3)
+    m.E_step_precompute(th, {}, {"x_infr": np.ones((2, D), bool)})
+    for k in ("pre1", "pil_bar", "piH", "ljc"):
+        assert th[k] == oth[k]
+    th = {"W": rng.normal(size=(D, H)), "pies": rng.uniform(0.1, 0.4, H), "mus": rng.normal(size=H),
+          "Psi": np.eye(H), "sigma2": np.float64(0.37)}
+    oth = dict(th)
+    orc.sssc_precompute(oth, D)
+    s = SSSC(D, H, 3)
+    s.E_step_precompute(th, {}, {"x_infr": np.ones((2, D), bool)})
+    assert th["ljc"] == oth["ljc"] and th["sigma2_inv"] == oth["sigma2_inv"] and th["piH"] == oth["piH"]
+    assert np.array_equal(th["pil_bar"], oth["pil_bar"])
+
+
+def test_acc_layout_and_views():
+    for model, D, H in (("bsc", 5, 7), ("sssc", 5, 7)):
+        n = eng_mod.acc_size(model, D, H)
+        assert n == (H * D + H * H + H + 1 + 8 if model == "bsc" else 2 * H + 4 * H * H + D * H + D + 8)
+        acc = np.arange(n, dtype=np.float64)
+        v = eng_mod.acc_views(acc, model, D, H)
+        assert v["Wp"].shape == ((H, D) if model == "bsc" else (D, H))
+        assert float(v["Fs"]) == n - 8 and float(v["N"]) == n - 5
+        v["Wp"][0, 0] = -1.0
+        assert acc.min() == -1.0  # views, not copies
+
+
+def test_shard_bounds_is_array_split():
+    for N in (1, 7, 100, 101, 1000):
+        for R in (1, 2, 3, 8):
+            want = [len(c) for c in np.array_split(np.arange(N), R)]
+            b = parallel.shard_bounds(N, R)
+            assert list(np.diff(b)) == want
+            x = np.arange(N * 2).reshape(N, 2)
+            assert np.array_equal(np.concatenate([parallel.shard(x, r, R) for r in range(R)]), x)
+
+
+def test_library_exports_every_declared_symbol():
+    """No compute call: the box running this has no GPU.  The .so must load and export exactly
+    the prototypes of include/evo_amd.h; the ctypes table must cover them all."""
+    header = open(os.path.join(ROOT, "include", "evo_amd.h")).read()
+    declared = set(re.findall(r"\b(evoamd_[a-z0-9_]+)\s*\(", header))
+    declared.discard("evoamd_ctx")
+    assert len(declared) >= 30
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail("libevo_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library lacks " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.evoamd_abi_version() == 1
+
+
+def test_product_path_has_no_cpu_fallback():
+    """evo_amd must not import the oracle, and creating an engine without a GPU must raise."""
+    import evo_amd
+    pkg = os.path.dirname(evo_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle/", ""), f
+    lib = _lib.load()
+    cnt = ctypes.c_int(-1)
+    rc = lib.evoamd_device_count(ctypes.byref(cnt))
+    if rc != 0 or cnt.value == 0:
+        with pytest.raises(_lib.EvoAmdError):
+            eng_mod.Engine(0)
