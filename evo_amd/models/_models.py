@@ -33,22 +33,22 @@ _blas_controller = None
 
 
 class small_blas:
-    """Run the tiny H x H host solves of the Theta update on one BLAS thread when H is small.
-    On a many-core GPU host OpenBLAS otherwise spins up dozens of threads for a 128 x 128 inverse
-    and the M-step's host part takes longer than all the kernels together (measured: 18 ms vs
-    < 1 ms at H = 128).  No-op when threadpoolctl is not installed or H > 256."""
+    """Bound the BLAS thread count for the H x H host solves of the Theta update: 1 thread up to
+    H = 256, 8 above.  On a many-core GPU host whose process may only use a few CPUs, OpenBLAS
+    otherwise starts one thread per *visible* core and the M-step's host part takes longer than
+    all the kernels together (measured on the GPU box: 18 ms vs < 1 ms at H = 128, 300 ms at
+    H = 512).  No-op when threadpoolctl is not installed."""
 
     def __init__(self, H):
         self._ctx = None
-        if H <= 256:
-            global _blas_controller
-            try:
-                if _blas_controller is None:
-                    from threadpoolctl import ThreadpoolController
-                    _blas_controller = ThreadpoolController()
-                self._ctx = _blas_controller.limit(limits=1, user_api="blas")
-            except Exception:  # threadpoolctl missing or no BLAS found: run unrestricted
-                self._ctx = None
+        global _blas_controller
+        try:
+            if _blas_controller is None:
+                from threadpoolctl import ThreadpoolController
+                _blas_controller = ThreadpoolController()
+            self._ctx = _blas_controller.limit(limits=1 if H <= 256 else 8, user_api="blas")
+        except Exception:  # threadpoolctl missing or no BLAS found: run unrestricted
+            self._ctx = None
 
     def __enter__(self):
         if self._ctx is not None:
