@@ -177,3 +177,32 @@ def test_clamp_flags(engine):
     out, flags = engine.lpj_single(np.zeros(D), st)
     assert out[0] == np.finfo(np.float64).min
     assert flags[0] == 1
+
+
+def test_rccl_single_rank_allreduce(engine):
+    """RCCL is reached through dlopen inside libevo_amd; a 1-rank communicator must initialise on
+    the GPU box and leave the packed accumulator unchanged (sum over one rank).  Multi-rank runs
+    are the driver's (8-GPU node); the N>1 host logic is covered by test_multirank_gloo.py."""
+    from evo_amd.engine import Engine
+    from evo_amd.utils import parallel
+    g = load_golden("step_es3c_bars.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    eng = Engine()
+    try:
+        eng.configure("sssc", N, D, H, S, 0, 4)
+        eng.upload_data(g["Y"])
+        eng.upload_states(unpack_bits(g["t0_ss_in"], H))
+        eng.set_params_sssc(g["t0_in_W"], g["t0_in_pies"], g["t0_in_mus"], g["t0_in_Psi"], float(g["t0_in_sigma2"]))
+        eng.lpj_resident()
+        before = eng.stats()
+        comm = parallel.RcclComm(eng, 0, 1, Engine.comm_unique_id())
+        assert comm.device_reduces and comm.size == 1
+        after = eng.stats()
+        np.testing.assert_allclose(after, before, rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(comm.allreduce_array(np.arange(5.0)), np.arange(5.0))
+        assert comm.allreduce_max(3.5) == 3.5 and comm.allreduce(7) == 7
+        assert comm.bcast(np.float64(2.5)) == 2.5
+        comm.Barrier()
+        comm.close()
+    finally:
+        eng.close()

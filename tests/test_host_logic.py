@@ -225,3 +225,23 @@ def test_product_path_has_no_cpu_fallback():
     if rc != 0 or cnt.value == 0:
         with pytest.raises(_lib.EvoAmdError):
             eng_mod.Engine(0)
+
+
+def test_rendezvous_file_roundtrip(tmp_path, monkeypatch):
+    """Rank 0 publishes the 128-byte RCCL id atomically; another rank polling the same tag reads it."""
+    import threading
+    monkeypatch.setenv("EVO_AMD_RDZV_DIR", str(tmp_path))
+    uid = bytes(range(128))
+    got = {}
+
+    def reader():
+        got["uid"] = parallel.rendezvous_unique_id(1, 2, lambda: b"", tag="t1", timeout_s=20)
+
+    t = threading.Thread(target=reader)
+    t.start()
+    assert parallel.rendezvous_unique_id(0, 2, lambda: uid, tag="t1") == uid
+    t.join(25)
+    assert got["uid"] == uid
+    assert parallel.rendezvous_unique_id(0, 1, lambda: uid) == uid  # single rank: no file
+    with pytest.raises(TimeoutError):
+        parallel.rendezvous_unique_id(1, 2, lambda: b"", tag="never", timeout_s=0.2)
