@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -114,6 +115,7 @@ struct evoamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
+  bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
   int model = 0;
   i64 N = 0;
   int D = 0, H = 0, S = 0, S_perm = 0, Cmax = 0, HW = 0, L = 0;
@@ -128,7 +130,7 @@ struct evoamd_ctx {
   double *lpj = nullptr, *cand_lpj = nullptr;
   int *cand_counts = nullptr;
   unsigned *flags = nullptr;  // 3 x N: resident | candidates | permanent
-  double *rowmax = nullptr, *rowsum = nullptr, *partial = nullptr;
+  double *rowmax = nullptr, *rowsum = nullptr, *partial = nullptr, *partial2 = nullptr, *diag = nullptr;
   i64 n_partial = 0;
   uint8_t *stage = nullptr;  // bool staging for (N, max(S,Cmax), H)
   size_t stage_bytes = 0;
@@ -141,7 +143,8 @@ struct evoamd_ctx {
   double *acc = nullptr;
   i64 acc_n = 0;
   double *Es = nullptr;  // BSC: (N,H); SSSC: columns D..D+H of c->Y (Ez follows)
-  int *list1 = nullptr, *list2 = nullptr, *list_n = nullptr, *err = nullptr;
+  int *list1 = nullptr, *list2 = nullptr, *list3 = nullptr, *list_n = nullptr, *err = nullptr;
+  size_t list_words = 0;  // capacity of each overflow list (ints)
   // scratch for single / shared evaluations
   double *tmp_y = nullptr, *tmp_lpj = nullptr;
   u64 *tmp_states = nullptr;
@@ -215,6 +218,9 @@ static int dev_alloc(T **p, size_t n) {
   } while (0)
 
 static inline unsigned cdiv(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
+// entries one shard of an overflow list can receive from `total` pairs (workgroup batches of 256..1024
+// pairs are dealt round-robin to the shards)
+static inline size_t list_cap(i64 total) { return (size_t)(256 * (((total + 255) / 256 + LIST_SHARDS - 1) / LIST_SHARDS) + 1024); }
 
 // out[c] += sum_r X[r][c] (out must be zeroed by the caller); SQUARE sums squares.
 template <bool SQUARE>
@@ -224,6 +230,18 @@ static void launch_colsum(evoamd_ctx *c, const double *X, int ldx, i64 R, int Cn
   colsum_f64<SQUARE><<<grid, 256, 0, c->stream>>>(X, ldx, R, Cn, rpb, out);
 }
 
+
+// overflow lists big enough for a batch of `total` (datapoint, state) pairs
+static int ensure_lists(evoamd_ctx *c, i64 total) {
+  const size_t need = list_cap(total) * LIST_SHARDS;
+  if (need <= c->list_words) return 0;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ALLOC(c->list1, need);
+  ALLOC(c->list2, need);
+  ALLOC(c->list3, need);
+  c->list_words = need;
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------
 // library / context
@@ -268,9 +286,9 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 
 static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
-                  c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->stage,    c->W,
+                  c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
-                  c->acc,    c->Es,     c->list1,   c->list2,    c->list_n,    c->err,
+                  c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -356,7 +374,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->HW = (H + 63) / 64;
   c->L = S + S_perm;
   const i64 HW = c->HW;
-  c->ldY = (model == EVOAMD_MODEL_SSSC) ? D + 2 * H : D;
+  c->ldY = (model == EVOAMD_MODEL_SSSC) ? D + 3 * H : D;  // ES3C: [Y | Es | Ez | Ed]
   ALLOC(c->Y, (size_t)N * c->ldY);
   ALLOC(c->yy, (size_t)N);
   ALLOC(c->y2sum, (size_t)D);
@@ -369,7 +387,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->rowmax, (size_t)N);
   ALLOC(c->rowsum, (size_t)N);
   c->n_partial = cdiv(N, 4);
-  ALLOC(c->partial, (size_t)c->n_partial);
+  ALLOC(c->partial, (size_t)3 * c->n_partial);
+  ALLOC(c->partial2, (size_t)c->n_partial);
+  ALLOC(c->diag, (size_t)H);
   const int SC = S > Cmax ? S : Cmax;
   c->stage_bytes = (size_t)N * SC * H;
   ALLOC(c->stage, c->stage_bytes);
@@ -392,9 +412,10 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->Bm, (size_t)N * H);
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
-    ALLOC(c->list1, (size_t)N * SC);
-    ALLOC(c->list2, (size_t)N * SC);
-    ALLOC(c->list_n, 4);
+    c->list_words = 0;
+    int rl = ensure_lists(c, (i64)N * SC);
+    if (rl) return rl;
+    ALLOC(c->list_n, 4 * LIST_SHARDS);
   }
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
@@ -409,7 +430,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
-  c->have_data = c->have_params = c->have_cand = false;
+  c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
   return 0;
 }
 
@@ -467,6 +488,7 @@ extern "C" int evoamd_upload_lpj(evoamd_ctx *c, const double *lpj) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(c->lpj, lpj, (size_t)c->N * c->L * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->rows_fresh = false;
   return 0;
 }
 
@@ -485,11 +507,13 @@ extern "C" int evoamd_download_lpj(evoamd_ctx *c, double *lpj) {
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                           int M, int Nc, i64 K) {
   const unsigned gx = cdiv(Nc, GEMM_BN), gy = cdiv(M, GEMM_BM);
+  // no prefetch in the tile loop yet, so latency is hidden by parallelism: aim for >= 512
+  // workgroups, at least 64 rows of K per split
   i64 splits = 1;
   const i64 tiles = (i64)gx * gy;
-  if (K > 4096) {
-    splits = (1024 + tiles - 1) / tiles;  // aim for ~1024 workgroups
-    const i64 maxs = (K + 511) / 512;     // at least 512 rows per split
+  if (K >= 128) {
+    splits = (512 + tiles - 1) / tiles;
+    const i64 maxs = (K + 63) / 64;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
   }
@@ -612,6 +636,7 @@ struct Batch {
   int ldo, col0;
   unsigned *flags;
   int kid;
+  int tag;  // 0 resident K^n, 1 candidate batch, 2 anything else (names the kernel instantiation)
 };
 
 static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
@@ -658,24 +683,36 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
 static const size_t SSSC_BIG_LDS = (size_t)(2 * SSSC_KCAP * SSSC_KCAP + 5 * SSSC_KCAP) * sizeof(double) +
                                    SSSC_KCAP * sizeof(int);
 
-template <int MODE>
-static int launch_sssc(evoamd_ctx *c, const SsscArgs &a, int kid_main, int kid_ovf) {
+// ES3C lpj of a batch: states are binned by their number of active latents on the fly.  The main
+// launch walks the pairs in natural (coalesced) order, evaluates every state with k <= 2 in
+// registers and appends the rest to a list; the list is then served by the K = 4 and K = 8
+// register kernels and finally by the LDS wavefront kernel.  Each level only sees what the
+// previous one could not hold, so waves stay homogeneous in k.
+static unsigned list_grid(i64 total, unsigned cap) {
+  unsigned g = cdiv(total, 256);
+  return g > cap ? cap : (g < 1 ? 1 : g);
+}
+
+template <int TAG>
+static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main) {
   const i64 total = a.N * (i64)a.C;
-  HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * sizeof(int), c->stream));
+  const int cap = (int)list_cap(total);
+  HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+  const ListIn none = {nullptr, nullptr, 0};
+  const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
+                o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
+  const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
   {
     SpanGuard g(c, kid_main);
-    unsigned grid = cdiv(total, 256);
-    sssc_small_kernel<4, MODE><<<grid, 256, 0, c->stream>>>(a, nullptr, nullptr, c->list1, c->list_n + 0);
+    sssc_small_kernel<2, 0, TAG, 1024><<<cdiv(total, 1024), 1024, 0, c->stream>>>(a, none, o1);
     HIP_TRY(hipGetLastError());
   }
   {
-    SpanGuard g(c, kid_ovf);
-    unsigned grid = cdiv(total, 256);
-    if (grid > 1024) grid = 1024;
-    sssc_small_kernel<8, MODE><<<grid, 256, 0, c->stream>>>(a, c->list1, c->list_n + 0, c->list2, c->list_n + 1);
-    HIP_TRY(hipGetLastError());
-    unsigned gridb = (unsigned)(total < 2048 ? total : 2048);
-    sssc_big_kernel<MODE><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, c->list2, c->list_n + 1);
+    SpanGuard g(c, KID_LPJ_OVF);
+    sssc_small_kernel<4, 0, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(a, i1, o2);
+    sssc_small_kernel<8, 0, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(a, i2, o3);
+    const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
+    sssc_big_kernel<0><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -684,7 +721,9 @@ static int launch_sssc(evoamd_ctx *c, const SsscArgs &a, int kid_main, int kid_o
 static int launch_lpj(evoamd_ctx *c, const Batch &b) {
   if (c->model == EVOAMD_MODEL_BSC) return launch_bsc_lpj(c, b);
   SsscArgs a = sssc_args(c, b);
-  return launch_sssc<0>(c, a, b.kid, KID_LPJ_OVF);
+  if (b.tag == 0) return launch_sssc_lpj<0>(c, a, b.kid);
+  if (b.tag == 1) return launch_sssc_lpj<1>(c, a, b.kid);
+  return launch_sssc_lpj<2>(c, a, b.kid);
 }
 
 static int check_err(evoamd_ctx *c) {
@@ -706,13 +745,14 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
     int rb = ensure_B(c);
     if (rb) return rb;
   }
+  c->rows_fresh = false;
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
   if (c->S_perm) {
     const double pre = (c->model == EVOAMD_MODEL_BSC) ? c->pre1 : -0.5 * c->s2inv;
     allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, pre, c->lpj, c->L, c->flags + 2 * c->N);
     HIP_TRY(hipGetLastError());
   }
-  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES};
+  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
   return launch_lpj(c, b);  // stream-ordered; device-side errors surface at the next host-returning call
 }
 
@@ -722,7 +762,7 @@ static int eval_candidates(evoamd_ctx *c) {
     if (rb) return rb;
   }
   Batch b = {c->cand, c->cand_counts, c->Y, c->Bm, c->yy, c->N, c->Cmax, 0, c->cand_lpj, c->Cmax, 0,
-             c->flags + c->N, KID_LPJ_CAND};
+             c->flags + c->N, KID_LPJ_CAND, 1};
   return launch_lpj(c, b);
 }
 
@@ -796,20 +836,15 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
   HIP_TRY(hipMalloc((void **)&st, (size_t)C * c->H));
   HIP_TRY(hipMemcpyAsync(st, states_bool, (size_t)C * c->H, hipMemcpyHostToDevice, c->stream));
   pack_states_kernel<<<cdiv((i64)C * c->HW, 256), 256, 0, c->stream>>>(st, c->tmp_states, C, c->H, c->HW);
-  int *lists = nullptr;
   if (c->model == EVOAMD_MODEL_SSSC) {
-    // overflow lists sized for this batch
-    HIP_TRY(hipMalloc((void **)&lists, (size_t)2 * c->N * C * sizeof(int)));
+    r = ensure_lists(c, (i64)c->N * C);
+    if (r) {
+      (void)hipFree(st);
+      return r;
+    }
   }
-  int *l1 = c->list1, *l2 = c->list2;
-  if (lists) {
-    c->list1 = lists;
-    c->list2 = lists + (size_t)c->N * C;
-  }
-  Batch b = {c->tmp_states, nullptr, c->Y, c->Bm, c->yy, c->N, C, 1, c->tmp_lpj, C, 0, c->flags + c->N, KID_MISC};
+  Batch b = {c->tmp_states, nullptr, c->Y, c->Bm, c->yy, c->N, C, 1, c->tmp_lpj, C, 0, c->flags + c->N, KID_MISC, 2};
   r = launch_lpj(c, b);
-  c->list1 = l1;
-  c->list2 = l2;
   if (!r) {
     hipError_t e = hipMemcpyAsync(lpj_out, c->tmp_lpj, (size_t)c->N * C * sizeof(double), hipMemcpyDeviceToHost,
                                   c->stream);
@@ -817,7 +852,6 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
     if (e != hipSuccess) r = fail(EVOAMD_E_HIP, "lpj_shared copy back: %s", hipGetErrorString(e));
   }
   (void)hipFree(st);
-  if (lists) (void)hipFree(lists);
   if (r) return r;
   if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
   return 0;
@@ -833,6 +867,10 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
   if (!c->tmp_y) ALLOC(c->tmp_y, (size_t)c->D + c->H + 2);
   r = ensure_stage(c, (size_t)C * c->H);
   if (r) return r;
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    r = ensure_lists(c, C);
+    if (r) return r;
+  }
   double *dy = c->tmp_y, *db = c->tmp_y + c->D, *dyy = c->tmp_y + c->D + c->H;
   unsigned *dfl = (unsigned *)(c->tmp_lpj + C);
   HIP_TRY(hipMemcpyAsync(dy, y, (size_t)c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -844,7 +882,7 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
     r = launch_gemm_nn(c, dy, c->D, c->W, c->H, db, c->H, 1, c->H, c->D);
     if (r) return r;
   }
-  Batch b = {c->tmp_states, nullptr, dy, db, dyy, 1, C, 1, c->tmp_lpj, C, 0, dfl, KID_MISC};
+  Batch b = {c->tmp_states, nullptr, dy, db, dyy, 1, C, 1, c->tmp_lpj, C, 0, dfl, KID_MISC, 2};
   r = launch_lpj(c, b);
   if (r) return r;
   unsigned fl = 0;
@@ -870,10 +908,21 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
   const AccLayout a = acc_layout(c);
   {
     SpanGuard g(c, KID_VARY_KN);
-    vary_kn_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->cand, c->cand_lpj, c->cand_counts,
-                                                         c->N, c->S, c->S_perm, c->HW, c->Cmax, Mprime,
-                                                         c->acc + a.tail + 1);
+#define VK_LAUNCH(SPL, CPL)                                                                                   \
+  vary_kn_kernel<SPL, CPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->cand, c->cand_lpj,        \
+                                                                 c->cand_counts, c->N, c->S, c->S_perm, c->HW,   \
+                                                                 c->Cmax, Mprime, c->rowmax,                      \
+                                                                 c->rowsum, c->partial)
+    const bool c1 = c->Cmax <= 64;
+    if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
+    else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }
+    else if (c->S <= 256) { if (c1) VK_LAUNCH(4, 1); else VK_LAUNCH(4, 4); }
+    else if (c->S <= 512) { if (c1) VK_LAUNCH(8, 1); else VK_LAUNCH(8, 4); }
+    else { if (c1) VK_LAUNCH(16, 1); else VK_LAUNCH(16, 4); }
+#undef VK_LAUNCH
+    reduce3_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(c->N, 4), nullptr, c->acc + a.tail + 1);
     HIP_TRY(hipGetLastError());
+    c->rows_fresh = true;
   }
   if (sums_out) {
     HIP_TRY(hipMemcpyAsync(sums_out, c->acc + a.tail + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -900,9 +949,16 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
   HIP_TRY(hipSetDevice(c->device));
   {
     SpanGuard g(c, KID_EVOLVE);
-    evolve_randflip_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H,
-                                                                 c->HW, n_parents, n_children, c->Cmax, seed,
-                                                                 fit_parents, c->cand, c->cand_counts);
+#define EV_LAUNCH(SPL)                                                                                         \
+  evolve_randflip_kernel<SPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H, \
+                                                                    c->HW, n_parents, n_children, c->Cmax, seed,  \
+                                                                    fit_parents, c->cand, c->cand_counts)
+    if (c->S <= 64) EV_LAUNCH(1);
+    else if (c->S <= 128) EV_LAUNCH(2);
+    else if (c->S <= 256) EV_LAUNCH(4);
+    else if (c->S <= 512) EV_LAUNCH(8);
+    else EV_LAUNCH(16);
+#undef EV_LAUNCH
     HIP_TRY(hipGetLastError());
   }
   int r = eval_candidates(c);
@@ -919,9 +975,11 @@ extern "C" int64_t evoamd_acc_size(evoamd_ctx *c) { return (c && c->configured) 
 static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowmax, double *rowsum, double *out_slot) {
   const unsigned nb = cdiv(N, 4);
   if ((i64)nb > c->n_partial) {
-    ALLOC(c->partial, (size_t)nb);
+    ALLOC(c->partial, (size_t)3 * nb);
+    ALLOC(c->partial2, (size_t)nb);
     c->n_partial = nb;
   }
+  if (lpj != c->lpj) c->rows_fresh = false;  // the partial buffer now belongs to another matrix
   SpanGuard g(c, KID_ROW_LSE);
   row_lse_kernel<<<nb, 256, 0, c->stream>>>(lpj, N, L, rowmax, rowsum, c->partial);
   reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, nb, out_slot, 0);
@@ -941,19 +999,26 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   HIP_TRY(hipMemsetAsync(c->acc + a.tail + 3, 0, 5 * sizeof(double), c->stream));
   int r = ensure_B(c);
   if (r) return r;
-  r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
-  if (r) return r;
+  if (c->rows_fresh) {
+    // vary_kn left rowmax / rowsum and the per-block free-energy partials behind
+    SpanGuard g(c, KID_ROW_LSE);
+    reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.tail + 0, 0);
+    HIP_TRY(hipGetLastError());
+  } else {
+    r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
+    if (r) return r;
+  }
   if (c->model == EVOAMD_MODEL_BSC) {
     {
       SpanGuard g(c, KID_STATS);
       bsc_stats_kernel<<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(
           c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->pre1, c->pil_bar, c->Es,
-          c->acc + a.Wq, c->partial);
+          c->acc + a.Wq, c->partial2);
       HIP_TRY(hipGetLastError());
     }
     {
       SpanGuard g(c, KID_MISC);
-      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.sigma, 0);
+      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial2, cdiv(N, 4), c->acc + a.sigma, 0);
       launch_colsum<false>(c, c->Es, H, N, H, c->acc + a.pies);
       finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, H);
       HIP_TRY(hipGetLastError());
@@ -961,43 +1026,50 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
     r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
     if (r) return r;
   } else {
-    double *Es = c->Y + D, *Ez = c->Y + D + H;  // columns of [Y | Es | Ez]
-    Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS};
+    double *Es = c->Y + D, *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed]
+    Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS, 0};
     SsscArgs sa = sssc_args(c, b);
     sa.lpj_in = c->lpj;
     sa.rowmax = c->rowmax;
     sa.rowsum = c->rowsum;
     sa.Es = Es;
     sa.Ez = Ez;
+    sa.Ed = Ed;
     sa.ldE = c->ldY;
     sa.xss = c->acc + a.xss;
     sa.xszsz = c->acc + a.xszsz;
-    HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * sizeof(int), c->stream));
+    const i64 total = N * (i64)c->S;
+    const int cap = (int)list_cap(total);
+    HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+    const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
+                  o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
+    const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
     {
       // workgroups own whole datapoints; rows of Es / Ez staged in LDS (<= 64 KiB)
       int npb = 256 / c->S;
       if (npb < 1) npb = 1;
-      const int cap = (int)(65536 / ((size_t)16 * H));
-      if (npb > cap) npb = cap < 1 ? 1 : cap;
-      const size_t lds = (size_t)npb * 2 * H * sizeof(double);
+      const int lim = (int)(65536 / ((size_t)24 * H));
+      if (npb > lim) npb = lim < 1 ? 1 : lim;
+      const size_t lds = (size_t)npb * 3 * H * sizeof(double);
       SpanGuard g(c, KID_STATS);
-      sssc_stats_kernel<4><<<cdiv(N, npb), 256, lds, c->stream>>>(sa, npb, c->list1, c->list_n + 0);
+      sssc_stats_kernel<2><<<cdiv(N, npb), 256, lds, c->stream>>>(sa, npb, o1);
       HIP_TRY(hipGetLastError());
     }
     {
       SpanGuard g(c, KID_STATS_OVF);
-      const i64 total = N * (i64)c->S;
-      unsigned grid = cdiv(total, 256);
-      if (grid > 1024) grid = 1024;
-      sssc_small_kernel<8, 1><<<grid, 256, 0, c->stream>>>(sa, c->list1, c->list_n + 0, c->list2, c->list_n + 1);
-      unsigned gridb = (unsigned)(total < 2048 ? total : 2048);
-      sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, c->list2, c->list_n + 1);
+      sssc_small_kernel<4, 1, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(sa, i1, o2);
+      sssc_small_kernel<8, 1, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(sa, i2, o3);
+      const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
+      sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
       HIP_TRY(hipGetLastError());
     }
     {
       SpanGuard g(c, KID_MISC);
       launch_colsum<false>(c, Es, c->ldY, N, H, c->acc + a.xs);
       launch_colsum<false>(c, Ez, c->ldY, N, H, c->acc + a.xsz);
+      HIP_TRY(hipMemsetAsync(c->diag, 0, (size_t)H * sizeof(double), c->stream));
+      launch_colsum<false>(c, Ed, c->ldY, N, H, c->diag);
+      set_diag_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->acc + a.xszsz, c->diag, H);
       finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xs, H);
       HIP_TRY(hipMemcpyAsync(c->acc + a.y2, c->y2sum, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       HIP_TRY(hipGetLastError());

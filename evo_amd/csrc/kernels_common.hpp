@@ -83,6 +83,34 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
   }
 }
 
+// Three partial arrays of length n laid out back to back -> out[0], out[1] (+=), out[2] (+=):
+// free-energy sum (assigned) and the two E-step counters (accumulated), one launch.
+__global__ __launch_bounds__(256) void reduce3_partials_kernel(const double *__restrict__ partial, i64 n,
+                                                               double *__restrict__ out_f,
+                                                               double *__restrict__ out_counts) {
+  __shared__ double sh[3][256];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (i64 i = threadIdx.x; i < n; i += 256) {
+    s0 += partial[i];
+    s1 += partial[n + i];
+    s2 += partial[2 * n + i];
+  }
+  sh[0][threadIdx.x] = s0;
+  sh[1][threadIdx.x] = s1;
+  sh[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (out_f) *out_f = sh[0][0];
+    out_counts[0] += sh[1][0];
+    out_counts[1] += sh[2][0];
+  }
+}
+
 // Reset counters with the reference's per-call if/elif priority (_models.py:585-590): one
 // "call" per datapoint per flag array.  counters[0..2] += {#nan calls, #(<eps) calls, #inf calls}.
 __global__ __launch_bounds__(256) void count_flags_kernel(const unsigned *__restrict__ flags, i64 n,
@@ -121,16 +149,37 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const unsigned *__rest
 #define VK_MAX_S_PER_LANE 16  // S <= 1024
 #define VK_MAX_C_PER_LANE 4   // Cmax <= 256
 
+__device__ __forceinline__ double readlane_f64(double v, int src) {  // src must be wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// SPL / CPL: old states / candidates held per lane (S <= 64*SPL, Cmax <= 64*CPL); instantiated for
+// the few sizes that occur so the unrolled per-lane scans carry no dead iterations.
+//
+// Ranks instead of repeated arg-max: every kept candidate gets its descending rank among the kept
+// candidates and every old state its ascending rank among the old states (values broadcast with
+// v_readlane, no LDS traffic); rank-j owners meet through a small LDS table, a ballot finds the
+// accepted prefix {j : n_j > o_j}, and lane j performs swap j.  The updated row never leaves the
+// registers, so the row statistics the M-step needs (max, sum of exp, free-energy term; same
+// arithmetic as row_lse_kernel) are produced here as well.
+template <int SPL, int CPL>
 __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, double *__restrict__ lpj,
                                                       const u64 *__restrict__ cand,
                                                       const double *__restrict__ cand_lpj,
                                                       const int *__restrict__ counts, i64 N, int S,
                                                       int S_perm, int HW, int Cmax, int Mprime,
-                                                      double *__restrict__ sums) {
+                                                      double *__restrict__ rowmax,
+                                                      double *__restrict__ rowsum, double *__restrict__ fpartial) {
   __shared__ int blk_uniq[4], blk_sub[4];
+  __shared__ double wsum[4];
+  __shared__ double new_v[4][64 * CPL], old_v[4][64 * CPL];
+  __shared__ int new_i[4][64 * CPL], old_i[4][64 * CPL];
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;
   int n_uniq = 0, n_sub = 0;
+  double f = 0.0;
   if (n < N) {
     const int L = S + S_perm;
     u64 *st_n = states + n * (i64)S * HW;
@@ -140,9 +189,9 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     int cnt = counts[n];
     if (cnt > Cmax) cnt = Cmax;
     // --- de-duplicate: candidate c survives iff no equal row precedes it in [incl; K^n; cand[0:c]]
-    unsigned keep_mask[VK_MAX_C_PER_LANE];  // bit per candidate owned by this lane (c = lane + 64 q)
+    bool keep[CPL];
 #pragma unroll
-    for (int q = 0; q < VK_MAX_C_PER_LANE; q++) keep_mask[q] = 0;
+    for (int q = 0; q < CPL; q++) keep[q] = false;
     for (int c = 0; c < cnt; c++) {
       const u64 *cw = cd_n + (i64)c * HW;
       bool dup = false;
@@ -163,95 +212,142 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
         for (int w = 0; w < HW; w++) zero = zero && (cw[w] == 0ull);
         dup = zero;
       }
-      const bool any_dup = __any(dup);
-      if (!any_dup) {
+      if (!__any(dup)) {
         n_uniq++;
-        if ((c & 63) == lane) keep_mask[c >> 6] = 1u;
+#pragma unroll
+        for (int q = 0; q < CPL; q++)
+          if (c == lane + 64 * q) keep[q] = true;
       }
     }
-    // --- candidate and old values owned by this lane
-    double nv[VK_MAX_C_PER_LANE];
-    bool navail[VK_MAX_C_PER_LANE];
+    // --- values owned by this lane
+    double nv[CPL], ov[SPL];
+    int nrank[CPL], orank[SPL];
 #pragma unroll
-    for (int q = 0; q < VK_MAX_C_PER_LANE; q++) {
-      int c = lane + 64 * q;
-      navail[q] = (c < cnt) && keep_mask[q];
-      nv[q] = navail[q] ? cl_n[c] : 0.0;
+    for (int q = 0; q < CPL; q++) {
+      const int c = lane + 64 * q;
+      nv[q] = (c < cnt && keep[q]) ? cl_n[c] : 0.0;
+      nrank[q] = 0;
     }
-    double ov[VK_MAX_S_PER_LANE];
-    bool oavail[VK_MAX_S_PER_LANE];
 #pragma unroll
-    for (int q = 0; q < VK_MAX_S_PER_LANE; q++) {
-      int s = lane + 64 * q;
-      oavail[q] = s < S;
-      ov[q] = oavail[q] ? lpj_n[s] : 0.0;
+    for (int q = 0; q < SPL; q++) {
+      const int s = lane + 64 * q;
+      ov[q] = (s < S) ? lpj_n[s] : 0.0;
+      orank[q] = 0;
     }
-    const int rounds = n_uniq < Mprime ? n_uniq : Mprime;
-    for (int j = 0; j < rounds; j++) {
-      // best remaining candidate (max value, lowest index on ties)
-      double bv = -INFINITY;
-      int bi = 0x7fffffff;
+    const int M = n_uniq < Mprime ? n_uniq : Mprime;
+    if (M > 0) {
+      // descending rank of each kept candidate (ties: lower index first)
 #pragma unroll
-      for (int q = 0; q < VK_MAX_C_PER_LANE; q++)
-        if (navail[q] && (bi == 0x7fffffff || nv[q] > bv)) {
-          bv = nv[q];
-          bi = lane + 64 * q;
-        }
+      for (int q2 = 0; q2 < CPL; q2++) {
+        for (int l2 = 0; l2 < 64; l2++) {
+          const int c2 = q2 * 64 + l2;
+          if (c2 >= cnt) break;
+          const bool k2 = __builtin_amdgcn_readlane((int)keep[q2], l2) != 0;
+          if (!k2) continue;
+          const double v2 = readlane_f64(nv[q2], l2);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        double v2 = __shfl_xor(bv, o, 64);
-        int i2 = __shfl_xor(bi, o, 64);
-        bool take = (i2 != 0x7fffffff) && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi));
-        if (take) {
-          bv = v2;
-          bi = i2;
+          for (int q = 0; q < CPL; q++) {
+            const int c = lane + 64 * q;
+            nrank[q] += (v2 > nv[q] || (v2 == nv[q] && c2 < c)) ? 1 : 0;
+          }
         }
       }
-      // worst remaining old state (min value, lowest index on ties)
-      double wv = INFINITY;
-      int wi = 0x7fffffff;
+      // ascending rank of each old state (ties: lower index first)
 #pragma unroll
-      for (int q = 0; q < VK_MAX_S_PER_LANE; q++)
-        if (oavail[q] && (wi == 0x7fffffff || ov[q] < wv)) {
-          wv = ov[q];
-          wi = lane + 64 * q;
-        }
+      for (int q2 = 0; q2 < SPL; q2++) {
+        for (int l2 = 0; l2 < 64; l2++) {
+          const int s2 = q2 * 64 + l2;
+          if (s2 >= S) break;
+          const double v2 = readlane_f64(ov[q2], l2);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        double v2 = __shfl_xor(wv, o, 64);
-        int i2 = __shfl_xor(wi, o, 64);
-        bool take = (i2 != 0x7fffffff) && (wi == 0x7fffffff || v2 < wv || (v2 == wv && i2 < wi));
-        if (take) {
-          wv = v2;
-          wi = i2;
+          for (int q = 0; q < SPL; q++) {
+            const int s = lane + 64 * q;
+            orank[q] += (v2 < ov[q] || (v2 == ov[q] && s2 < s)) ? 1 : 0;
+          }
         }
       }
-      if (bi == 0x7fffffff || wi == 0x7fffffff || !(bv > wv)) break;
-      // swap: candidate bi -> slot wi
-      for (int w = lane; w < HW; w += 64) st_n[(i64)wi * HW + w] = cd_n[(i64)bi * HW + w];
-      if (lane == 0) lpj_n[wi] = bv;
-      if ((bi & 63) == lane) {
+      // rank-j owners publish (value, index)
 #pragma unroll
-        for (int q = 0; q < VK_MAX_C_PER_LANE; q++)
-          if (q == (bi >> 6)) navail[q] = false;
+      for (int q = 0; q < CPL; q++) {
+        const int c = lane + 64 * q;
+        if (c < cnt && keep[q] && nrank[q] < M) {
+          new_v[wave][nrank[q]] = nv[q];
+          new_i[wave][nrank[q]] = c;
+        }
       }
-      if ((wi & 63) == lane) {
 #pragma unroll
-        for (int q = 0; q < VK_MAX_S_PER_LANE; q++)
-          if (q == (wi >> 6)) oavail[q] = false;
+      for (int q = 0; q < SPL; q++) {
+        const int s = lane + 64 * q;
+        if (s < S && orank[q] < M) {
+          old_v[wave][orank[q]] = ov[q];
+          old_i[wave][orank[q]] = s;
+        }
       }
-      n_sub++;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      // accepted prefix: j-th best candidate strictly better than j-th worst old state
+      int g = 0;
+      bool open = true;
+#pragma unroll
+      for (int q = 0; q < CPL; q++) {
+        const int j = lane + 64 * q;
+        const bool ok = (j < M) && (new_v[wave][j < M ? j : 0] > old_v[wave][j < M ? j : 0]);
+        const u64 m = __ballot(ok);
+        if (open) {
+          const int run = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
+          g += run;
+          if (run < 64) open = false;
+        }
+      }
+      n_sub = g;
+      // swap j: candidate new_i[j] -> slot old_i[j]
+#pragma unroll
+      for (int q = 0; q < CPL; q++) {
+        const int j = lane + 64 * q;
+        if (j < g) {
+          const int bi = new_i[wave][j], wi = old_i[wave][j];
+          for (int w = 0; w < HW; w++) st_n[(i64)wi * HW + w] = cd_n[(i64)bi * HW + w];
+          lpj_n[wi] = new_v[wave][j];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SPL; q++)
+        if (lane + 64 * q < S && orank[q] < g) ov[q] = new_v[wave][orank[q]];
+    }
+    // --- row statistics of the updated row (row_lse_kernel's arithmetic)
+    double m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < SPL; q++)
+      if (lane + 64 * q < S) m = fmax(m, ov[q]);
+    const double perm = S_perm ? lpj_n[-1] : -INFINITY;
+    if (S_perm && lane == 0) m = fmax(m, perm);
+    m = wave_max(m);
+    const double B = 0.0 - m;
+    double z = 0.0;
+#pragma unroll
+    for (int q = 0; q < SPL; q++)
+      if (lane + 64 * q < S) z += exp(ov[q] + B);
+    if (S_perm && lane == 0) z += exp(perm + B);
+    z = wave_sum(z);
+    f = log(z) - B;
+    if (lane == 0) {
+      rowmax[n] = m;
+      rowsum[n] = z;
     }
   }
   if (lane == 0) {
     blk_uniq[wave] = n_uniq;
     blk_sub[wave] = n_sub;
+    wsum[wave] = f;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int u = blk_uniq[0] + blk_uniq[1] + blk_uniq[2] + blk_uniq[3];
-    int s = blk_sub[0] + blk_sub[1] + blk_sub[2] + blk_sub[3];
-    if (u) unsafeAtomicAdd(&sums[0], (double)u);  // integer-valued: order independent
-    if (s) unsafeAtomicAdd(&sums[1], (double)s);
+    // per-workgroup partials, summed in block order by reduce3_partials_kernel: thousands of
+    // atomics on ONE address serialise at ~11 ns each (measured: 2 x 2500 of them were 2/3 of
+    // this kernel's 85 us)
+    const i64 nb = gridDim.x;
+    fpartial[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    fpartial[nb + blockIdx.x] = (double)(blk_uniq[0] + blk_uniq[1] + blk_uniq[2] + blk_uniq[3]);
+    fpartial[2 * nb + blockIdx.x] = (double)(blk_sub[0] + blk_sub[1] + blk_sub[2] + blk_sub[3]);
   }
 }

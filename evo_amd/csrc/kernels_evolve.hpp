@@ -34,6 +34,7 @@ __device__ __forceinline__ double rng_u01(u64 seed, u64 n, u64 purpose, u64 inde
 #define EV_MAX_S_PER_LANE 16
 #define EV_MAX_CHILDREN 8
 
+template <int SPL>
 __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, i64 N, int S, int S_perm, int H, int HW,
     int n_parents, int n_children, int Cmax, u64 seed, int fit_parents, u64 *__restrict__ cand,
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
   int *sel = sel_sh[wave];
   const double *row = lpj + n * (S + S_perm) + S_perm;
   // ---- parent selection
-  double key[EV_MAX_S_PER_LANE];
+  double key[SPL];
   double lmin = INFINITY;
 #pragma unroll
-  for (int q = 0; q < EV_MAX_S_PER_LANE; q++) {
+  for (int q = 0; q < SPL; q++) {
     int s = lane + 64 * q;
     key[q] = (s < S) ? row[s] : INFINITY;
     lmin = fmin(lmin, key[q]);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
   for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_xor(lmin, o, 64));
   const double shift = 2.0 * fmin(lmin, 0.0);
 #pragma unroll
-  for (int q = 0; q < EV_MAX_S_PER_LANE; q++) {
+  for (int q = 0; q < SPL; q++) {
     int s = lane + 64 * q;
     if (s < S) {
       const double p = fit_parents ? (key[q] - shift) : 1.0;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     double bv = INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < EV_MAX_S_PER_LANE; q++)
+    for (int q = 0; q < SPL; q++)
       if (key[q] < bv) {
         bv = key[q];
         bi = lane + 64 * q;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     if (lane == 0) sel[j] = bi;
     if ((bi & 63) == lane) {
 #pragma unroll
-      for (int q = 0; q < EV_MAX_S_PER_LANE; q++)
+      for (int q = 0; q < SPL; q++)
         if (q == (bi >> 6)) key[q] = INFINITY;
     }
   }

@@ -43,7 +43,7 @@ struct SsscArgs {
   // STATS mode
   const double *lpj_in;  // (N, ldo) rows incl. permanent column
   const double *rowmax, *rowsum;
-  double *Es, *Ez;        // (N, ldE) rows of first moments xpt_s / xpt_sz per datapoint
+  double *Es, *Ez, *Ed;   // (N, ldE) rows per datapoint: xpt_s, xpt_sz and the DIAGONAL of xpt_szsz
   int ldE;
   double *xss, *xszsz;    // (H,H) zero-initialised
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
@@ -54,7 +54,7 @@ struct SsscArgs {
 template <int K>
 __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K], double (*P)[K], bool with_P,
                                               double &logdet, bool &singular) {
-  logdet = 0.0;
+  LogDetAcc ld;
 #pragma unroll
   for (int p = 0; p < K; p++) {
     int piv = p;
@@ -91,8 +91,9 @@ __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K],
     }
     const double d = T[p][p];
     if (d == 0.0) singular = true;
-    logdet += log(fabs(d));
-    const double r = 1.0 / d;
+    ld.mul(d);
+    const double r = fast_rcp(d);
+    T[p][p] = r;  // keep the reciprocal for the back substitution
 #pragma unroll
     for (int i = p + 1; i < K; i++) {
       const double f = T[i][p] * r;
@@ -105,10 +106,11 @@ __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K],
       }
     }
   }
+  logdet = ld.value();
   // back substitution (in place: w -> x, P -> Lam)
 #pragma unroll
   for (int p = K - 1; p >= 0; p--) {
-    const double r = 1.0 / T[p][p];
+    const double r = T[p][p];
     double s = w[p];
 #pragma unroll
     for (int j = p + 1; j < K; j++) s -= T[p][j] * w[j];
@@ -123,6 +125,89 @@ __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K],
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Overflow lists.  A single append counter serialises: with one returning atomic per wave the
+// K = 2 pass over 640k pairs took 121 us instead of 16 us as soon as 8 % of the states had k > 2
+// (tools/microbench_lpj.py; one address sustains ~90 returning atomics per us, MI355X guide
+// "dequeue").  Lists are therefore split into LIST_SHARDS shards, chunk c of 64 pairs appends to
+// shard c % LIST_SHARDS (region shard*cap of the list, own counter), and a consumer workgroup
+// rebuilds the global numbering from the 64 counters with one wave scan in LDS.
+// ---------------------------------------------------------------------------------------
+#define LIST_SHARDS 64
+
+struct ListIn {
+  const int *items;   // LIST_SHARDS regions of `cap` entries; nullptr = natural order
+  const int *counts;  // LIST_SHARDS counters
+  int cap;
+};
+struct ListOut {
+  int *items;
+  int *counts;
+  int cap;
+};
+
+// Block-aggregated append: every thread of the workgroup calls block_append once per loop
+// iteration (uniform control flow: it contains barriers).  Lanes with `over` set are packed into
+// an LDS buffer (one LDS atomic per wave, ballot prefix inside the wave), then ONE returning
+// global atomic per workgroup reserves the range in the shard's region and the buffer is copied
+// out coalesced.  Measured on the c2 shape with 8 % of the states overflowing: 121 us with one
+// global counter and an atomic per wave, 57 us sharded per wave, vs 15 us without any append.
+template <int BS>
+__device__ __forceinline__ void block_append(const ListOut &lo, int shard, int value, bool over, int *buf /* LDS BS */,
+                                             int *ctl /* LDS 2 */) {
+  if (threadIdx.x == 0) ctl[0] = 0;
+  __syncthreads();
+  const u64 mask = __ballot(over);
+  int pos = 0;
+  if (mask != 0ull) {
+    const int lane = lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&ctl[0], __popcll(mask));
+    base = __shfl(base, leader, 64);
+    pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (over) buf[pos] = value;
+  }
+  __syncthreads();
+  const int n = ctl[0];
+  if (n == 0) return;  // uniform
+  if (threadIdx.x == 0) ctl[1] = atomicAdd(&lo.counts[shard], n);
+  __syncthreads();
+  const i64 dst = (i64)shard * lo.cap + ctl[1];
+  for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
+}
+
+// prefix[0..64] of the shard counters in LDS; returns the total.  Call with all threads.
+__device__ __forceinline__ int list_prefix(const ListIn &li, int *prefix /* LDS, 65 ints */) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int v = li.counts[lane];
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    prefix[lane + 1] = incl;
+    if (lane == 0) prefix[0] = 0;
+  }
+  __syncthreads();
+  return prefix[LIST_SHARDS];
+}
+
+__device__ __forceinline__ int list_fetch(const ListIn &li, const int *prefix, i64 t) {
+  int lo = 0, hi = LIST_SHARDS;  // find shard with prefix[shard] <= t < prefix[shard+1]
+#pragma unroll
+  for (int it = 0; it < 6; it++) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= t)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return li.items[(i64)lo * li.cap + (int)(t - prefix[lo])];
 }
 
 // Per-(datapoint, state) evaluation with the k x k system in registers (k <= K).
@@ -218,36 +303,46 @@ __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&i
         if (j < k) {
           const i64 o = (i64)idx[i] * a.H + idx[j];
           if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
-          unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
+          if (j != i) unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
         }
       }
     }
   }
 }
 
-// lpj (MODE 0) or statistics (MODE 1) of the pairs in natural order (list_in == nullptr, N*C
-// pairs) or of an overflow list.  Pairs with more than K active latents are appended to list_out.
+// lpj (MODE 0) or statistics (MODE 1) of the pairs in natural order (li.items == nullptr, N*C
+// pairs) or of an overflow list.  Pairs with more than K active latents are appended to `lo`.
 // In MODE 1 this kernel adds into Es / Ez with global atomics (used for the overflow lists only;
-// the main statistics pass is sssc_stats_kernel below).
-template <int K, int MODE>
-__global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *__restrict__ list_in,
-                                                         const int *__restrict__ n_in,
-                                                         int *__restrict__ list_out,
-                                                         int *__restrict__ n_out) {
-  const i64 total = list_in ? (i64)(*n_in) : a.N * (i64)a.C;
-  for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
-    const i64 e = list_in ? (i64)list_in[t] : t;
-    const i64 n = e / a.C;
-    const int c = (int)(e - n * a.C);
-    if (a.counts && c >= a.counts[n]) continue;
-    const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
-    int ktot = 0;
-    for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
-    if (ktot > K) {
-      int pos = atomicAdd(n_out, 1);
-      list_out[pos] = (int)e;
-      continue;
+// the main statistics pass is sssc_stats_kernel below).  TAG only separates instantiations so
+// that profilers report the pass over K^n (0), over the candidate batch (1) and the list-driven /
+// auxiliary launches (2) under different kernel names.  BS = workgroup size.
+template <int K, int MODE, int TAG, int BS>
+__global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo) {
+  __shared__ int prefix[LIST_SHARDS + 1];
+  __shared__ int ovf_buf[BS];
+  __shared__ int ovf_ctl[2];
+  const i64 total = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
+  i64 round = blockIdx.x;
+  for (i64 base = (i64)blockIdx.x * BS; base < total; base += (i64)gridDim.x * BS, round += gridDim.x) {
+    const i64 t = base + threadIdx.x;
+    bool live = t < total;
+    i64 e = 0, n = 0;
+    int c = 0, ktot = 0;
+    const u64 *sp = nullptr;
+    if (live) {
+      e = li.items ? (i64)list_fetch(li, prefix, t) : t;
+      const unsigned eu = (unsigned)e;  // N*C < 2^31 (checked by evoamd_configure)
+      n = (i64)(eu / (unsigned)a.C);
+      c = (int)(eu - (unsigned)n * (unsigned)a.C);
+      live = !(a.counts && c >= a.counts[n]);
     }
+    if (live) {
+      sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
+      for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+    }
+    const bool over = live && ktot > K;
+    block_append<BS>(lo, (int)(round & (LIST_SHARDS - 1)), (int)e, over, ovf_buf, ovf_ctl);
+    if (!live || over) continue;  // no barrier below this point in the iteration
     double qn = 0.0;
     if (MODE == 1) {
       const double l = a.lpj_in[n * a.ldo + a.col0 + c];
@@ -270,6 +365,7 @@ __global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *
         if (i < k) {
           unsafeAtomicAdd(&a.Es[n * a.ldE + idx[i]], qn);
           unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[i]], qn * kap[i]);
+          unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
         }
       }
       sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
@@ -284,25 +380,31 @@ __global__ __launch_bounds__(256) void sssc_small_kernel(SsscArgs a, const int *
 // more than K active latents go to list_out and are added by the overflow kernels afterwards
 // (stream order guarantees their atomics land after the row stores).
 template <int K>
-__global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, int *__restrict__ list_out,
-                                                         int *__restrict__ n_out) {
-  extern __shared__ double rows[];  // npb x 2 x H
+__global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, ListOut lo) {
+  extern __shared__ double rows[];  // npb x 3 x H : xpt_s | xpt_sz | diag(xpt_szsz)
+  __shared__ int ovf_buf[256];
+  __shared__ int ovf_ctl[2];
   const i64 n0 = (i64)blockIdx.x * npb;
   const int nrows = (int)((n0 + npb <= a.N) ? npb : (a.N - n0));
-  for (int i = threadIdx.x; i < nrows * 2 * a.H; i += 256) rows[i] = 0.0;
+  for (int i = threadIdx.x; i < nrows * 3 * a.H; i += 256) rows[i] = 0.0;
   __syncthreads();
   const int work = nrows * a.C;
-  for (int t = threadIdx.x; t < work; t += 256) {
-    const int r = t / a.C, c = t - r * a.C;
-    const i64 n = n0 + r;
-    const u64 *sp = a.states + (n * (i64)a.C + c) * a.HW;
-    int ktot = 0;
-    for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
-    if (ktot > K) {
-      int pos = atomicAdd(n_out, 1);
-      list_out[pos] = (int)(n * a.C + c);
-      continue;
+  for (int t0 = 0; t0 < work; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool live = t < work;
+    int r = 0, c = 0, ktot = 0;
+    i64 n = n0;
+    const u64 *sp = nullptr;
+    if (live) {
+      r = t / a.C;
+      c = t - r * a.C;
+      n = n0 + r;
+      sp = a.states + (n * (i64)a.C + c) * a.HW;
+      for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
     }
+    const bool over = live && ktot > K;
+    block_append<256>(lo, (int)(blockIdx.x & (LIST_SHARDS - 1)), (int)(n * a.C + c), over, ovf_buf, ovf_ctl);
+    if (!live || over) continue;
     const double l = a.lpj_in[n * a.ldo + a.col0 + c];
     const double q = exp(l + (0.0 - a.rowmax[n]));
     if (q == 0.0) continue;
@@ -312,12 +414,13 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, in
     bool singular = false;
     sssc_eval_regs<K, 1>(a, n, sp, idx, k, val, kap, P, singular);
     if (singular) atomicOr(a.err, 2);
-    double *es = rows + (size_t)r * 2 * a.H, *ez = es + a.H;
+    double *es = rows + (size_t)r * 3 * a.H, *ez = es + a.H, *ed = ez + a.H;
 #pragma unroll
     for (int i = 0; i < K; i++) {
       if (i < k) {
         unsafeAtomicAdd(&es[idx[i]], qn);
         unsafeAtomicAdd(&ez[idx[i]], qn * kap[i]);
+        unsafeAtomicAdd(&ed[idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
       }
     }
     sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
@@ -325,8 +428,9 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, in
   __syncthreads();
   for (int i = threadIdx.x; i < nrows * a.H; i += 256) {
     const int r = i / a.H, h = i - r * a.H;
-    a.Es[(n0 + r) * a.ldE + h] = rows[(size_t)r * 2 * a.H + h];
-    a.Ez[(n0 + r) * a.ldE + h] = rows[(size_t)r * 2 * a.H + a.H + h];
+    a.Es[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + h];
+    a.Ez[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + a.H + h];
+    a.Ed[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + 2 * a.H + h];
   }
 }
 
@@ -346,8 +450,8 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 // LDS: Tm[k*k] | Pm[k*k] | idx[KCAP] ints | vectors b, mu, v, w, f  (dynamic shared memory
 // sized for KCAP by the launcher).
 template <int MODE>
-__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, const int *__restrict__ list_in,
-                                                      const int *__restrict__ n_in) {
+__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
+  __shared__ int prefix[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   double *Tm = lds;
   double *Pm = Tm + SSSC_KCAP * SSSC_KCAP;
@@ -358,9 +462,9 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, const int *__r
   double *fv = wv + SSSC_KCAP;
   int *idx = (int *)(fv + SSSC_KCAP);
   const int lane = threadIdx.x;
-  const i64 total = list_in ? (i64)(*n_in) : a.N * (i64)a.C;
+  const i64 total = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
-    const i64 e = list_in ? (i64)list_in[t] : t;
+    const i64 e = li.items ? (i64)list_fetch(li, prefix, t) : t;
     const i64 n = e / a.C;
     const int c = (int)(e - n * a.C);
     if (a.counts && c >= a.counts[n]) continue;  // uniform
@@ -510,16 +614,23 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, const int *__r
         fv[lane] = kap;
         unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
         unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
+        unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
       }
       __syncthreads();
       for (int q = lane; q < k * k; q += 64) {
         const int i = q / k, j = q - i * k;
         const i64 o = (i64)idx[i] * a.H + idx[j];
         if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
-        unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
+        if (j != i) unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
       }
     }
   }
+}
+
+// M[h][h] = d[h]
+__global__ __launch_bounds__(256) void set_diag_kernel(double *__restrict__ M, const double *__restrict__ d, int H) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h < H) M[(i64)h * H + h] = d[h];
 }
 
 // GP[i][j] = {G[i][j], Psi[i][j]}
