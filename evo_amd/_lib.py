@@ -35,6 +35,7 @@ SIGNATURES = {
     "evoamd_ctx_create": (_I, [_I, ctypes.POINTER(_vp)]),
     "evoamd_ctx_destroy": (None, [_vp]),
     "evoamd_synchronize": (_I, [_vp]),
+    "evoamd_set_option": (_I, [_vp, ctypes.c_char_p, _I]),
     "evoamd_configure": (_I, [_vp, _I, _I64, _I, _I, _I, _I, _I]),
     "evoamd_upload_data": (_I, [_vp, _c_dp]),
     "evoamd_upload_states": (_I, [_vp, _c_u8p]),

@@ -115,6 +115,7 @@ struct evoamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
+  bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
   int model = 0;
   i64 N = 0;
@@ -312,6 +313,16 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   delete c;
 }
 
+extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
+  REQUIRE(c && name, "bad arguments");
+  if (strcmp(name, "bsc_direct") == 0) {
+    c->bsc_direct = value != 0;
+    c->have_params = false;  // G / B are (not) needed: set_params again
+    return 0;
+  }
+  return fail(EVOAMD_E_INVALID, "unknown option '%s'", name);
+}
+
 extern "C" int evoamd_synchronize(evoamd_ctx *c) {
   REQUIRE(c, "ctx is NULL");
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -405,6 +416,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->err, 4);
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Wt, (size_t)H * D);
+    ALLOC(c->G, (size_t)H * H);
+    ALLOC(c->Bm, (size_t)N * H);
   } else {
     ALLOC(c->G, (size_t)H * H);
     ALLOC(c->Psi, (size_t)H * H);
@@ -556,7 +569,16 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(wt, W, (size_t)c->D * c->H * sizeof(double));
   HIP_TRY(hipMemcpyAsync(c->W, wt, (size_t)c->D * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->B_valid = false;
+  if (!c->bsc_direct) {
+    int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D);  // G = W^T W
+    if (r) return r;
+    if (c->have_data) {
+      r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);  // B = Y W
+      if (r) return r;
+      c->B_valid = true;
+    }
+  }
   c->have_params = true;
   return 0;
 }
@@ -614,7 +636,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
 
 // B = Y W depends on both the data and Theta; recompute it if either arrived later.
 static int ensure_B(evoamd_ctx *c) {
-  if (c->model != EVOAMD_MODEL_SSSC || c->B_valid) return 0;
+  if (c->B_valid || (c->model == EVOAMD_MODEL_BSC && c->bsc_direct)) return 0;
   int r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
   if (r) return r;
   c->B_valid = true;
@@ -640,6 +662,21 @@ struct Batch {
 };
 
 static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
+  if (!c->bsc_direct && b.tag != 2) {
+    const i64 total = b.N * (i64)b.C;
+    unsigned grid = cdiv(total, 256);
+    SpanGuard g(c, b.kid);
+#define GRAM_LAUNCH(TAG)                                                                                       \
+  bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
+                                                        c->H, c->HW, c->pre1, c->pil_bar, b.out, b.ldo, b.col0, b.flags)
+    if (b.tag == 0)
+      GRAM_LAUNCH(0);
+    else
+      GRAM_LAUNCH(1);
+#undef GRAM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int nchunk = (b.C + BSC_CHUNK - 1) / BSC_CHUNK;
   const unsigned grid = cdiv(b.N * nchunk, 4);
   SpanGuard g(c, b.kid);

@@ -197,15 +197,15 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
       bool dup = false;
       for (int s = lane; s < S && !dup; s += 64) {
         const u64 *sw = st_n + (i64)s * HW;
-        bool eq = true;
-        for (int w = 0; w < HW; w++) eq = eq && (sw[w] == cw[w]);
-        dup = eq;
+        int w = 0;
+        while (w < HW && sw[w] == cw[w]) w++;  // almost always stops at the first differing word
+        dup = (w == HW);
       }
       for (int c2 = lane; c2 < c && !dup; c2 += 64) {
         const u64 *sw = cd_n + (i64)c2 * HW;
-        bool eq = true;
-        for (int w = 0; w < HW; w++) eq = eq && (sw[w] == cw[w]);
-        dup = eq;
+        int w = 0;
+        while (w < HW && sw[w] == cw[w]) w++;
+        dup = (w == HW);
       }
       if (S_perm && lane == 0 && !dup) {
         bool zero = true;

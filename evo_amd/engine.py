@@ -47,6 +47,9 @@ class Engine:
     def synchronize(self):
         check(self.lib.evoamd_synchronize(self._h))
 
+    def set_option(self, name, value):
+        check(self.lib.evoamd_set_option(self._h, name.encode(), int(value)))
+
     # ---- geometry / uploads --------------------------------------------------------------
     def configure(self, model, N, D, H, S, S_perm=0, Cmax=16):
         self.model = MODEL_BSC if model in (MODEL_BSC, "bsc", "BSC") else MODEL_SSSC

@@ -62,6 +62,10 @@ int evoamd_device_count(int *count);
 int evoamd_ctx_create(int device, evoamd_ctx **out);
 void evoamd_ctx_destroy(evoamd_ctx *ctx);
 int evoamd_synchronize(evoamd_ctx *ctx);
+/* Options: "bsc_direct" (0/1, default 0): evaluate EBSC batches with the direct residual kernel
+ * (the reference's arithmetic, bsc.py:91-93) instead of the Gram-form kernel.  Takes effect at the
+ * next evoamd_set_params_bsc. */
+int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */
 /* Allocates device storage for N datapoints on this rank: Y (N,D), K^n (N,S,HW) packed,

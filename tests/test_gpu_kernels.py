@@ -38,13 +38,20 @@ def test_lpj_bsc_kat(engine):
     engine.upload_states(np.tile(states[None], (N, 1, 1)))
     ljc = engine.set_params_bsc(g["W"], float(g["pi"]), float(g["sigma"]))
     np.testing.assert_allclose(ljc, float(g["ljc"]), rtol=1e-14)
-    engine.lpj_resident()
-    _close(engine.download_lpj(), g["lpj"], 1e-13, "resident")
+    engine.lpj_resident()                      # Gram-form batch kernel (k from 0 to H)
+    _close(engine.download_lpj(), g["lpj"], 1e-11, "resident, Gram form")
     _close(engine.lpj_shared(states), g["lpj"], 1e-13, "shared")
     for n in range(N):
         out, flags = engine.lpj_single(Y[n], states)
         _close(out, g["lpj"][n], 1e-13, "single")
         assert not flags.any()
+    try:                                       # direct residual form: the reference's own arithmetic
+        engine.set_option("bsc_direct", 1)
+        engine.set_params_bsc(g["W"], float(g["pi"]), float(g["sigma"]))
+        engine.lpj_resident()
+        _close(engine.download_lpj(), g["lpj"], 1e-13, "resident, direct form")
+    finally:
+        engine.set_option("bsc_direct", 0)
 
 
 def test_lpj_sssc_kat(engine):

@@ -39,6 +39,16 @@ def make_suff(g, ss):
     }
 
 
+@pytest.mark.parametrize("name", ["ebsc_bars", "ebsc_mid", "ebsc_dense"])
+def test_trajectory_bsc_direct_form(engine, name):
+    """Same trajectories with the cancellation-free direct EBSC kernel selected."""
+    try:
+        engine.set_option("bsc_direct", 1)
+        test_trajectory_reference_rng(engine, name)
+    finally:
+        engine.set_option("bsc_direct", 0)
+
+
 @pytest.mark.parametrize("name", STEP_FIXTURES)
 def test_trajectory_reference_rng(engine, name):
     """Theta and K^n are carried from step to step (not reloaded), so errors would compound:
