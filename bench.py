@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-mstep", action="store_true", help="Theta update with host NumPy (reference formulas)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -147,7 +148,8 @@ def main():
     eng = Engine()  # LOCAL_RANK selects the GPU
     comm = parallel.init_rccl_from_env(eng)
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
-    model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17)
+    model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17,
+                device_mstep=not args.host_mstep)
     my_data, theta, suff = make_problem(cfg, 1234 + 2 + 1000 * rank, model)
     if world > 1:  # every rank must start from the same Theta (the reference broadcasts rank 0's)
         theta = {k: comm.bcast(v) for k, v in theta.items()}
@@ -172,7 +174,7 @@ def main():
         dt = comm.allreduce_max(dt)
     kernel_ms = {}
     for name in ("lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse", "vary_kn", "stats", "stats_overflow",
-                 "gemm_f64", "evolve", "misc"):
+                 "gemm_f64", "evolve", "misc", "mstep_device"):
         avg, n = eng.kernel_time_ms(name)
         if n:
             kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_step": n / max(1, args.steps)}
@@ -191,7 +193,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_per_gpu": cfg["N"], "N_total": N_tot,
                        "D": cfg["D"], "H": cfg["H"], "S": cfg["S"], "ea": "fit/randflip 10 parents x 1 child x 1 gen",
-                       "rng": "device", "parallelism": "dp%d" % world, "free_energy_last": F,
+                       "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world, "free_energy_last": F,
                        "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms},
             "roofline": {"bound": "hbm", "kernel": "sssc_small_kernel<4,0> (lpj over K^n)" if cfg["algo"] == "es3c"
                          else "bsc_lpj_kernel (lpj over K^n)",

@@ -18,7 +18,7 @@ MODEL_BSC, MODEL_SSSC = 0, 1
 # kernel-class ids of evoamd_kernel_time_ms (evo_amd.hip: KID_*)
 KERNEL_IDS = {
     "lpj_resident": 0, "lpj_candidates": 1, "lpj_overflow": 2, "row_lse": 3, "vary_kn": 4,
-    "stats": 5, "stats_overflow": 6, "gemm_f64": 7, "evolve": 8, "misc": 9,
+    "stats": 5, "stats_overflow": 6, "gemm_f64": 7, "evolve": 8, "misc": 9, "mstep_device": 10,
 }
 
 _c_dp = ctypes.POINTER(ctypes.c_double)
@@ -53,6 +53,9 @@ SIGNATURES = {
     "evoamd_evolve_randflip": (_I, [_vp, _I, _I, _U64, _I]),
     "evoamd_acc_size": (_I64, [_vp]),
     "evoamd_stats": (_I, [_vp, _c_dp]),
+    "evoamd_mstep_device": (_I, [_vp, _I, _c_dp, _c_dp]),
+    "evoamd_get_params_bsc": (_I, [_vp, _c_dp, _c_dp, _c_dp]),
+    "evoamd_get_params_sssc": (_I, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
     "evoamd_free_energy": (_I, [_vp, _c_dp, _I64, _I, _c_dp]),
     "evoamd_set_estep_counts": (_I, [_vp, _DBL, _DBL]),
     "evoamd_comm_unique_id": (_I, [_c_u8p]),

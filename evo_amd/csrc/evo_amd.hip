@@ -17,6 +17,7 @@
 #include "kernels_bsc.hpp"
 #include "kernels_common.hpp"
 #include "kernels_evolve.hpp"
+#include "kernels_mstep.hpp"
 #include "kernels_sssc.hpp"
 
 // ---------------------------------------------------------------------------------------
@@ -103,6 +104,7 @@ enum {  // internal kernel ids (see evoamd_kernel_name)
   KID_GEMM,
   KID_EVOLVE,
   KID_MISC,
+  KID_MSTEP,
   KID_COUNT
 };
 
@@ -139,7 +141,11 @@ struct evoamd_ctx {
   double *W = nullptr, *Wt = nullptr, *G = nullptr, *Psi = nullptr, *Bm = nullptr, *mus = nullptr,
          *pilbar_v = nullptr;
   double2 *GP = nullptr;
-  double pre1 = 0, pil_bar = 0, s2inv = 0, ljc = 0;
+  double *pies = nullptr;            // SSSC (H)
+  double *dpar = nullptr;            // device scalar block (DP_*), kernels read their scalars here
+  double *h_dpar = nullptr;          // pinned mirror
+  double *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;  // (H,H) scratch of the device Theta update
+  double ljc = 0;
   // statistics
   double *acc = nullptr;
   i64 acc_n = 0;
@@ -289,6 +295,7 @@ static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
+                  c->pies,   c->dpar,   c->tmpA,    c->tmpB,    c->tmpC,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
   for (void *p : ptrs)
@@ -296,6 +303,7 @@ static void free_all(evoamd_ctx *c) {
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
   if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->h_dpar) (void)hipHostFree(c->h_dpar);
 }
 
 extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
@@ -405,6 +413,10 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->stage_bytes = (size_t)N * SC * H;
   ALLOC(c->stage, c->stage_bytes);
   ALLOC(c->W, (size_t)D * H);
+  ALLOC(c->dpar, DP_COUNT);
+  ALLOC(c->tmpA, (size_t)H * H);
+  ALLOC(c->tmpB, (size_t)H * H);
+  ALLOC(c->tmpC, (size_t)H * H);
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Es, (size_t)N * H);
   } else {
@@ -425,6 +437,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->Bm, (size_t)N * H);
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
+    ALLOC(c->pies, (size_t)H);
     c->list_words = 0;
     int rl = ensure_lists(c, (i64)N * SC);
     if (rl) return rl;
@@ -433,7 +446,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
   if (!c->h_err) HIP_TRY(hipHostMalloc((void **)&c->h_err, 4 * sizeof(int), hipHostMallocDefault));
-  c->h_par_n = (size_t)D * H + (size_t)H * H + 2 * (size_t)H;
+  if (!c->h_dpar) HIP_TRY(hipHostMalloc((void **)&c->h_dpar, (DP_COUNT + 8) * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipMemsetAsync(c->dpar, 0, DP_COUNT * sizeof(double), c->stream));
+  c->h_par_n = (size_t)D * H + (size_t)H * H + 3 * (size_t)H;
   HIP_TRY(hipHostMalloc((void **)&c->h_acc, (size_t)c->acc_n * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&c->h_par, c->h_par_n * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMemsetAsync(c->Y, 0, (size_t)N * c->ldY * sizeof(double), c->stream));
@@ -518,13 +533,13 @@ extern "C" int evoamd_download_lpj(evoamd_ctx *c, double *lpj) {
 // ---------------------------------------------------------------------------------------
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
-                          int M, int Nc, i64 K) {
+                          int M, int Nc, i64 K, bool deterministic = false) {
   const unsigned gx = cdiv(Nc, GEMM_BN), gy = cdiv(M, GEMM_BM);
   // no prefetch in the tile loop yet, so latency is hidden by parallelism: aim for >= 512
   // workgroups, at least 64 rows of K per split
   i64 splits = 1;
   const i64 tiles = (i64)gx * gy;
-  if (K >= 128) {
+  if (K >= 128 && !deterministic) {  // split-K sums with atomics: order (hence last bits) varies
     splits = (512 + tiles - 1) / tiles;
     const i64 maxs = (K + 63) / 64;
     if (splits > maxs) splits = maxs;
@@ -556,10 +571,16 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   REQUIRE(W, "W is NULL");
   HIP_TRY(hipSetDevice(c->device));
   // bsc.py:111-121 (complete data)
-  c->pre1 = -1.0 / 2.0 / sigma / sigma;
-  c->pil_bar = log(pi / (1.0 - pi));
   c->ljc = c->H * log(1.0 - pi) - c->D / 2.0 * log(2 * M_PI * sigma * sigma);
   if (ljc) *ljc = c->ljc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // pinned mirrors may still be in flight
+  memset(c->h_dpar, 0, DP_COUNT * sizeof(double));
+  c->h_dpar[DP_PRE1] = -1.0 / 2.0 / sigma / sigma;
+  c->h_dpar[DP_PILBAR] = log(pi / (1.0 - pi));
+  c->h_dpar[DP_LJC] = c->ljc;
+  c->h_dpar[DP_PI] = pi;
+  c->h_dpar[DP_SIGMA] = sigma;
+  HIP_TRY(hipMemcpyAsync(c->dpar, c->h_dpar, DP_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
   // W^T on the host (H x D); tiny
   HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned staging area may still be in flight
   double *wt = c->h_par;                      // D*H doubles
@@ -591,7 +612,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   const int H = c->H, D = c->D;
   // sssc.py:340-353: sigma2 through long double, rounded back to double
   const long double s2 = (long double)sigma2;
-  c->s2inv = (double)(1.0L / s2);
+  const double s2inv = (double)(1.0L / s2);
   double l = 0.0;
   std::vector<double> pb(H);
   {
@@ -610,11 +631,18 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   if (ljc) *ljc = l;
   HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned staging area may still be in flight
   {
-    double *hw = c->h_par, *hpsi = hw + (size_t)D * H, *hmu = hpsi + (size_t)H * H, *hpb = hmu + H;
+    double *hw = c->h_par, *hpsi = hw + (size_t)D * H, *hmu = hpsi + (size_t)H * H, *hpb = hmu + H, *hpi = hpb + H;
     memcpy(hw, W, (size_t)D * H * sizeof(double));
     memcpy(hpsi, Psi, (size_t)H * H * sizeof(double));
     memcpy(hmu, mus, (size_t)H * sizeof(double));
     memcpy(hpb, pb.data(), (size_t)H * sizeof(double));
+    memcpy(hpi, pies, (size_t)H * sizeof(double));
+    memset(c->h_dpar, 0, DP_COUNT * sizeof(double));
+    c->h_dpar[DP_S2INV] = s2inv;
+    c->h_dpar[DP_SIGMA2] = sigma2;
+    c->h_dpar[DP_LJC] = l;
+    HIP_TRY(hipMemcpyAsync(c->dpar, c->h_dpar, DP_COUNT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pies, hpi, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->W, hw, (size_t)D * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->Psi, hpsi, (size_t)H * H * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->mus, hmu, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -668,7 +696,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     SpanGuard g(c, b.kid);
 #define GRAM_LAUNCH(TAG)                                                                                       \
   bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
-                                                        c->H, c->HW, c->pre1, c->pil_bar, b.out, b.ldo, b.col0, b.flags)
+                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags)
     if (b.tag == 0)
       GRAM_LAUNCH(0);
     else
@@ -682,7 +710,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
   SpanGuard g(c, b.kid);
 #define BSC_LAUNCH(R)                                                                                     \
   bsc_lpj_kernel<R><<<grid, 256, 0, c->stream>>>(b.Y, c->Wt, b.states, b.counts, b.N, b.C, b.C, b.shared, \
-                                                  c->D, c->HW, c->pre1, c->pil_bar, b.out, b.ldo, b.col0, b.flags)
+                                                  c->D, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags)
   if (c->D <= 64)
     BSC_LAUNCH(1);
   else if (c->D <= 128)
@@ -703,7 +731,8 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.GP = c->GP;
   a.mus = c->mus;
   a.pil_bar = c->pilbar_v;
-  a.s2inv = c->s2inv;
+  a.s2inv = 0.0;
+  a.dpar = c->dpar;
   a.N = b.N;
   a.C = b.C;
   a.shared = b.shared;
@@ -785,8 +814,8 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
   c->rows_fresh = false;
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
   if (c->S_perm) {
-    const double pre = (c->model == EVOAMD_MODEL_BSC) ? c->pre1 : -0.5 * c->s2inv;
-    allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, pre, c->lpj, c->L, c->flags + 2 * c->N);
+    allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, c->dpar, c->model == EVOAMD_MODEL_SSSC,
+                                                               c->lpj, c->L, c->flags + 2 * c->N);
     HIP_TRY(hipGetLastError());
   }
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
@@ -1024,9 +1053,10 @@ static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowma
   return 0;
 }
 
-extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
+// Everything of evoamd_stats up to (and including) the all-reduce; the packed accumulator stays on
+// the device.  tail[7] receives ljc of the Theta the E-step ran with.
+static int stats_compute(evoamd_ctx *c) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
-  REQUIRE(acc_out, "acc_out is NULL");
   HIP_TRY(hipSetDevice(c->device));
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
@@ -1049,7 +1079,7 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
     {
       SpanGuard g(c, KID_STATS);
       bsc_stats_kernel<<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(
-          c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->pre1, c->pil_bar, c->Es,
+          c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->dpar, c->Es,
           c->acc + a.Wq, c->partial2);
       HIP_TRY(hipGetLastError());
     }
@@ -1117,8 +1147,7 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   }
   // tail: N and the reset counters (per-call priority semantics)
   {
-    c->h_acc[0] = (double)N;
-    HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 3, c->h_acc, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    set_scalar_kernel<<<1, 1, 0, c->stream>>>(c->acc + a.tail + 3, (double)N);
     for (int k = 0; k < 3; k++)
       count_flags_kernel<<<64, 256, 0, c->stream>>>(c->flags + (size_t)k * N, N, c->acc + a.tail + 4);
     HIP_TRY(hipGetLastError());
@@ -1126,12 +1155,164 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
+  // ljc is a property of Theta, not a sum over ranks: written after the all-reduce
+  HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 7, c->dpar + DP_LJC, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
+  REQUIRE(acc_out, "acc_out is NULL");
+  int r = stats_compute(c);
+  if (r) return r;
+  const AccLayout a = acc_layout(c);
   HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc, (size_t)c->acc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   // the E-step counts have been consumed
   HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
   r = check_err(c);  // synchronises the stream
   memcpy(acc_out, c->h_acc, (size_t)c->acc_n * sizeof(double));
   return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// device-side Theta update
+// ---------------------------------------------------------------------------------------
+// Inverts A (and B, if not null) in place; the two are independent.
+static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
+  const size_t aux = (size_t)2 * n * sizeof(double) + (size_t)n * sizeof(int);
+  if (n <= GJR_N) {
+    gj_inverse_reg_kernel<<<B ? 2 : 1, MS_T, 0, c->stream>>>(A, B, n, c->dpar + DP_STATUS);
+  } else {
+    gj_inverse_kernel<<<1, MS_T, aux, c->stream>>>(A, n, c->dpar + DP_STATUS);
+    if (B) gj_inverse_kernel<<<1, MS_T, aux, c->stream>>>(B, n, c->dpar + DP_STATUS);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Theta^new from the device accumulator (which evoamd_stats / stats_compute left behind), clamps,
+// precompute and the dense G / B refresh; all stream-ordered, no host arithmetic.
+static int update_params_device(evoamd_ctx *c, int learn) {
+  const AccLayout a = acc_layout(c);
+  const int H = c->H, D = c->D;
+  const i64 HH = (i64)H * H;
+  const double *Nptr = c->acc + a.tail + 3;
+  int r = 0;
+  SpanGuard g(c, KID_MSTEP);
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    // mus / pies first (Psi needs the NEW mus, sssc.py:733), then both H x H inverses in one launch:
+    // tmpA <- xpt_szsz (for W, sssc.py:693), tmpB <- xpt_ss + eps I (for Psi, sssc.py:738)
+    sssc_update_vectors_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, Nptr, H, learn,
+                                                                    c->pies, c->mus);
+    if (learn & L_W)
+      HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.xszsz, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (learn & L_PSI)
+      sssc_psi_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->mus, c->acc + a.xss, c->acc + a.xszsz,
+                                                                    c->acc + a.s_sz, H, c->tmpC, c->tmpB);
+    if ((learn & L_W) && (learn & L_PSI))
+      r = launch_inverse(c, c->tmpA, c->tmpB, H);
+    else if (learn & L_W)
+      r = launch_inverse(c, c->tmpA, nullptr, H);
+    else if (learn & L_PSI)
+      r = launch_inverse(c, c->tmpB, nullptr, H);
+    if (r) return r;
+    if (learn & L_W)
+      gemm_nn_f64<<<dim3(cdiv(H, GEMM_BN), cdiv(D, GEMM_BM)), 256, 0, c->stream>>>(c->acc + a.sWp, H, c->tmpA, H, c->W,
+                                                                                    H, D, H, H);
+    if (learn & L_PSI)
+      sssc_psi_finish_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->tmpC, c->tmpB, H, c->Psi);
+    else
+      psi_floor_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->Psi, H);
+    HIP_TRY(hipGetLastError());
+    r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, /*deterministic=*/true);  // G = W^T W (new W)
+    if (r) return r;
+    sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->acc + a.sz_sz, c->G, H, Nptr, learn,
+                                                            c->pies, c->pilbar_v, c->dpar);
+    interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP);
+    HIP_TRY(hipGetLastError());
+    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    if (r) return r;
+    c->B_valid = true;
+  } else {
+    if (learn & L_W) {  // W^T = solve(Wq, Wp)  (bsc.py:237; lstsq == solve for a non-singular Wq)
+      HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      r = launch_inverse(c, c->tmpA, nullptr, H);
+      if (r) return r;
+      gemm_nn_f64<<<dim3(cdiv(D, GEMM_BN), cdiv(H, GEMM_BM)), 256, 0, c->stream>>>(c->tmpA, H, c->acc + a.Wp, D, c->Wt,
+                                                                                    D, H, D, H);
+      transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
+    }
+    bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar);
+    HIP_TRY(hipGetLastError());
+    c->B_valid = false;
+    if (!c->bsc_direct) {
+      r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
+      if (r) return r;
+      r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+      if (r) return r;
+      c->B_valid = true;
+    }
+  }
+  return 0;
+}
+
+extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
+  REQUIRE(tail_out && dpar_out, "NULL output");
+  int r = stats_compute(c);
+  if (r) return r;
+  const AccLayout a = acc_layout(c);
+  HIP_TRY(hipMemcpyAsync(c->h_dpar + DP_COUNT, c->acc + a.tail, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (learn_mask) {
+    r = update_params_device(c, learn_mask);
+    if (r) return r;
+  }
+  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_dpar, c->dpar, DP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  r = check_err(c);  // synchronises
+  memcpy(tail_out, c->h_dpar + DP_COUNT, 8 * sizeof(double));
+  memcpy(dpar_out, c->h_dpar, DP_COUNT * sizeof(double));
+  if (r) return r;
+  if (c->h_dpar[DP_STATUS] != 0.0) {
+    HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
+    return fail(EVOAMD_E_SINGULAR, "device Theta update: %s",
+                c->h_dpar[DP_STATUS] == 1.0 ? "singular H x H system (the reference falls back to pinv / lstsq here)"
+                                            : "non-finite sigma / pi");
+  }
+  return 0;
+}
+
+extern "C" int evoamd_get_params_bsc(evoamd_ctx *c, double *W, double *pi, double *sigma) {
+  REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC && c->have_params, "no BSC parameters on the device");
+  REQUIRE(W && pi && sigma, "NULL output");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_par, c->W, (size_t)c->D * c->H * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_dpar, c->dpar, DP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(W, c->h_par, (size_t)c->D * c->H * sizeof(double));
+  *pi = c->h_dpar[DP_PI];
+  *sigma = c->h_dpar[DP_SIGMA];
+  return 0;
+}
+
+extern "C" int evoamd_get_params_sssc(evoamd_ctx *c, double *W, double *pies, double *mus, double *Psi, double *sigma2) {
+  REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_SSSC && c->have_params, "no SSSC parameters on the device");
+  REQUIRE(W && pies && mus && Psi && sigma2, "NULL output");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
+  double *hw = c->h_par, *hpsi = hw + DH, *hmu = hpsi + HH, *hpi = hmu + 2 * H;
+  HIP_TRY(hipMemcpyAsync(hw, c->W, DH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hpsi, c->Psi, HH * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hmu, c->mus, H * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hpi, c->pies, H * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_dpar, c->dpar, DP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(W, hw, DH * sizeof(double));
+  memcpy(Psi, hpsi, HH * sizeof(double));
+  memcpy(mus, hmu, H * sizeof(double));
+  memcpy(pies, hpi, H * sizeof(double));
+  *sigma2 = c->h_dpar[DP_SIGMA2];
+  return 0;
 }
 
 extern "C" int evoamd_free_energy(evoamd_ctx *c, const double *lpj, int64_t N, int C, double *Fs_out) {
@@ -1243,6 +1424,6 @@ extern "C" int evoamd_kernel_time_ms(evoamd_ctx *c, int kid, double *avg_ms, int
 
 extern "C" const char *evoamd_kernel_name(int kid) {
   static const char *names[KID_COUNT] = {"lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse",  "vary_kn",
-                                         "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc"};
+                                         "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc", "mstep_device"};
   return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }

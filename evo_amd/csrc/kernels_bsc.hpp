@@ -2,6 +2,7 @@
 // sufficient statistics (bsc.py:176-223).
 #pragma once
 #include "common.hpp"
+#include "kernels_mstep.hpp"
 
 #define BSC_CHUNK 8  // states handled by one wavefront before it moves on (y_n stays in registers)
 
@@ -19,8 +20,9 @@
 template <int R>
 __global__ __launch_bounds__(256) void bsc_lpj_kernel(
     const double *__restrict__ Y, const double *__restrict__ Wt, const u64 *__restrict__ states,
-    const int *__restrict__ counts, i64 N, int C, int Cstride, int shared, int D, int HW, double pre1,
-    double pil_bar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+    const int *__restrict__ counts, i64 N, int C, int Cstride, int shared, int D, int HW,
+    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+  const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const int lane = lane_id(), wave = wave_id_uniform();
   const int nchunk = (C + BSC_CHUNK - 1) / BSC_CHUNK;
   const i64 g = (i64)blockIdx.x * 4 + wave;
@@ -109,7 +111,8 @@ template <int TAG>
 __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int shared, int H, int HW,
-    double pre1, double pil_bar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+  const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
   for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
     const unsigned tu = (unsigned)t;  // N*C < 2^31
@@ -146,11 +149,13 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
 
 // Permanent all-zero state: lpj = pre * ||y_n||^2 (bsc.py:72 with pre = pre1; sssc.py:237 with
 // pre = -0.5*sigma2_inv).  yy (N) is the precomputed squared norm.  One thread per n.
-__global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N, double pre,
+__global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N,
+                                                          const double *__restrict__ dpar, int sssc,
                                                           double *__restrict__ lpj_out, int ldo,
                                                           unsigned *__restrict__ flags) {
   i64 n = (i64)blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
+  const double pre = sssc ? -0.5 * dpar[DP_S2INV] : dpar[DP_PRE1];
   unsigned fl = 0;
   lpj_out[n * ldo] = clamp_lpj(pre * yy[n], fl);
   if (fl) atomicOr(&flags[n], fl);
@@ -184,9 +189,10 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restric
 __global__ __launch_bounds__(256) void bsc_stats_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
     const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H,
-    int HW, double pre1, double pil_bar, double *__restrict__ Es, double *__restrict__ Wq,
+    int HW, const double *__restrict__ dpar, double *__restrict__ Es, double *__restrict__ Wq,
     double *__restrict__ sig_partial) {
   extern __shared__ double es_lds[];  // 4 waves x H
+  const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   __shared__ double wsig[4];
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;

@@ -31,6 +31,8 @@ __global__ __launch_bounds__(256) void unpack_states_kernel(const u64 *__restric
   out[idx] = (uint8_t)((w >> (63 - (h & 63))) & 1ull);
 }
 
+__global__ void set_scalar_kernel(double *p, double v) { *p = v; }
+
 // One wavefront per datapoint: m_n = max_s lpj_ns, z_n = sum_s exp(lpj_ns - m_n) and the
 // free-energy term f_n = log z_n + m_n  (= logsumexp(lpj_n + B_n) - B_n with B_n = -m_n;
 // _models.py:544-546).  Per-block partial sums of f_n go to partial[blockIdx.x] and are

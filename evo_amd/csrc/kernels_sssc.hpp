@@ -22,6 +22,7 @@
 // second overflow list handled by one wavefront per pair with the system in LDS (k <= 64).
 #pragma once
 #include "common.hpp"
+#include "kernels_mstep.hpp"
 
 struct SsscArgs {
   const u64 *states;     // (shared ? 1 : N) x C x HW
@@ -31,7 +32,8 @@ struct SsscArgs {
   const double2 *GP;     // (H,H) interleaved {G_ij, Psi_ij}
   const double *mus;     // (H)
   const double *pil_bar; // (H)
-  double s2inv;
+  double s2inv;          // filled in by the kernels from dpar[DP_S2INV]
+  const double *dpar;    // device scalar block
   i64 N;
   int C;       // states per datapoint in this batch (row stride of `states`)
   int shared;  // one state set for every n
@@ -318,6 +320,7 @@ __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&i
 // auxiliary launches (2) under different kernel names.  BS = workgroup size.
 template <int K, int MODE, int TAG, int BS>
 __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo) {
+  a.s2inv = a.dpar[DP_S2INV];
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int ovf_buf[BS];
   __shared__ int ovf_ctl[2];
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
 // (stream order guarantees their atomics land after the row stores).
 template <int K>
 __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, ListOut lo) {
+  a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double rows[];  // npb x 3 x H : xpt_s | xpt_sz | diag(xpt_szsz)
   __shared__ int ovf_buf[256];
   __shared__ int ovf_ctl[2];
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 // sized for KCAP by the launcher).
 template <int MODE>
 __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
+  a.s2inv = a.dpar[DP_S2INV];
   __shared__ int prefix[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   double *Tm = lds;

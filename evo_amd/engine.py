@@ -170,6 +170,34 @@ class Engine:
         check(self.lib.evoamd_stats(self._h, dptr(acc)))
         return acc
 
+    LEARN_BITS = {"W": 1, "pies": 2, "pi": 2, "mus": 4, "sigma2": 8, "sigma": 8, "Psi": 16}
+    DPAR = {"pre1": 0, "pil_bar": 1, "sigma2_inv": 2, "ljc": 3, "pi": 4, "sigma": 5, "sigma2": 6, "status": 7}
+
+    def mstep_device(self, to_learn):
+        """Statistics + Theta update on the device.  Returns (tail dict, scalar-parameter dict)."""
+        mask = 0
+        for name in to_learn:
+            mask |= self.LEARN_BITS[name]
+        tail = np.zeros(8)
+        dpar = np.zeros(16)
+        check(self.lib.evoamd_mstep_device(self._h, mask, dptr(tail), dptr(dpar)))
+        t = dict(zip(TAIL, tail))
+        t["ljc"] = tail[7]
+        return t, {k: dpar[i] for k, i in self.DPAR.items()}
+
+    def get_params_bsc(self):
+        W = np.empty((self.D, self.H))
+        pi, sigma = ctypes.c_double(), ctypes.c_double()
+        check(self.lib.evoamd_get_params_bsc(self._h, dptr(W), ctypes.byref(pi), ctypes.byref(sigma)))
+        return {"W": W, "pi": pi.value, "sigma": np.float64(sigma.value)}
+
+    def get_params_sssc(self):
+        W, Psi = np.empty((self.D, self.H)), np.empty((self.H, self.H))
+        pies, mus = np.empty(self.H), np.empty(self.H)
+        s2 = ctypes.c_double()
+        check(self.lib.evoamd_get_params_sssc(self._h, dptr(W), dptr(pies), dptr(mus), dptr(Psi), ctypes.byref(s2)))
+        return {"W": W, "pies": pies, "mus": mus, "Psi": Psi, "sigma2": np.float64(s2.value)}
+
     def free_energy_sum(self, lpj):
         lpj = as_f64(lpj)
         out = ctypes.c_double()
@@ -216,7 +244,7 @@ class Engine:
         return avg.value, n.value
 
 
-TAIL = ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf", "pad")
+TAIL = ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf", "ljc_local")
 
 
 def acc_layout(model, D, H):

@@ -74,7 +74,7 @@ class Model:
     model_name = None  # "bsc" | "sssc"
 
     def __init__(self, D, H, S, to_learn=("W", "pi", "sigma"), comm=None, rng="reference", sync_host=True,
-                 device=None, engine=None, seed=0):
+                 device=None, engine=None, seed=0, device_mstep=False):
         """``D, H, S, to_learn, comm`` as in the reference (_models.py:20-56).  ``comm`` may be an
         mpi4py communicator or one of evo_amd.utils.parallel; None means one rank."""
         if rng not in ("reference", "device"):
@@ -85,6 +85,12 @@ class Model:
         self.to_learn = list(to_learn)
         self.D, self.H, self.S = int(D), int(H), int(S)
         self.rng, self.sync_host, self.seed = rng, bool(sync_host), int(seed)
+        # device_mstep: Theta update, clamps and precompute run on the GPU too (csrc/kernels_mstep.hpp);
+        # an EM iteration is then ONE stream of kernels with a single host sync.  The H x H solves
+        # use Gauss-Jordan instead of LAPACK, so Theta agrees with the host formulas to ~1e-12 but
+        # not bit for bit -- keep it off for rng="reference" parity runs.
+        self.device_mstep = bool(device_mstep)
+        self._dev_theta = None   # the dict whose values mirror the parameters resident on the device
         tol = 1e-5
         self.noise_policy = {  # _models.py:47-52
             "W": (-np.inf, +np.inf, False, None),
@@ -155,6 +161,10 @@ class Model:
     def _push_params(self, model_params):
         raise NotImplementedError
 
+    def _pull_params(self, dpar):
+        """Host copy of the parameters resident on the device + the derived keys of the reference."""
+        raise NotImplementedError
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         raise NotImplementedError
 
@@ -199,10 +209,38 @@ class Model:
             model_params[name] = v
         return model_params
 
+    def _step_device(self, model_params, my_suff_stat, my_data):
+        """EM iteration with the M-step on the device (device_mstep=True)."""
+        if self.comm.size > 1 and not getattr(self.comm, "device_reduces", False):
+            raise ValueError("device_mstep with several ranks needs an RcclComm (device-side all-reduce)")
+        eng = self._prepare(my_suff_stat, my_data)
+        if model_params is not self._dev_theta:  # new host Theta: clamp, precompute, upload
+            model_params = self.check_params(model_params)
+            self.E_step_precompute(model_params, my_suff_stat, my_data)
+        eng.lpj_resident()
+        if self.rng == "reference":
+            self._candidates_reference(eng, model_params, my_suff_stat, my_data)
+        else:
+            self._candidates_device(eng, my_suff_stat)
+        eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
+        self._n_steps += 1
+        tail, dpar = eng.mstep_device(self.to_learn)
+        if self.sync_host:
+            self.sync_to_host(my_suff_stat)
+        my_suff_stat["reset_lpj_isnan"] = int(tail["reset_isnan"])
+        my_suff_stat["reset_lpj_smaller_eps_lpj"] = int(tail["reset_smaller_eps"])
+        my_suff_stat["reset_lpj_isinf"] = int(tail["reset_isinf"])
+        model_params.update(self._pull_params(dpar))
+        self._dev_theta = model_params
+        N = tail["N"]
+        return tail["ljc_local"] + tail["Fs"] / N, tail["sum_nunique"] / N, tail["sum_sub"] / N, model_params
+
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """One EM iteration (_models.py:161-203): check_params -> E_step -> M_step."""
         if do_reconstruction:
             raise NotImplementedError("reconstruct() is outside the accelerated path (SURVEY 8f rank 3)")
+        if self.device_mstep:
+            return self._step_device(model_params, my_suff_stat, my_data)
         model_params = self.check_params(model_params)
         F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
         new_params = (self.M_step(model_params, my_suff_stat, my_data, _from_step=True)

@@ -28,6 +28,11 @@ class BSC(Model):
     def _push_params(self, model_params):
         self.engine.set_params_bsc(model_params["W"], model_params["pi"], model_params["sigma"])
 
+    def _pull_params(self, dpar):
+        th = self.engine.get_params_bsc()
+        th.update(piH=th["pi"] * self.H, pre1=dpar["pre1"], pil_bar=dpar["pil_bar"], ljc=dpar["ljc"])
+        return th
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         """State-independent terms (bsc.py:99-125, complete data) stored into ``model_params``
         under the reference's keys, then Theta is pushed to the device."""

@@ -91,6 +91,12 @@ class SSSC(Model):
         self.engine.set_params_sssc(model_params["W"], model_params["pies"], model_params["mus"],
                                     model_params["Psi"], float(model_params["sigma2"]))
 
+    def _pull_params(self, dpar):
+        th = self.engine.get_params_sssc()
+        th.update(piH=th["pies"].sum(), pil_bar=np.log(th["pies"] / (1.0 - th["pies"])),
+                  sigma2_inv=np.float64(dpar["sigma2_inv"]), ljc=dpar["ljc"])
+        return th
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         """State-independent terms (sssc.py:328-366, complete data): ljc, piH, pil_bar, sigma2_inv
         (through long double like the reference), stored under the reference's keys."""
@@ -111,6 +117,10 @@ class SSSC(Model):
 
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """check_params -> fused EM_step (sssc.py:407-417)."""
+        if do_reconstruction:
+            raise NotImplementedError("reconstruction is outside the accelerated path (SURVEY 8f rank 3)")
+        if self.device_mstep:
+            return self._step_device(model_params, my_suff_stat, my_data)
         model_params = self.check_params(model_params)
         return self.EM_step(model_params, my_suff_stat, my_data, do_reconstruction)
 

@@ -184,3 +184,40 @@ def test_device_rng_mode(engine, algo):
     np.testing.assert_allclose(F2, Fs[-1], rtol=1e-12)
     engine.lpj_resident()
     np.testing.assert_allclose(engine.download_lpj(), lpj_after, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense"])
+def test_device_mstep_matches_host(engine, name):
+    """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
+    instead of LAPACK).  Same inputs as the host path => Theta within 1e-8, F and K^n identical
+    for this step (the E-step is shared), and the reference's Theta within 1e-6."""
+    from evo_amd.models import BSC, SSSC
+    g = load_golden("step_%s.npz" % name)
+    algo = str(g["algo"])
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    Y = g["Y"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    out = {}
+    for mode in (False, True):
+        model = (BSC if algo == "ebsc" else SSSC)(D, H, S, engine=engine, device_mstep=mode)
+        theta = {k: np.array(g["t0_in_%s" % k]) for k in keys}
+        for k in ("pi", "sigma", "sigma2"):
+            if k in theta:
+                theta[k] = np.float64(theta[k])
+        suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+        res = []
+        for t in range(int(g["n_steps"])):
+            np.random.seed(1000 + int(g["seed"]) + t)
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            res.append((F, nu, nsub, {k: np.array(theta[k]) for k in keys}, suff["ss"].copy()))
+        out[mode] = res
+    for t, (h, d) in enumerate(zip(out[False], out[True])):
+        np.testing.assert_allclose(d[0], h[0], rtol=1e-10, err_msg="F step %d" % t)
+        assert d[1:3] == h[1:3]
+        assert np.array_equal(d[4], h[4]), "K^n differs at step %d" % t
+        for k in keys:
+            ref = g["t%d_out_%s" % (t, k)]
+            scale = max(1.0, float(np.abs(ref).max()))
+            np.testing.assert_allclose(d[3][k], h[3][k], rtol=1e-7, atol=1e-9 * scale, err_msg="%s vs host" % k)
+            np.testing.assert_allclose(d[3][k], ref, rtol=1e-6, atol=1e-7 * scale, err_msg="%s vs reference" % k)
