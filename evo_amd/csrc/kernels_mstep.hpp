@@ -34,7 +34,8 @@ enum {
 // Inverse of an n x n matrix, n <= 128, by Gauss-Jordan with partial (row) pivoting, ONE workgroup,
 // the whole matrix in REGISTERS: thread (ti = t>>6, tj = t&63) owns elements (ti + 16 r, tj + 64 c),
 // r < 8, c < 2 (16 doubles).  Per pivot step the threads exchange only column p, the two
-// interchanged rows and the pivot through (double-buffered) LDS: 3 barriers and no matrix traffic.
+// interchanged rows and 16 pivot candidates through (double-buffered) LDS: 2 barriers per step, no
+// cross-lane reduction and no matrix traffic.
 // Rows/columns beyond n are padded with the identity.  Row interchanges are undone as one column
 // permutation when the result is written.  status[0] = 1 on a zero / non-finite pivot.
 #define GJR_N 128
@@ -45,81 +46,73 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
   double *__restrict__ Ag = blockIdx.x == 0 ? A0 : A1;
   __shared__ double colp[2][GJR_N], bufP[2][GJR_N], bufR[2][GJR_N];
   __shared__ int perm[GJR_N], dest[GJR_N];
-  __shared__ int piv_sh[2];
+  __shared__ double red_v[2][16];
+  __shared__ int red_i[2][16];
   __shared__ int bad;
   const int t = threadIdx.x, ti = t >> 6, tj = t & 63;
-  double a[8][2];
+  double a[16];  // element (ti + 16 r, tj + 64 c) at a[2 r + c]; p-dependent indices are wave-uniform
 #pragma unroll
   for (int r = 0; r < 8; r++)
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int i = ti + 16 * r, j = tj + 64 * c;
-      a[r][c] = (i < n && j < n) ? Ag[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
+      a[2 * r + c] = (i < n && j < n) ? Ag[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
     }
   if (t == 0) bad = 0;
   for (int p = 0; p < n; p++) {
     const int b = p & 1;
-    // S1: owners of column p publish it
+    const int pc = p >> 6, pr = p >> 4;  // register column / row slot of the pivot (uniform)
+    // S1: the 16 owners of column p (one per wavefront) publish it together with their own best
+    // pivot candidate among rows >= p; everybody then scans the 16 candidates -- no cross-lane
+    // reduction, one barrier
     if (tj == (p & 63)) {
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-          if (c == (p >> 6)) colp[b][ti + 16 * r] = a[r][c];
-    }
-    __syncthreads();
-    // S2: wave 0 finds the pivot row (first maximum of |column p| over rows >= p)
-    if (t < 64) {
       double bv = -1.0;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int i = t + 64 * q;
-        if (i >= p && i < GJR_N) {
-          const double v = fabs(colp[b][i]);
-          if (v > bv || (v == bv && i < bi)) {
-            bv = v;
-            bi = i;
-          }
+      for (int r = 0; r < 8; r++) {
+        const int i = ti + 16 * r;
+        const double x = a[2 * r + pc];
+        colp[b][i] = x;
+        const double v = fabs(x);
+        if (i >= p && v > bv) {  // ascending i: the first maximum is kept
+          bv = v;
+          bi = i;
         }
       }
+      red_v[b][ti] = bv;
+      red_i[b][ti] = bi;
+    }
+    __syncthreads();
+    int piv;
+    {
+      double bv = red_v[b][0];
+      piv = red_i[b][0];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(bv, o, 64);
-        const int i2 = __shfl_xor(bi, o, 64);
-        if (v2 > bv || (v2 == bv && i2 < bi)) {
+      for (int w = 1; w < 16; w++) {
+        const double v2 = red_v[b][w];
+        const int i2 = red_i[b][w];
+        if (v2 > bv || (v2 == bv && i2 < piv)) {
           bv = v2;
-          bi = i2;
+          piv = i2;
         }
       }
       if (t == 0) {
-        piv_sh[b] = bi;
-        perm[p] = bi;
+        perm[p] = piv;
         if (!(bv > 0.0) || isinf(bv)) bad = 1;
       }
     }
-    __syncthreads();
-    const int piv = piv_sh[b];
-    // S3: owners of rows p and piv publish them
+    const int vr = piv >> 4;
+    // S3: owners of rows p and piv publish them (ti is the wavefront index: uniform branches)
     if (ti == (p & 15)) {
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-        if (r == (p >> 4)) {
-#pragma unroll
-          for (int c = 0; c < 2; c++) bufP[b][tj + 64 * c] = a[r][c];
-        }
+      bufP[b][tj] = a[2 * pr];
+      bufP[b][tj + 64] = a[2 * pr + 1];
     }
     if (ti == (piv & 15)) {
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-        if (r == (piv >> 4)) {
-#pragma unroll
-          for (int c = 0; c < 2; c++) bufR[b][tj + 64 * c] = a[r][c];
-        }
+      bufR[b][tj] = a[2 * vr];
+      bufR[b][tj + 64] = a[2 * vr + 1];
     }
     __syncthreads();
-    // S4: rank-1 update of every register tile; the three special cases (row p, row piv, column p)
-    // are fix-ups, and the row cases are wave-uniform because ti is the wavefront index
+    // S4: rank-1 update of every register tile; row p, row piv and column p are fix-ups
     const double rinv = fast_rcp(bufR[b][p]);
     double rp[2], f[8];
 #pragma unroll
@@ -130,32 +123,21 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
 #pragma unroll
     for (int r = 0; r < 8; r++) f[r] = colp[b][ti + 16 * r];
     if (piv != p && ti == (piv & 15)) {  // row piv now holds the old row p
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-        if (r == (piv >> 4)) {
-          f[r] = colp[b][p];
-#pragma unroll
-          for (int c = 0; c < 2; c++) a[r][c] = bufP[b][tj + 64 * c];
-        }
+      f[vr] = colp[b][p];
+      a[2 * vr] = bufP[b][tj];
+      a[2 * vr + 1] = bufP[b][tj + 64];
     }
     if (tj == (p & 63)) {  // column p starts from zero
 #pragma unroll
-      for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-          if (c == (p >> 6)) a[r][c] = 0.0;
+      for (int r = 0; r < 8; r++) a[2 * r + pc] = 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 8; r++)
 #pragma unroll
-      for (int c = 0; c < 2; c++) a[r][c] = fma(-f[r], rp[c], a[r][c]);
+      for (int c = 0; c < 2; c++) a[2 * r + c] = fma(-f[r], rp[c], a[2 * r + c]);
     if (ti == (p & 15)) {  // row p is the scaled pivot row itself
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-        if (r == (p >> 4)) {
-#pragma unroll
-          for (int c = 0; c < 2; c++) a[r][c] = rp[c];
-        }
+      a[2 * pr] = rp[0];
+      a[2 * pr + 1] = rp[1];
     }
     // no barrier here: the next step writes the other half of the double buffers
   }
@@ -179,7 +161,7 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       const int i = ti + 16 * r, j = tj + 64 * c;
-      if (i < n && j < n) Ag[(size_t)i * n + perm[j]] = a[r][c];
+      if (i < n && j < n) Ag[(size_t)i * n + perm[j]] = a[2 * r + c];
     }
 }
 
