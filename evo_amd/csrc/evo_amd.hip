@@ -144,6 +144,7 @@ struct evoamd_ctx {
   double *pies = nullptr;            // SSSC (H)
   double *dpar = nullptr;            // device scalar block (DP_*), kernels read their scalars here
   double *h_dpar = nullptr;          // pinned mirror
+  double *gjwork = nullptr;  // colp | rowp | perm of the multi-launch Gauss-Jordan inverse
   double *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;  // (H,H) scratch of the device Theta update
   double ljc = 0;
   // statistics
@@ -295,7 +296,7 @@ static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
-                  c->pies,   c->dpar,   c->tmpA,    c->tmpB,    c->tmpC,
+                  c->pies,   c->dpar,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
   for (void *p : ptrs)
@@ -417,6 +418,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->tmpA, (size_t)H * H);
   ALLOC(c->tmpB, (size_t)H * H);
   ALLOC(c->tmpC, (size_t)H * H);
+  ALLOC(c->gjwork, (size_t)3 * H + 8);
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Es, (size_t)N * H);
   } else {
@@ -1178,14 +1180,22 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
 // ---------------------------------------------------------------------------------------
 // Inverts A (and B, if not null) in place; the two are independent.
 static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
-  const size_t aux = (size_t)2 * n * sizeof(double) + (size_t)n * sizeof(int);
   if (n <= GJR_N) {
     gj_inverse_reg_kernel<<<B ? 2 : 1, MS_T, 0, c->stream>>>(A, B, n, c->dpar + DP_STATUS);
-  } else {
-    gj_inverse_kernel<<<1, MS_T, aux, c->stream>>>(A, n, c->dpar + DP_STATUS);
-    if (B) gj_inverse_kernel<<<1, MS_T, aux, c->stream>>>(B, n, c->dpar + DP_STATUS);
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
-  HIP_TRY(hipGetLastError());
+  double *mats[2] = {A, B};
+  const dim3 ugrid(cdiv(n, 64), cdiv(n, 64));
+  for (int m = 0; m < 2; m++) {
+    if (!mats[m]) continue;
+    for (int p = 0; p < n; p++) {
+      gj_pivot_kernel<<<1, MS_T, 0, c->stream>>>(mats[m], n, p, c->gjwork, c->dpar + DP_STATUS);
+      gj_update_kernel<<<ugrid, 256, 0, c->stream>>>(mats[m], n, p, c->gjwork);
+    }
+    gj_unscramble_kernel<<<n, 256, (size_t)n * (sizeof(double) + sizeof(int)), c->stream>>>(mats[m], n, c->gjwork);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 

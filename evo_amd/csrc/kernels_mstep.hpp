@@ -165,96 +165,121 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
     }
 }
 
-// General n (> 128): same algorithm with the matrix in global memory (L2-resident up to n = 1024),
-// one workgroup, 16 x 64 thread tiling of the element loops.
-__global__ __launch_bounds__(MS_T) void gj_inverse_kernel(double *__restrict__ A, int n, double *__restrict__ status) {
-  extern __shared__ double lds[];
+// General n (> 128): the same Gauss-Jordan elimination with the matrix in global memory, spread
+// over the whole chip.  Every pivot step is two launches -- the stream order is the grid-wide
+// barrier -- so an inverse is 2 n + 1 launches (n = 512: ~5 ms; the earlier single-workgroup
+// version needed 32 ms, host LAPACK behind a pageable copy 50-300 ms):
+//   gj_pivot_kernel   one workgroup: first-maximum pivot in column p, row interchange, scaled
+//                     pivot row; leaves column p and the scaled row in `work`
+//   gj_update_kernel  all other rows: A[i][j] = (j == p ? 0 : A[i][j]) - colp[i] * rowp[j]
+//   gj_unscramble_kernel  the recorded row interchanges applied as one column permutation
+// work: colp (n) | rowp (n) | perm (n ints, stored as doubles' storage)
+__global__ __launch_bounds__(MS_T) void gj_pivot_kernel(double *__restrict__ A, int n, int p, double *__restrict__ work,
+                                                        double *__restrict__ status) {
   __shared__ double red_v[MS_T / 64];
   __shared__ int red_i[MS_T / 64];
   __shared__ int piv_row;
-  __shared__ int bad;
-  double *colp = lds;             // n
-  double *rowp = colp + n;        // n
-  int *perm = (int *)(rowp + n);  // n
-  const int t = threadIdx.x, ti = t >> 6, tj = t & 63;
-  if (t == 0) bad = 0;
-  __syncthreads();
-  for (int p = 0; p < n; p++) {
-    double bv = -1.0;
-    int bi = 0x7fffffff;
-    for (int i = p + t; i < n; i += MS_T) {
-      const double v = fabs(A[(size_t)i * n + p]);
-      if (v > bv || (v == bv && i < bi)) {
-        bv = v;
-        bi = i;
-      }
+  double *colp = work, *rowp = work + n;
+  int *perm = (int *)(work + 2 * (size_t)n);
+  const int t = threadIdx.x;
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = p + t; i < n; i += MS_T) {
+    const double v = fabs(A[(size_t)i * n + p]);
+    if (v > bv || (v == bv && i < bi)) {
+      bv = v;
+      bi = i;
     }
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double v2 = __shfl_xor(bv, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (v2 > bv || (v2 == bv && i2 < bi)) {
-        bv = v2;
-        bi = i2;
-      }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double v2 = __shfl_xor(bv, o, 64);
+    const int i2 = __shfl_xor(bi, o, 64);
+    if (v2 > bv || (v2 == bv && i2 < bi)) {
+      bv = v2;
+      bi = i2;
     }
-    if ((t & 63) == 0) {
-      red_v[t >> 6] = bv;
-      red_i[t >> 6] = bi;
-    }
-    __syncthreads();
-    if (t == 0) {
-      double v = red_v[0];
-      int r = red_i[0];
-      for (int w = 1; w < MS_T / 64; w++)
-        if (red_v[w] > v || (red_v[w] == v && red_i[w] < r)) {
-          v = red_v[w];
-          r = red_i[w];
-        }
-      piv_row = r;
-      perm[p] = r;
-      if (!(v > 0.0) || isinf(v)) bad = 1;
-    }
-    __syncthreads();
-    const int r = piv_row;
-    if (r != p && r < n)
-      for (int j = t; j < n; j += MS_T) {
-        const double x = A[(size_t)p * n + j];
-        A[(size_t)p * n + j] = A[(size_t)r * n + j];
-        A[(size_t)r * n + j] = x;
-      }
-    __syncthreads();
-    const double rinv = 1.0 / A[(size_t)p * n + p];
-    for (int i = t; i < n; i += MS_T) colp[i] = A[(size_t)i * n + p];
-    __syncthreads();
-    for (int j = t; j < n; j += MS_T) {
-      const double v = (j == p) ? rinv : A[(size_t)p * n + j] * rinv;
-      rowp[j] = v;
-      A[(size_t)p * n + j] = v;
-    }
-    __syncthreads();
-    for (int i = ti; i < n; i += MS_T / 64) {
-      if (i == p) continue;
-      const double f = colp[i];
-      for (int j = tj; j < n; j += 64) {
-        const size_t e = (size_t)i * n + j;
-        const double cur = (j == p) ? 0.0 : A[e];
-        A[e] = cur - f * rowp[j];
-      }
-    }
-    __syncthreads();
   }
-  for (int p = n - 1; p >= 0; p--) {
-    const int r = perm[p];
-    if (r != p)
-      for (int i = t; i < n; i += MS_T) {
-        const double x = A[(size_t)i * n + p];
-        A[(size_t)i * n + p] = A[(size_t)i * n + r];
-        A[(size_t)i * n + r] = x;
-      }
-    __syncthreads();
+  if ((t & 63) == 0) {
+    red_v[t >> 6] = bv;
+    red_i[t >> 6] = bi;
   }
-  if (t == 0 && bad) status[0] = 1.0;
+  __syncthreads();
+  if (t == 0) {
+    double v = red_v[0];
+    int r = red_i[0];
+    for (int w = 1; w < MS_T / 64; w++)
+      if (red_v[w] > v || (red_v[w] == v && red_i[w] < r)) {
+        v = red_v[w];
+        r = red_i[w];
+      }
+    piv_row = r;
+    perm[p] = r;
+    if (!(v > 0.0) || isinf(v)) status[0] = 1.0;
+  }
+  __syncthreads();
+  const int r = piv_row < n ? piv_row : p;
+  // interchange rows p and r while scaling the new row p; column p of the (interchanged) matrix
+  const double rinv = 1.0 / A[(size_t)r * n + p];
+  for (int j = t; j < n; j += MS_T) {
+    const double old_p = A[(size_t)p * n + j];
+    const double new_p = A[(size_t)r * n + j];
+    const double v = (j == p) ? rinv : new_p * rinv;
+    rowp[j] = v;
+    A[(size_t)p * n + j] = v;
+    if (r != p) A[(size_t)r * n + j] = old_p;
+  }
+  __syncthreads();  // the interchanged rows are in place: read column p
+  __threadfence_block();
+  for (int i = t; i < n; i += MS_T) {
+    double x;
+    if (i == p)
+      x = 0.0;  // row p is not updated
+    else
+      x = A[(size_t)i * n + p];
+    colp[i] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void gj_update_kernel(double *__restrict__ A, int n, int p,
+                                                        const double *__restrict__ work) {
+  const double *colp = work, *rowp = work + n;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+  if (j >= n) return;
+  const double rj = rowp[j];
+#pragma unroll 4
+  for (int ii = 0; ii < 16; ii++) {
+    const int i = i0 + ii;
+    if (i >= n || i == p) continue;
+    const size_t e = (size_t)i * n + j;
+    const double cur = (j == p) ? 0.0 : A[e];
+    A[e] = cur - colp[i] * rj;
+  }
+}
+
+// in place, one workgroup per row: row <- row[inverse column permutation]
+__global__ __launch_bounds__(256) void gj_unscramble_kernel(double *__restrict__ A, int n,
+                                                            const double *__restrict__ work) {
+  extern __shared__ double rowbuf[];  // n doubles + n ints
+  int *dest = (int *)(rowbuf + n);
+  const int *perm = (const int *)(work + 2 * (size_t)n);
+  const int t = threadIdx.x;
+  if (t == 0) {
+    // content tracker: start with the identity, apply the column swaps (p, perm[p]) last first
+    for (int k = 0; k < n; k++) dest[k] = k;
+    for (int p = n - 1; p >= 0; p--) {
+      const int r = perm[p];
+      const int tmp = dest[p];
+      dest[p] = dest[r];
+      dest[r] = tmp;
+    }
+  }
+  __syncthreads();
+  const size_t row = (size_t)blockIdx.x * n;
+  for (int k = t; k < n; k += 256) rowbuf[k] = A[row + dest[k]];  // output column k holds old column dest[k]
+  __syncthreads();
+  for (int k = t; k < n; k += 256) A[row + k] = rowbuf[k];
 }
 
 // out (rows x cols) = in^T (cols x rows)
