@@ -117,6 +117,12 @@ struct evoamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
+  // which ES3C overflow levels (K=4, K=8, LDS) the next pass over K^n needs; exact, from the
+  // counters of the last statistics pass (dpar[DP_NGT*]); unknown -> all
+  bool need_known = false;
+  bool res_need[3] = {true, true, true};
+  bool cand_from_device = false;  // resident candidate batch came from evolve_randflip (k <= k_parent + 1)
+  bool lists_clean = false;       // overflow counters are zero (a previous kernel cleared them)
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
   int model = 0;
@@ -144,6 +150,8 @@ struct evoamd_ctx {
   double *pies = nullptr;            // SSSC (H)
   double *dpar = nullptr;            // device scalar block (DP_*), kernels read their scalars here
   double *h_dpar = nullptr;          // pinned mirror
+  double *colpart = nullptr;  // per-workgroup partial column sums
+  size_t colpart_n = 0;
   double *gjwork = nullptr;  // colp | rowp | perm of the multi-launch Gauss-Jordan inverse
   double *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;  // (H,H) scratch of the device Theta update
   double ljc = 0;
@@ -239,6 +247,14 @@ static void launch_colsum(evoamd_ctx *c, const double *X, int ldx, i64 R, int Cn
 }
 
 
+static int ensure_colpart(evoamd_ctx *c, size_t n) {
+  if (n <= c->colpart_n) return 0;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  ALLOC(c->colpart, n);
+  c->colpart_n = n;
+  return 0;
+}
+
 // overflow lists big enough for a batch of `total` (datapoint, state) pairs
 static int ensure_lists(evoamd_ctx *c, i64 total) {
   const size_t need = list_cap(total) * LIST_SHARDS;
@@ -296,7 +312,7 @@ static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
-                  c->pies,   c->dpar,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,
+                  c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
   for (void *p : ptrs)
@@ -414,7 +430,6 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->stage_bytes = (size_t)N * SC * H;
   ALLOC(c->stage, c->stage_bytes);
   ALLOC(c->W, (size_t)D * H);
-  ALLOC(c->dpar, DP_COUNT);
   ALLOC(c->tmpA, (size_t)H * H);
   ALLOC(c->tmpB, (size_t)H * H);
   ALLOC(c->tmpC, (size_t)H * H);
@@ -426,7 +441,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     c->Es = nullptr;  // lives inside c->Y for SSSC
   }
   c->acc_n = acc_len(c);
-  ALLOC(c->acc, (size_t)c->acc_n);
+  ALLOC(c->acc, (size_t)c->acc_n + DP_COUNT);  // packed accumulator, then the scalar block (one D2H)
+  c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 4);
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Wt, (size_t)H * D);
@@ -449,18 +465,18 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (c->h_par) (void)hipHostFree(c->h_par);
   if (!c->h_err) HIP_TRY(hipHostMalloc((void **)&c->h_err, 4 * sizeof(int), hipHostMallocDefault));
   if (!c->h_dpar) HIP_TRY(hipHostMalloc((void **)&c->h_dpar, (DP_COUNT + 8) * sizeof(double), hipHostMallocDefault));
-  HIP_TRY(hipMemsetAsync(c->dpar, 0, DP_COUNT * sizeof(double), c->stream));
   c->h_par_n = (size_t)D * H + (size_t)H * H + 3 * (size_t)H;
-  HIP_TRY(hipHostMalloc((void **)&c->h_acc, (size_t)c->acc_n * sizeof(double), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c->h_acc, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&c->h_par, c->h_par_n * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipMemsetAsync(c->Y, 0, (size_t)N * c->ldY * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
-  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc, 0, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
   c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
+  c->lists_clean = c->need_known = c->cand_from_device = false;  // fresh (uninitialised) overflow counters
   return 0;
 }
 
@@ -498,6 +514,7 @@ extern "C" int evoamd_upload_states(evoamd_ctx *c, const uint8_t *ss_bool) {
   int r = pack_to_device(c, ss_bool, c->N * (i64)c->S, c->states);
   if (r) return r;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->need_known = false;
   return 0;
 }
 
@@ -698,7 +715,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     SpanGuard g(c, b.kid);
 #define GRAM_LAUNCH(TAG)                                                                                       \
   bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
-                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags)
+                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
     if (b.tag == 0)
       GRAM_LAUNCH(0);
     else
@@ -712,7 +729,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
   SpanGuard g(c, b.kid);
 #define BSC_LAUNCH(R)                                                                                     \
   bsc_lpj_kernel<R><<<grid, 256, 0, c->stream>>>(b.Y, c->Wt, b.states, b.counts, b.N, b.C, b.C, b.shared, \
-                                                  c->D, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags)
+                                                  c->D, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
   if (c->D <= 64)
     BSC_LAUNCH(1);
   else if (c->D <= 128)
@@ -761,11 +778,18 @@ static unsigned list_grid(i64 total, unsigned cap) {
   return g > cap ? cap : (g < 1 ? 1 : g);
 }
 
+static int zero_lists(evoamd_ctx *c) {
+  if (!c->lists_clean) HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+  c->lists_clean = false;  // the chain about to be launched appends to them
+  return 0;
+}
+
 template <int TAG>
-static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main) {
+static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const bool need[3]) {
   const i64 total = a.N * (i64)a.C;
   const int cap = (int)list_cap(total);
-  HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+  int r = zero_lists(c);
+  if (r) return r;
   const ListIn none = {nullptr, nullptr, 0};
   const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                 o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
@@ -775,23 +799,42 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main) {
     sssc_small_kernel<2, 0, TAG, 1024><<<cdiv(total, 1024), 1024, 0, c->stream>>>(a, none, o1);
     HIP_TRY(hipGetLastError());
   }
-  {
+  if (need[0] || need[1] || need[2]) {
     SpanGuard g(c, KID_LPJ_OVF);
-    sssc_small_kernel<4, 0, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(a, i1, o2);
-    sssc_small_kernel<8, 0, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(a, i2, o3);
+    if (need[0]) sssc_small_kernel<4, 0, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(a, i1, o2);
+    if (need[1]) sssc_small_kernel<8, 0, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(a, i2, o3);
     const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
-    sssc_big_kernel<0><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
+    if (need[2]) sssc_big_kernel<0><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
 
+// Overflow levels a batch needs.  tag 0 (K^n itself): exactly what the last statistics pass
+// counted.  tag 1 with device-generated candidates: a child differs from its parent in one bit, so
+// it can exceed a level only if some resident state exceeds the level below.  Anything else: all.
+static void levels_for(const evoamd_ctx *c, int tag, bool need[3]) {
+  need[0] = need[1] = need[2] = true;
+  if (!c->need_known) return;
+  if (tag == 0) {
+    need[0] = c->res_need[0];
+    need[1] = c->res_need[1];
+    need[2] = c->res_need[2];
+  } else if (tag == 1 && c->cand_from_device) {
+    need[0] = true;
+    need[1] = c->res_need[0];
+    need[2] = c->res_need[1];
+  }
+}
+
 static int launch_lpj(evoamd_ctx *c, const Batch &b) {
   if (c->model == EVOAMD_MODEL_BSC) return launch_bsc_lpj(c, b);
   SsscArgs a = sssc_args(c, b);
-  if (b.tag == 0) return launch_sssc_lpj<0>(c, a, b.kid);
-  if (b.tag == 1) return launch_sssc_lpj<1>(c, a, b.kid);
-  return launch_sssc_lpj<2>(c, a, b.kid);
+  bool need[3];
+  levels_for(c, b.tag, need);
+  if (b.tag == 0) return launch_sssc_lpj<0>(c, a, b.kid, need);
+  if (b.tag == 1) return launch_sssc_lpj<1>(c, a, b.kid, need);
+  return launch_sssc_lpj<2>(c, a, b.kid, need);
 }
 
 static int check_err(evoamd_ctx *c) {
@@ -799,7 +842,8 @@ static int check_err(evoamd_ctx *c) {
   HIP_TRY(hipMemcpyAsync(e, c->err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (e[0]) {
-    HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
+    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), c->stream));
+    if (e[0] & 4) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow level was skipped although its list was not empty");
     if (e[0] & 1) return fail(EVOAMD_E_KLIMIT, "ES3C: a state has more than %d active latents", SSSC_KCAP);
     return fail(EVOAMD_E_SINGULAR, "ES3C: exactly singular k x k system (the reference takes pinv here)");
   }
@@ -814,10 +858,9 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
     if (rb) return rb;
   }
   c->rows_fresh = false;
-  HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
   if (c->S_perm) {
     allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, c->dpar, c->model == EVOAMD_MODEL_SSSC,
-                                                               c->lpj, c->L, c->flags + 2 * c->N);
+                                                               c->lpj, c->L, c->flags + 2 * c->N, c->err);
     HIP_TRY(hipGetLastError());
   }
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
@@ -843,6 +886,7 @@ extern "C" int evoamd_lpj_candidates(evoamd_ctx *c, const uint8_t *cand_bool, co
   int r = pack_to_device(c, cand_bool, c->N * (i64)Cmax, c->cand);
   if (r) return r;
   HIP_TRY(hipMemcpyAsync(c->cand_counts, counts, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->cand_from_device = false;
   r = eval_candidates(c);
   if (r) return r;
   if (lpj_out)
@@ -865,6 +909,7 @@ extern "C" int evoamd_set_candidates(evoamd_ctx *c, const uint8_t *cand_bool, co
   HIP_TRY(hipMemcpyAsync(c->cand_counts, counts, (size_t)c->N * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->cand_lpj, lpj, (size_t)c->N * Cmax * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cand_from_device = false;
   c->have_cand = true;
   return 0;
 }
@@ -973,14 +1018,13 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
   REQUIRE(c && c->configured && c->have_cand, "no resident candidate batch (call lpj_candidates / evolve first)");
   REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
   HIP_TRY(hipSetDevice(c->device));
-  const AccLayout a = acc_layout(c);
   {
     SpanGuard g(c, KID_VARY_KN);
 #define VK_LAUNCH(SPL, CPL)                                                                                   \
   vary_kn_kernel<SPL, CPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->cand, c->cand_lpj,        \
                                                                  c->cand_counts, c->N, c->S, c->S_perm, c->HW,   \
                                                                  c->Cmax, Mprime, c->rowmax,                      \
-                                                                 c->rowsum, c->partial)
+                                                                 c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS)
     const bool c1 = c->Cmax <= 64;
     if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
     else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }
@@ -988,12 +1032,13 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
     else if (c->S <= 512) { if (c1) VK_LAUNCH(8, 1); else VK_LAUNCH(8, 4); }
     else { if (c1) VK_LAUNCH(16, 1); else VK_LAUNCH(16, 4); }
 #undef VK_LAUNCH
-    reduce3_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(c->N, 4), nullptr, c->acc + a.tail + 1);
+    reduce3_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(c->N, 4), c->dpar);
     HIP_TRY(hipGetLastError());
     c->rows_fresh = true;
+    c->lists_clean = c->model == EVOAMD_MODEL_SSSC;  // vary_kn zeroed the overflow counters
   }
   if (sums_out) {
-    HIP_TRY(hipMemcpyAsync(sums_out, c->acc + a.tail + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(sums_out, c->dpar + DP_ECNT0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   return 0;
@@ -1002,9 +1047,8 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
 extern "C" int evoamd_set_estep_counts(evoamd_ctx *c, double sum_nunique, double sum_sub) {
   REQUIRE(c && c->configured, "configure first");
   HIP_TRY(hipSetDevice(c->device));
-  const AccLayout a = acc_layout(c);
   double v[2] = {sum_nunique, sum_sub};
-  HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 1, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->dpar + DP_ECNT0, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1020,7 +1064,8 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
 #define EV_LAUNCH(SPL)                                                                                         \
   evolve_randflip_kernel<SPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H, \
                                                                     c->HW, n_parents, n_children, c->Cmax, seed,  \
-                                                                    fit_parents, c->cand, c->cand_counts)
+                                                                    fit_parents, c->cand, c->cand_counts, c->list_n,   \
+                                                                    c->model == EVOAMD_MODEL_SSSC ? 4 * LIST_SHARDS : 0)
     if (c->S <= 64) EV_LAUNCH(1);
     else if (c->S <= 128) EV_LAUNCH(2);
     else if (c->S <= 256) EV_LAUNCH(4);
@@ -1028,6 +1073,8 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
     else EV_LAUNCH(16);
 #undef EV_LAUNCH
     HIP_TRY(hipGetLastError());
+    c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
+    c->cand_from_device = true;
   }
   int r = eval_candidates(c);
   if (r) return r;
@@ -1063,20 +1110,16 @@ static int stats_compute(evoamd_ctx *c) {
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
   const int H = c->H, D = c->D;
-  // keep tail[1..2] (E-step counts written by vary_kn / set_estep_counts); zero everything else
-  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)(a.tail + 1) * sizeof(double), c->stream));
-  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 3, 0, 5 * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
   int r = ensure_B(c);
   if (r) return r;
-  if (c->rows_fresh) {
-    // vary_kn left rowmax / rowsum and the per-block free-energy partials behind
-    SpanGuard g(c, KID_ROW_LSE);
-    reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(N, 4), c->acc + a.tail + 0, 0);
-    HIP_TRY(hipGetLastError());
-  } else {
-    r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->acc + a.tail + 0);
+  if (!c->rows_fresh) {  // otherwise vary_kn left rowmax / rowsum / dpar[DP_FS] behind
+    r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->dpar + DP_FS);
     if (r) return r;
   }
+  const i64 rpb = 256;
+  const int nblk = (int)cdiv(N, rpb);
+  int skipped = 0;
   if (c->model == EVOAMD_MODEL_BSC) {
     {
       SpanGuard g(c, KID_STATS);
@@ -1087,9 +1130,11 @@ static int stats_compute(evoamd_ctx *c) {
     }
     {
       SpanGuard g(c, KID_MISC);
-      reduce_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial2, cdiv(N, 4), c->acc + a.sigma, 0);
-      launch_colsum<false>(c, c->Es, H, N, H, c->acc + a.pies);
-      finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, H);
+      r = ensure_colpart(c, (size_t)nblk * H);
+      if (r) return r;
+      colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk), 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->colpart);
+      bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
+                                                                       c->partial2, cdiv(N, 4), c->acc + a.sigma);
       HIP_TRY(hipGetLastError());
     }
     r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
@@ -1109,12 +1154,16 @@ static int stats_compute(evoamd_ctx *c) {
     sa.xszsz = c->acc + a.xszsz;
     const i64 total = N * (i64)c->S;
     const int cap = (int)list_cap(total);
-    HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+    // the final K^n is made of resident states and accepted candidates: same levels as the candidates
+    bool need[3];
+    levels_for(c, 1, need);
+    r = zero_lists(c);
+    if (r) return r;
     const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                   o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
     const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
     {
-      // workgroups own whole datapoints; rows of Es / Ez staged in LDS (<= 64 KiB)
+      // workgroups own whole datapoints; rows of Es / Ez / Ed staged in LDS (<= 64 KiB)
       int npb = 256 / c->S;
       if (npb < 1) npb = 1;
       const int lim = (int)(65536 / ((size_t)24 * H));
@@ -1124,54 +1173,67 @@ static int stats_compute(evoamd_ctx *c) {
       sssc_stats_kernel<2><<<cdiv(N, npb), 256, lds, c->stream>>>(sa, npb, o1);
       HIP_TRY(hipGetLastError());
     }
-    {
+    if (need[0] || need[1] || need[2]) {
       SpanGuard g(c, KID_STATS_OVF);
-      sssc_small_kernel<4, 1, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(sa, i1, o2);
-      sssc_small_kernel<8, 1, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(sa, i2, o3);
+      if (need[0]) sssc_small_kernel<4, 1, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(sa, i1, o2);
+      if (need[1]) sssc_small_kernel<8, 1, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(sa, i2, o3);
       const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
-      sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
+      if (need[2]) sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
       HIP_TRY(hipGetLastError());
     }
+    // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
+    // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
+    for (int j = 0; j < 3; j++)
+      if (!need[j]) {
+        skipped |= 1 << j;
+        break;
+      }
     {
       SpanGuard g(c, KID_MISC);
-      launch_colsum<false>(c, Es, c->ldY, N, H, c->acc + a.xs);
-      launch_colsum<false>(c, Ez, c->ldY, N, H, c->acc + a.xsz);
-      HIP_TRY(hipMemsetAsync(c->diag, 0, (size_t)H * sizeof(double), c->stream));
-      launch_colsum<false>(c, Ed, c->ldY, N, H, c->diag);
-      set_diag_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->acc + a.xszsz, c->diag, H);
-      finish_sym_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xs, H);
-      HIP_TRY(hipMemcpyAsync(c->acc + a.y2, c->y2sum, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      r = ensure_colpart(c, (size_t)nblk * 3 * H);
+      if (r) return r;
+      colsum_partial_kernel<<<dim3(cdiv(3 * H, 64), nblk), 256, 0, c->stream>>>(Es, c->ldY, N, 3 * H, rpb, c->colpart);
+      const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
+      sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
+                                                                 c->acc + a.xsz, c->colpart, nblk, H, c->y2sum,
+                                                                 c->acc + a.y2, D);
       HIP_TRY(hipGetLastError());
     }
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
     r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N);
     if (r) return r;
   }
-  // tail: N and the reset counters (per-call priority semantics)
   {
-    set_scalar_kernel<<<1, 1, 0, c->stream>>>(c->acc + a.tail + 3, (double)N);
-    for (int k = 0; k < 3; k++)
-      count_flags_kernel<<<64, 256, 0, c->stream>>>(c->flags + (size_t)k * N, N, c->acc + a.tail + 4);
+    SpanGuard g(c, KID_MISC);
+    tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
+                                          c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped);
     HIP_TRY(hipGetLastError());
+    c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
   }
   if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
-  // ljc is a property of Theta, not a sum over ranks: written after the all-reduce
-  HIP_TRY(hipMemcpyAsync(c->acc + a.tail + 7, c->dpar + DP_LJC, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return 0;
+}
+
+// After the accumulator + scalar block reached the host: remember which overflow levels K^n needs.
+static void note_levels(evoamd_ctx *c, const double *dpar_host) {
+  if (c->model != EVOAMD_MODEL_SSSC) return;
+  c->res_need[0] = dpar_host[DP_NGT2] > 0.0;
+  c->res_need[1] = dpar_host[DP_NGT4] > 0.0;
+  c->res_need[2] = dpar_host[DP_NGT8] > 0.0;
+  c->need_known = true;
 }
 
 extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   REQUIRE(acc_out, "acc_out is NULL");
   int r = stats_compute(c);
   if (r) return r;
-  const AccLayout a = acc_layout(c);
-  HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc, (size_t)c->acc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  // the E-step counts have been consumed
-  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost,
+                         c->stream));
   r = check_err(c);  // synchronises the stream
   memcpy(acc_out, c->h_acc, (size_t)c->acc_n * sizeof(double));
+  if (!r) note_levels(c, c->h_acc + c->acc_n);
   return r;
 }
 
@@ -1270,17 +1332,19 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   int r = stats_compute(c);
   if (r) return r;
   const AccLayout a = acc_layout(c);
-  HIP_TRY(hipMemcpyAsync(c->h_dpar + DP_COUNT, c->acc + a.tail, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (learn_mask) {
     r = update_params_device(c, learn_mask);
     if (r) return r;
   }
-  HIP_TRY(hipMemsetAsync(c->acc + a.tail + 1, 0, 2 * sizeof(double), c->stream));
-  HIP_TRY(hipMemcpyAsync(c->h_dpar, c->dpar, DP_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // accumulator tail (8) and the scalar block (16) are adjacent: one copy
+  double *h = c->h_acc + a.tail;
+  HIP_TRY(hipMemcpyAsync(h, c->acc + a.tail, (8 + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   r = check_err(c);  // synchronises
-  memcpy(tail_out, c->h_dpar + DP_COUNT, 8 * sizeof(double));
-  memcpy(dpar_out, c->h_dpar, DP_COUNT * sizeof(double));
+  memcpy(tail_out, h, 8 * sizeof(double));
+  memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
+  memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
   if (r) return r;
+  note_levels(c, c->h_dpar);
   if (c->h_dpar[DP_STATUS] != 0.0) {
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
     return fail(EVOAMD_E_SINGULAR, "device Theta update: %s",

@@ -21,7 +21,8 @@ template <int R>
 __global__ __launch_bounds__(256) void bsc_lpj_kernel(
     const double *__restrict__ Y, const double *__restrict__ Wt, const u64 *__restrict__ states,
     const int *__restrict__ counts, i64 N, int C, int Cstride, int shared, int D, int HW,
-    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
+    int *__restrict__ err) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const int lane = lane_id(), wave = wave_id_uniform();
   const int nchunk = (C + BSC_CHUNK - 1) / BSC_CHUNK;
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
       }
     }
   }
-  if (lane == 0 && fl) atomicOr(&flags[n], fl);
+  if (lane == 0 && fl) {
+    atomicOr(&flags[n], fl);
+    atomicOr(&err[1], 1);  // tells tail_kernel that there is something to count
+  }
 }
 
 // Gram-form lpj, one THREAD per (datapoint, state):
@@ -111,7 +115,8 @@ template <int TAG>
 __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int shared, int H, int HW,
-    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags) {
+    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
+    int *__restrict__ err) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
   for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
@@ -143,7 +148,10 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const double res = ((yy[n] - 2.0 * s1) + s3) + 2.0 * s2;
     unsigned fl = 0;
     lpj_out[n * ldo + col0 + c] = clamp_lpj(pre1 * res + pil_bar * (double)k, fl);
-    if (fl) atomicOr(&flags[n], fl);
+    if (fl) {
+      atomicOr(&flags[n], fl);
+      atomicOr(&err[1], 1);
+    }
   }
 }
 
@@ -152,13 +160,16 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
 __global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N,
                                                           const double *__restrict__ dpar, int sssc,
                                                           double *__restrict__ lpj_out, int ldo,
-                                                          unsigned *__restrict__ flags) {
+                                                          unsigned *__restrict__ flags, int *__restrict__ err) {
   i64 n = (i64)blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   const double pre = sssc ? -0.5 * dpar[DP_S2INV] : dpar[DP_PRE1];
   unsigned fl = 0;
   lpj_out[n * ldo] = clamp_lpj(pre * yy[n], fl);
-  if (fl) atomicOr(&flags[n], fl);
+  if (fl) {
+    atomicOr(&flags[n], fl);
+    atomicOr(&err[1], 1);
+  }
 }
 
 // yy_n = sum_d y_nd^2, one wavefront per n.
@@ -245,4 +256,35 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
   if (lane == 0) wsig[wave] = (n < N) ? sig : 0.0;
   __syncthreads();
   if (threadIdx.x == 0) sig_partial[blockIdx.x] = ((wsig[0] + wsig[1]) + wsig[2]) + wsig[3];
+}
+
+// Finishes the EBSC accumulator in one launch: mirror Wq, Wq[h][h] = pies[h] = column sum of Es
+// (nblk partials of H columns); thread 0 also adds the per-workgroup sigma partials in order.
+__global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq, double *__restrict__ pies,
+                                                         const double *__restrict__ part, int nblk, int H,
+                                                         const double *__restrict__ sig_part, i64 nsig,
+                                                         double *__restrict__ sigma) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {  // last workgroup: sigma (tree over 256 threads, fixed order)
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (i64 i = threadIdx.x; i < nsig; i += 256) s += sig_part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *sigma = sh[0];
+  }
+  if (t >= (i64)H * H) return;
+  const int i = (int)(t / H), j = (int)(t - (i64)i * H);
+  if (i == j) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += part[(i64)b * H + i];
+    pies[i] = s;
+    Wq[t] = s;
+  } else if (i > j) {
+    Wq[t] = Wq[(i64)j * H + i];
+  }
 }

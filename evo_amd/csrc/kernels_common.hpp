@@ -2,6 +2,7 @@
 // normalisers), K^n selection (vary_Kn) and small reductions.
 #pragma once
 #include "common.hpp"
+#include "kernels_mstep.hpp"
 
 // bool (nstates, H) -> packed (nstates, HW); one thread per output word.
 __global__ __launch_bounds__(256) void pack_states_kernel(const uint8_t *__restrict__ in,
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
   }
 }
 
-// Three partial arrays of length n laid out back to back -> out[0], out[1] (+=), out[2] (+=):
-// free-energy sum (assigned) and the two E-step counters (accumulated), one launch.
+// Three partial arrays of length n laid out back to back (free-energy terms, #new-unique, #swapped
+// per workgroup of vary_kn) -> dpar[DP_FS] (assigned), dpar[DP_ECNT0/1] (accumulated).  Fixed
+// summation order: reproducible run to run.
 __global__ __launch_bounds__(256) void reduce3_partials_kernel(const double *__restrict__ partial, i64 n,
-                                                               double *__restrict__ out_f,
-                                                               double *__restrict__ out_counts) {
+                                                               double *__restrict__ dpar) {
   __shared__ double sh[3][256];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (i64 i = threadIdx.x; i < n; i += 256) {
@@ -107,9 +108,96 @@ __global__ __launch_bounds__(256) void reduce3_partials_kernel(const double *__r
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (out_f) *out_f = sh[0][0];
-    out_counts[0] += sh[1][0];
-    out_counts[1] += sh[2][0];
+    dpar[DP_FS] = sh[0][0];
+    dpar[DP_ECNT0] += sh[1][0];
+    dpar[DP_ECNT1] += sh[2][0];
+  }
+}
+
+// Per-workgroup partial column sums of an (R x Cn) slab: part[blockIdx.y][c] = sum over the block's
+// rows.  No atomics and no zeroing; the consumer adds the gridDim.y partials in order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const double *__restrict__ X, int ldx, i64 R, int Cn,
+                                                             i64 rows_per_block, double *__restrict__ part) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const i64 r0 = (i64)blockIdx.y * rows_per_block;
+  const i64 r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  double s = 0.0;
+  if (c < Cn)
+    for (i64 r = r0 + rl; r < r1; r += 4) s += X[r * ldx + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < Cn) part[(i64)blockIdx.y * Cn + c] = ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
+}
+
+// Accumulator tail + bookkeeping in one single-workgroup launch (was 6 launches):
+//   tail = { Fs, sum_nunique, sum_sub, N, reset counters[3], 0 } from the device scalar block;
+//   the E-step counters are consumed (zeroed); clamp flags are counted with the reference's
+//   per-call if/elif priority (_models.py:585-590) and cleared, but only if some kernel raised
+//   any (word err[1]); the overflow-list counters of the statistics pass become dpar[DP_NGT*]
+//   and are zeroed for the next chain; a non-empty list behind a skipped level sets err[0] |= 4.
+__global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, double N, double *__restrict__ dpar,
+                                                   unsigned *__restrict__ flags, i64 nflags3, i64 nper,
+                                                   int *__restrict__ err, int *__restrict__ list_n, int nshards,
+                                                   int skipped_mask) {
+  __shared__ int cnt[3];
+  __shared__ int lvl[3];
+  const int t = threadIdx.x;
+  if (t < 3) {
+    cnt[t] = 0;
+    lvl[t] = 0;
+  }
+  __syncthreads();
+  if (err[1] != 0) {  // rare: some lpj was NaN / inf
+    for (int k = 0; k < 3; k++) {
+      int c0 = 0, c1 = 0, c2 = 0;
+      for (i64 i = t; i < nper; i += 256) {
+        const unsigned f = flags[k * nper + i];
+        if (f & EVO_FLAG_NAN)
+          c0++;
+        else if (f & EVO_FLAG_NEGINF)
+          c1++;
+        else if (f & EVO_FLAG_POSINF)
+          c2++;
+        if (f) flags[k * nper + i] = 0;
+      }
+      if (c0) atomicAdd(&cnt[0], c0);
+      if (c1) atomicAdd(&cnt[1], c1);
+      if (c2) atomicAdd(&cnt[2], c2);
+    }
+  }
+  if (list_n) {
+    for (int i = t; i < 3 * nshards; i += 256) {
+      const int v = list_n[i];
+      if (v) atomicAdd(&lvl[i / nshards], v);
+    }
+  }
+  __syncthreads();
+  if (list_n)
+    for (int i = t; i < 4 * nshards; i += 256) list_n[i] = 0;
+  if (t == 0) {
+    tail[0] = dpar[DP_FS];
+    tail[1] = dpar[DP_ECNT0];
+    tail[2] = dpar[DP_ECNT1];
+    tail[3] = N;
+    tail[4] = (double)cnt[0];
+    tail[5] = (double)cnt[1];
+    tail[6] = (double)cnt[2];
+    tail[7] = 0.0;
+    dpar[DP_ECNT0] = 0.0;
+    dpar[DP_ECNT1] = 0.0;
+    if (list_n) {
+      dpar[DP_NGT2] = (double)lvl[0];
+      dpar[DP_NGT4] = (double)lvl[1];
+      dpar[DP_NGT8] = (double)lvl[2];
+      // level j+1 consumes list j; if it was skipped its list must be empty
+      int lost = 0;
+      for (int j = 0; j < 3; j++)
+        if ((skipped_mask >> j) & 1) lost |= (lvl[j] != 0);
+      if (lost) atomicOr(&err[0], 4);
+    }
+    err[1] = 0;
   }
 }
 
@@ -173,8 +261,11 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
                                                       const int *__restrict__ counts, i64 N, int S,
                                                       int S_perm, int HW, int Cmax, int Mprime,
                                                       double *__restrict__ rowmax,
-                                                      double *__restrict__ rowsum, double *__restrict__ fpartial) {
+                                                      double *__restrict__ rowsum, double *__restrict__ fpartial,
+                                                      int *__restrict__ list_n, int n_list) {
   __shared__ int blk_uniq[4], blk_sub[4];
+  if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
+    for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
   __shared__ double wsum[4];
   __shared__ double new_v[4][64 * CPL], old_v[4][64 * CPL];
   __shared__ int new_i[4][64 * CPL], old_i[4][64 * CPL];

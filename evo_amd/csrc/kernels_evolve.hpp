@@ -38,8 +38,10 @@ template <int SPL>
 __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, i64 N, int S, int S_perm, int H, int HW,
     int n_parents, int n_children, int Cmax, u64 seed, int fit_parents, u64 *__restrict__ cand,
-    int *__restrict__ counts) {
+    int *__restrict__ counts, int *__restrict__ list_n, int n_list) {
   __shared__ int sel_sh[4][64];
+  if (blockIdx.x == 0 && list_n)  // the candidate lpj chain that follows appends to fresh overflow lists
+    for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;
   if (n >= N) return;

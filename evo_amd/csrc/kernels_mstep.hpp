@@ -26,6 +26,12 @@ enum {
   DP_SIGMA2 = 6,   // SSSC sigma2
   DP_STATUS = 7,   // != 0: a solve hit a zero / non-finite pivot
   DP_LJC_PREV = 8, // ljc of the Theta the last E-step ran with (F = ljc_prev + Fs/N)
+  DP_ECNT0 = 9,    // E-step counters accumulated by vary_kn: sum of #new-unique ...
+  DP_ECNT1 = 10,   // ... and of #swapped (this rank)
+  DP_FS = 11,      // sum_n logsumexp of the current lpj (this rank)
+  DP_NGT2 = 12,    // resident states with more than 2 / 4 / 8 active latents (this rank), counted by
+  DP_NGT4 = 13,    // the last statistics pass: tells the host which overflow levels the next
+  DP_NGT8 = 14,    // E-step can skip
   DP_COUNT = 16
 };
 
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     if (s2 < 1e-5) s2 = 1e-5;  // check_params
     dpar[DP_SIGMA2] = s2;
     dpar[DP_S2INV] = 1.0 / s2;
+    dpar[DP_LJC_PREV] = dpar[DP_LJC];
     dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - 0.5 * (D * log(s2));
     if (!(s2 == s2) || isinf(s2)) dpar[DP_STATUS] = 2.0;
   }
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restr
     dpar[DP_SIGMA] = sigma;
     dpar[DP_PRE1] = -1.0 / 2.0 / sigma / sigma;
     dpar[DP_PILBAR] = log(pi / (1.0 - pi));
+    dpar[DP_LJC_PREV] = dpar[DP_LJC];
     dpar[DP_LJC] = H * log(1.0 - pi) - D / 2.0 * log(2 * M_PI * sigma * sigma);
     if (!(sigma == sigma) || !(pi == pi)) dpar[DP_STATUS] = 2.0;
   }

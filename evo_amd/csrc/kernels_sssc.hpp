@@ -177,7 +177,9 @@ __device__ __forceinline__ void block_append(const ListOut &lo, int shard, int v
   if (n == 0) return;  // uniform
   if (threadIdx.x == 0) ctl[1] = atomicAdd(&lo.counts[shard], n);
   __syncthreads();
-  const i64 dst = (i64)shard * lo.cap + ctl[1];
+  const int start = ctl[1];
+  if (start < 0 || start + n > lo.cap) return;  // cannot happen with list_cap(); never write past the shard
+  const i64 dst = (i64)shard * lo.cap + start;
   for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
 }
 
@@ -186,6 +188,7 @@ __device__ __forceinline__ int list_prefix(const ListIn &li, int *prefix /* LDS,
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     int v = li.counts[lane];
+    v = v < 0 ? 0 : (v > li.cap ? li.cap : v);  // never index past a shard, whatever the counter holds
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -361,7 +364,10 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
     if (MODE == 0) {
       unsigned fl = 0;
       a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
-      if (fl) atomicOr(&a.flags[n], fl);
+      if (fl) {
+        atomicOr(&a.flags[n], fl);
+        atomicOr(&a.err[1], 1);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < K; i++) {
@@ -611,7 +617,10 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
         const double val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
         unsigned fl = 0;
         a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
-        if (fl) atomicOr(&a.flags[n], fl);
+        if (fl) {
+          atomicOr(&a.flags[n], fl);
+          atomicOr(&a.err[1], 1);
+        }
       }
     } else {
       if (lane < k) {
@@ -629,6 +638,36 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
         if (j != i) unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
       }
     }
+  }
+}
+
+// Finishes the ES3C accumulator after the scatter kernels, one launch (was 7): thread (i,j) of the
+// H x H grid mirrors xpt_ss; the diagonal threads add the per-workgroup partial column sums of
+// [Es | Ez | Ed] (colsum_partial_kernel, nblk partials of 3H columns, fixed order) and write
+// xpt_s[i], xpt_sz[i], xpt_ss[i][i] = xpt_s[i], xpt_szsz[i][i]; the first D threads copy y_outer_diag.
+__global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ xss, double *__restrict__ xszsz,
+                                                          double *__restrict__ xs, double *__restrict__ xsz,
+                                                          const double *__restrict__ part, int nblk, int H,
+                                                          const double *__restrict__ y2sum, double *__restrict__ y2out,
+                                                          int D) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t < D) y2out[t] = y2sum[t];
+  if (t >= (i64)H * H) return;
+  const int i = (int)(t / H), j = (int)(t - (i64)i * H);
+  if (i == j) {
+    double s = 0.0, z = 0.0, d = 0.0;
+    for (int b = 0; b < nblk; b++) {
+      const double *p = part + (i64)b * 3 * H;
+      s += p[i];
+      z += p[H + i];
+      d += p[2 * H + i];
+    }
+    xs[i] = s;
+    xsz[i] = z;
+    xss[t] = s;
+    xszsz[t] = d;
+  } else if (i > j) {
+    xss[t] = xss[(i64)j * H + i];
   }
 }
 

@@ -171,7 +171,8 @@ class Engine:
         return acc
 
     LEARN_BITS = {"W": 1, "pies": 2, "pi": 2, "mus": 4, "sigma2": 8, "sigma": 8, "Psi": 16}
-    DPAR = {"pre1": 0, "pil_bar": 1, "sigma2_inv": 2, "ljc": 3, "pi": 4, "sigma": 5, "sigma2": 6, "status": 7}
+    DPAR = {"pre1": 0, "pil_bar": 1, "sigma2_inv": 2, "ljc": 3, "pi": 4, "sigma": 5, "sigma2": 6, "status": 7,
+            "ljc_prev": 8, "n_gt2": 12, "n_gt4": 13, "n_gt8": 14}
 
     def mstep_device(self, to_learn):
         """Statistics + Theta update on the device.  Returns (tail dict, scalar-parameter dict)."""
@@ -181,9 +182,10 @@ class Engine:
         tail = np.zeros(8)
         dpar = np.zeros(16)
         check(self.lib.evoamd_mstep_device(self._h, mask, dptr(tail), dptr(dpar)))
-        t = dict(zip(TAIL, tail))
-        t["ljc"] = tail[7]
-        return t, {k: dpar[i] for k, i in self.DPAR.items()}
+        d = {k: dpar[i] for k, i in self.DPAR.items()}
+        # ljc of the Theta the E-step ran with: the update kernels move it to ljc_prev
+        d["ljc_estep"] = d["ljc_prev"] if mask else d["ljc"]
+        return dict(zip(TAIL, tail)), d
 
     def get_params_bsc(self):
         W = np.empty((self.D, self.H))
@@ -244,7 +246,7 @@ class Engine:
         return avg.value, n.value
 
 
-TAIL = ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf", "ljc_local")
+TAIL = ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf", "pad")
 
 
 def acc_layout(model, D, H):

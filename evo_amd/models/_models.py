@@ -233,7 +233,7 @@ class Model:
         model_params.update(self._pull_params(dpar))
         self._dev_theta = model_params
         N = tail["N"]
-        return tail["ljc_local"] + tail["Fs"] / N, tail["sum_nunique"] / N, tail["sum_sub"] / N, model_params
+        return dpar["ljc_estep"] + tail["Fs"] / N, tail["sum_nunique"] / N, tail["sum_sub"] / N, model_params
 
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """One EM iteration (_models.py:161-203): check_params -> E_step -> M_step."""

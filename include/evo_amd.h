@@ -145,8 +145,7 @@ int evoamd_evolve_randflip(evoamd_ctx *ctx, int n_parents, int n_children, uint6
  *   BSC : Wp (H,D) | Wq (H,H) | pies (H) | sigma | tail[8]
  *   SSSC: xpt_s (H) | xpt_ss (H,H) | xpt_sz (H) | xpt_szsz (H,H) | Wp (D,H) | s_sz_outer (H,H) |
  *         sz_sz_outer (H,H) | y_outer_diag (D) | tail[8]
- *   tail = { Fs, sum_nunique, sum_sub, N, reset_isnan, reset_smaller_eps, reset_isinf, ljc }
- *   (ljc = log-joint constant of the Theta used by the E-step; NOT summed over ranks) */
+ *   tail = { Fs, sum_nunique, sum_sub, N, reset_isnan, reset_smaller_eps, reset_isinf, 0 } */
 int64_t evoamd_acc_size(evoamd_ctx *ctx);
 /* Computes the per-rank sums from the resident K^n / lpj (bsc.py:176-223;
  * sssc.py:553-646,761; free energy _models.py:544-546), all-reduces them over the RCCL
@@ -158,8 +157,8 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * sssc.py:687-770), the clamps of check_params (_models.py:101-159) and E_step_precompute on the
  * GPU and installs the result as the context's current parameters.  learn_mask bits: 1 W, 2 pies
  * (BSC: pi), 4 mus, 8 sigma2 (BSC: sigma), 16 Psi; 0 = statistics only.  tail_out[8] = accumulator
- * tail (tail[7] = ljc of the Theta the E-step used), dpar_out[16] = scalar block of the NEW Theta
- * (see kernels_mstep.hpp: DP_*).  The H x H systems are solved by Gauss-Jordan with partial
+ * tail, dpar_out[16] = scalar block of the NEW Theta (kernels_mstep.hpp: DP_*; [8] = ljc of the Theta
+ * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
  * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
 /* Current parameters of the context back to the host (after evoamd_mstep_device). */
