@@ -121,8 +121,11 @@ struct evoamd_ctx {
   // counters of the last statistics pass (dpar[DP_NGT*]); unknown -> all
   bool need_known = false;
   bool res_need[3] = {true, true, true};
+  double res_cnt[3] = {0, 0, 0};  // how many resident states exceeded 2 / 4 / 8 active latents
   bool cand_from_device = false;  // resident candidate batch came from evolve_randflip (k <= k_parent + 1)
   bool lists_clean = false;       // overflow counters are zero (a previous kernel cleared them)
+  int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
+                     // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
   int model = 0;
@@ -340,6 +343,10 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
 
 extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   REQUIRE(c && name, "bad arguments");
+  if (strcmp(name, "sssc_k8") == 0) {
+    c->k8_mode = value < 0 ? -1 : (value != 0);
+    return 0;
+  }
   if (strcmp(name, "bsc_direct") == 0) {
     c->bsc_direct = value != 0;
     c->have_params = false;  // G / B are (not) needed: set_params again
@@ -778,6 +785,32 @@ static unsigned list_grid(i64 total, unsigned cap) {
   return g > cap ? cap : (g < 1 ? 1 : g);
 }
 
+// Grid of a list-driven level.  The kernels grid-stride over whatever the list holds, so the grid
+// only has to be big enough to be fast: when the last statistics pass counted the resident states
+// above each level, launch about twice that many threads instead of the worst case (the K = 8
+// kernel needs 256 VGPRs + scratch per wave; an oversized, mostly idle grid cost 20-70 us).
+static unsigned level_grid(const evoamd_ctx *c, int level, int tag, i64 total, unsigned cap, unsigned per_block) {
+  unsigned g = list_grid(total, cap);
+  if (!c->need_known || tag == 2) return g;
+  // candidates / final K^n can exceed a level if a resident state exceeds the level below
+  const int src = (tag == 0) ? level : (level > 0 ? level - 1 : 0);
+  double expect = c->res_cnt[src] * ((tag == 0) ? 1.0 : 1.0 + (double)c->Cmax / (double)c->S);
+  if (tag != 0 && level == 0) expect = (double)total;  // unknown: children of k = 2 parents
+  unsigned want = (unsigned)(2.0 * expect / per_block) + 4;
+  return want < g ? want : g;
+}
+
+// A few thousand states above 4 active latents are served fastest by the wavefront-per-state
+// kernel (64 lanes share one k x k system: short latency, 53 vs 100 us at 2.5k states), a large
+// population by the K=8 register kernel (one state per thread: 244 us vs 15 ms at 640k states).
+static bool use_k8_kernel(const evoamd_ctx *c, int tag) {
+  if (c->k8_mode >= 0) return c->k8_mode != 0;
+  if (!c->need_known || tag == 2) return true;
+  const double expect = c->res_cnt[tag == 0 ? 1 : 0] * (tag == 0 ? 1.0 : (double)c->Cmax / (double)c->S) +
+                        (tag == 0 ? 0.0 : c->res_cnt[1]);
+  return expect > 8192.0;
+}
+
 static int zero_lists(evoamd_ctx *c) {
   if (!c->lists_clean) HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
   c->lists_clean = false;  // the chain about to be launched appends to them
@@ -801,10 +834,18 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
   }
   if (need[0] || need[1] || need[2]) {
     SpanGuard g(c, KID_LPJ_OVF);
-    if (need[0]) sssc_small_kernel<4, 0, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(a, i1, o2);
-    if (need[1]) sssc_small_kernel<8, 0, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(a, i2, o3);
-    const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
-    if (need[2]) sssc_big_kernel<0><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
+    if (need[0])
+      sssc_small_kernel<4, 0, 2, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
+    if (use_k8_kernel(c, TAG)) {
+      if (need[1])
+        sssc_small_kernel<8, 0, 2, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
+      if (need[2])
+        sssc_big_kernel<0><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
+    } else if (need[1]) {
+      // everything above 4 active latents goes to the wavefront-per-state kernel: one state's k x k
+      // system and its k^2 scatter are spread over 64 lanes instead of one long thread program
+      sssc_big_kernel<0><<<level_grid(c, 1, TAG, total * 256, 2048, 1), 64, SSSC_BIG_LDS, c->stream>>>(a, i2);
+    }
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -1175,10 +1216,17 @@ static int stats_compute(evoamd_ctx *c) {
     }
     if (need[0] || need[1] || need[2]) {
       SpanGuard g(c, KID_STATS_OVF);
-      if (need[0]) sssc_small_kernel<4, 1, 2, 256><<<list_grid(total, 1024), 256, 0, c->stream>>>(sa, i1, o2);
-      if (need[1]) sssc_small_kernel<8, 1, 2, 256><<<list_grid(total, 256), 256, 0, c->stream>>>(sa, i2, o3);
-      const unsigned gridb = (unsigned)(total < 1024 ? total : 1024);
-      if (need[2]) sssc_big_kernel<1><<<gridb, 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
+      const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
+      if (need[0])
+        sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sa, i1, o2);
+      if (use_k8_kernel(c, tg)) {
+        if (need[1])
+          sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sa, i2, o3);
+        if (need[2])
+          sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
+      } else if (need[1]) {
+        sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 2048, 1), 64, SSSC_BIG_LDS, c->stream>>>(sa, i2);
+      }
       HIP_TRY(hipGetLastError());
     }
     // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
@@ -1219,9 +1267,10 @@ static int stats_compute(evoamd_ctx *c) {
 // After the accumulator + scalar block reached the host: remember which overflow levels K^n needs.
 static void note_levels(evoamd_ctx *c, const double *dpar_host) {
   if (c->model != EVOAMD_MODEL_SSSC) return;
-  c->res_need[0] = dpar_host[DP_NGT2] > 0.0;
-  c->res_need[1] = dpar_host[DP_NGT4] > 0.0;
-  c->res_need[2] = dpar_host[DP_NGT8] > 0.0;
+  for (int j = 0; j < 3; j++) {
+    c->res_cnt[j] = dpar_host[DP_NGT2 + j];
+    c->res_need[j] = c->res_cnt[j] > 0.0;
+  }
   c->need_known = true;
 }
 

@@ -64,7 +64,9 @@ void evoamd_ctx_destroy(evoamd_ctx *ctx);
 int evoamd_synchronize(evoamd_ctx *ctx);
 /* Options: "bsc_direct" (0/1, default 0): evaluate EBSC batches with the direct residual kernel
  * (the reference's arithmetic, bsc.py:91-93) instead of the Gram-form kernel.  Takes effect at the
- * next evoamd_set_params_bsc. */
+ * next evoamd_set_params_bsc.  "sssc_k8" (1 / 0 / -1, default -1): serve ES3C states with 5..8 active
+ * latents with the K=8 register kernel / the LDS wavefront kernel / whichever the counts of the last
+ * statistics pass favour. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */
