@@ -20,15 +20,44 @@ __device__ __forceinline__ int wave_id_uniform() {
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Wave-wide reductions of a double with DPP row operations (VALU crossbar, no LDS round trips):
+// quad swaps, half-row and row mirrors, then row_bcast15 / row_bcast31; the result is valid in lane
+// 63 and handed to every lane through v_readlane.  ALL 64 lanes must be active at the call.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_move<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+  {                              // row_bcast15 into rows 1 and 3 (old value kept elsewhere)
+    const double t = dpp_move<0x142, 0xA>(v);
+    if ((lane_id() >> 4) & 1) v += t;
+  }
+  {                              // row_bcast31 into rows 2 and 3
+    const double t = dpp_move<0x143, 0xC>(v);
+    if (lane_id() >= 32) v += t;
+  }
+  return lane63_f64(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_move<0xB1, 0xF>(v));
+  v = fmax(v, dpp_move<0x4E, 0xF>(v));
+  v = fmax(v, dpp_move<0x141, 0xF>(v));
+  v = fmax(v, dpp_move<0x140, 0xF>(v));
+  v = fmax(v, dpp_move<0x142, 0xA>(v));  // lanes outside the row mask read their own value: max is idempotent
+  v = fmax(v, dpp_move<0x143, 0xC>(v));
+  return lane63_f64(v);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -84,3 +113,5 @@ struct LogDetAcc {
   }
   __device__ __forceinline__ double value() const { return log(m) + (double)e * 0.6931471805599453094; }
 };
+
+__device__ __forceinline__ double wave_max_dpp(double v) { return wave_max(v); }

@@ -40,8 +40,8 @@ enum {
 // Inverse of an n x n matrix, n <= 128, by Gauss-Jordan with partial (row) pivoting, ONE workgroup,
 // the whole matrix in REGISTERS: thread (ti = t>>6, tj = t&63) owns elements (ti + 16 r, tj + 64 c),
 // r < 8, c < 2 (16 doubles).  Per pivot step the threads exchange only column p, the two
-// interchanged rows and 16 pivot candidates through (double-buffered) LDS: 2 barriers per step, no
-// cross-lane reduction and no matrix traffic.
+// interchanged rows and the pivot index through (double-buffered) LDS: 3 barriers per step, one DPP
+// max-reduce in wavefront 0, no matrix traffic.
 // Rows/columns beyond n are padded with the identity.  Row interchanges are undone as one column
 // permutation when the result is written.  status[0] = 1 on a zero / non-finite pivot.
 #define GJR_N 128
@@ -52,8 +52,7 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
   double *__restrict__ Ag = blockIdx.x == 0 ? A0 : A1;
   __shared__ double colp[2][GJR_N], bufP[2][GJR_N], bufR[2][GJR_N];
   __shared__ int perm[GJR_N], dest[GJR_N];
-  __shared__ double red_v[2][16];
-  __shared__ int red_i[2][16];
+  __shared__ int piv_sh[2];
   __shared__ int bad;
   const int t = threadIdx.x, ti = t >> 6, tj = t & 63;
   double a[16];  // element (ti + 16 r, tj + 64 c) at a[2 r + c]; p-dependent indices are wave-uniform
@@ -68,45 +67,38 @@ __global__ __launch_bounds__(MS_T) void gj_inverse_reg_kernel(double *__restrict
   for (int p = 0; p < n; p++) {
     const int b = p & 1;
     const int pc = p >> 6, pr = p >> 4;  // register column / row slot of the pivot (uniform)
-    // S1: the 16 owners of column p (one per wavefront) publish it together with their own best
-    // pivot candidate among rows >= p; everybody then scans the 16 candidates -- no cross-lane
-    // reduction, one barrier
+    // S1: the 16 owners of column p (one per wavefront) publish it
     if (tj == (p & 63)) {
-      double bv = -1.0;
-      int bi = 0x7fffffff;
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const int i = ti + 16 * r;
-        const double x = a[2 * r + pc];
-        colp[b][i] = x;
-        const double v = fabs(x);
-        if (i >= p && v > bv) {  // ascending i: the first maximum is kept
-          bv = v;
-          bi = i;
-        }
-      }
-      red_v[b][ti] = bv;
-      red_i[b][ti] = bi;
+      for (int r = 0; r < 8; r++) colp[b][ti + 16 * r] = a[2 * r + pc];
     }
     __syncthreads();
-    int piv;
-    {
-      double bv = red_v[b][0];
-      piv = red_i[b][0];
+    // S2: wavefront 0 picks the pivot: each candidate becomes one double whose low 7 mantissa bits
+    // hold 127 - row (so equal magnitudes resolve to the lowest row, like LAPACK's idamax, up to
+    // a 2^-45 relative quantisation of |x| that is irrelevant for stability), one DPP max-reduce
+    if (t < 64) {
+      double key = -1.0;
 #pragma unroll
-      for (int w = 1; w < 16; w++) {
-        const double v2 = red_v[b][w];
-        const int i2 = red_i[b][w];
-        if (v2 > bv || (v2 == bv && i2 < piv)) {
-          bv = v2;
-          piv = i2;
+      for (int q = 0; q < 2; q++) {
+        const int i = t + 64 * q;
+        if (i >= p) {
+          const unsigned long long bits =
+              ((unsigned long long)__double_as_longlong(fabs(colp[b][i])) & ~0x7FULL) | (unsigned long long)(127 - i);
+          key = fmax(key, __longlong_as_double((long long)bits));
         }
       }
+      key = wave_max_dpp(key);
       if (t == 0) {
-        perm[p] = piv;
-        if (!(bv > 0.0) || isinf(bv)) bad = 1;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(key);
+        const int row = 127 - (int)(bits & 0x7FULL);
+        piv_sh[b] = row;
+        perm[p] = row;
+        const double mag = __longlong_as_double((long long)(bits & ~0x7FULL));
+        if (!(mag > 0.0) || isinf(mag)) bad = 1;
       }
     }
+    __syncthreads();
+    const int piv = piv_sh[b];
     const int vr = piv >> 4;
     // S3: owners of rows p and piv publish them (ti is the wavefront index: uniform branches)
     if (ti == (p & 15)) {
