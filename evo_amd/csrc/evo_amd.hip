@@ -304,9 +304,9 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              96 * 1024));
+                              112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              96 * 1024));
+                              112 * 1024));
   *out = c;
   return 0;
 }
@@ -772,8 +772,7 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   return a;
 }
 
-static const size_t SSSC_BIG_LDS = (size_t)(2 * SSSC_KCAP * SSSC_KCAP + 5 * SSSC_KCAP) * sizeof(double) +
-                                   SSSC_KCAP * sizeof(int);
+static size_t big_lds(int kc) { return (size_t)(3 * kc * kc + 5 * kc) * sizeof(double) + (size_t)kc * sizeof(int); }
 
 // ES3C lpj of a batch: states are binned by their number of active latents on the fly.  The main
 // launch walks the pairs in natural (coalesced) order, evaluates every state with k <= 2 in
@@ -836,16 +835,18 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     SpanGuard g(c, KID_LPJ_OVF);
     if (need[0])
       sssc_small_kernel<4, 0, 2, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
+    const ListOut none_out = {nullptr, nullptr, 0};
     if (use_k8_kernel(c, TAG)) {
       if (need[1])
         sssc_small_kernel<8, 0, 2, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
-      if (need[2])
-        sssc_big_kernel<0><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, SSSC_BIG_LDS, c->stream>>>(a, i3);
     } else if (need[1]) {
-      // everything above 4 active latents goes to the wavefront-per-state kernel: one state's k x k
-      // system and its k^2 scatter are spread over 64 lanes instead of one long thread program
-      sssc_big_kernel<0><<<level_grid(c, 1, TAG, total * 256, 2048, 1), 64, SSSC_BIG_LDS, c->stream>>>(a, i2);
+      // a few thousand states above 4 active latents: the wavefront-per-state kernel, sized for k <= 8
+      // (1.9 KiB of LDS, many workgroups per CU); anything denser moves on to list 3
+      sssc_big_kernel<0><<<level_grid(c, 1, TAG, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(a, i2, o3, 8);
     }
+    if (need[2])
+      sssc_big_kernel<0><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+          a, i3, none_out, SSSC_KCAP);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -1219,14 +1220,16 @@ static int stats_compute(evoamd_ctx *c) {
       const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
       if (need[0])
         sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sa, i1, o2);
+      const ListOut none_out = {nullptr, nullptr, 0};
       if (use_k8_kernel(c, tg)) {
         if (need[1])
           sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sa, i2, o3);
-        if (need[2])
-          sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, SSSC_BIG_LDS, c->stream>>>(sa, i3);
       } else if (need[1]) {
-        sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 2048, 1), 64, SSSC_BIG_LDS, c->stream>>>(sa, i2);
+        sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sa, i2, o3, 8);
       }
+      if (need[2])
+        sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+            sa, i3, none_out, SSSC_KCAP);
       HIP_TRY(hipGetLastError());
     }
     // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is

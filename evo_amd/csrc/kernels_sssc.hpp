@@ -456,22 +456,25 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
     xss[t] = xss[(i64)j * H + i];
 }
 
-// One wavefront (64-thread workgroup) per listed pair; k <= SSSC_KCAP; system in LDS.
-// LDS: Tm[k*k] | Pm[k*k] | idx[KCAP] ints | vectors b, mu, v, w, f  (dynamic shared memory
-// sized for KCAP by the launcher).
+// One wavefront (64-thread workgroup) per listed pair, the k x k system in LDS, lanes over matrix
+// elements.  `kc` is the largest k this launch holds (LDS = 3 kc^2 + 5 kc doubles: 1.9 KiB at
+// kc = 8, 98 KiB at kc = 64); pairs above kc go to `lo` (or raise EVOAMD_E_KLIMIT when there is no
+// further level).  G_A and Psi_A are gathered into LDS once (k^2 parallel 16-byte gathers), so the
+// T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
 template <int MODE>
-__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
+__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc) {
   a.s2inv = a.dpar[DP_S2INV];
   __shared__ int prefix[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   double *Tm = lds;
-  double *Pm = Tm + SSSC_KCAP * SSSC_KCAP;
-  double *bv = Pm + SSSC_KCAP * SSSC_KCAP;
-  double *muv = bv + SSSC_KCAP;
-  double *vv = muv + SSSC_KCAP;
-  double *wv = vv + SSSC_KCAP;
-  double *fv = wv + SSSC_KCAP;
-  int *idx = (int *)(fv + SSSC_KCAP);
+  double *Pm = Tm + kc * kc;
+  double *Gm = Pm + kc * kc;
+  double *bv = Gm + kc * kc;
+  double *muv = bv + kc;
+  double *vv = muv + kc;
+  double *wv = vv + kc;
+  double *fv = wv + kc;
+  int *idx = (int *)(fv + kc);
   const int lane = threadIdx.x;
   const i64 total = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
@@ -487,13 +490,19 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
       const bool on = (bits >> (63 - lane)) & 1ull;
       const u64 m = __ballot(on);
       const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
-      if (on && pos < SSSC_KCAP) idx[pos] = w * 64 + lane;
+      if (on && pos < kc) idx[pos] = w * 64 + lane;
       k += __popcll(m);
     }
-    if (k > SSSC_KCAP) {
+    if (k > kc) {  // uniform
       if (lane == 0) {
-        atomicOr(a.err, 1);
-        if (MODE == 0) a.lpj_out[n * a.ldo + a.col0 + c] = EVO_F64_MIN;
+        if (lo.items) {
+          const int shard = (int)(t & (LIST_SHARDS - 1));
+          const int pos = atomicAdd(&lo.counts[shard], 1);
+          if (pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = (int)e;
+        } else {
+          atomicOr(a.err, 1);
+          if (MODE == 0) a.lpj_out[n * a.ldo + a.col0 + c] = EVO_F64_MIN;
+        }
       }
       continue;
     }
@@ -516,14 +525,15 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
     pb = wave_sum(pb);
     for (int q = lane; q < k * k; q += 64) {
       const int i = q / k, j = q - i * k;
-      Pm[q] = a.GP[(i64)idx[i] * a.H + idx[j]].y;
+      const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
+      Gm[q] = gp.x;
+      Pm[q] = gp.y;
     }
     __syncthreads();
     double rr_part = 0.0;
     if (lane < k) {
       double s = bv[lane];
-      const i64 ro = (i64)idx[lane] * a.H;
-      for (int j = 0; j < k; j++) s -= a.GP[ro + idx[j]].x * muv[j];
+      for (int j = 0; j < k; j++) s -= Gm[lane * k + j] * muv[j];
       vv[lane] = s;
       rr_part = muv[lane] * (bv[lane] + s);
     }
@@ -537,25 +547,22 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
     for (int q = lane; q < k * k; q += 64) {
       const int i = q / k, j = q - i * k;
       double tt = 0.0;
-      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * a.GP[(i64)idx[l] * a.H + idx[j]].x;
+      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
       Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
     }
     __syncthreads();
     // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
     bool singular = false;
     for (int p = 0; p < k; p++) {
-      double av = (lane >= p && lane < k) ? fabs(Tm[lane * k + p]) : -1.0;
-      int ai = lane;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double v2 = __shfl_xor(av, o, 64);
-        const int i2 = __shfl_xor(ai, o, 64);
-        if (v2 > av || (v2 == av && i2 < ai)) {
-          av = v2;
-          ai = i2;
-        }
+      // pivot: |column p| with 63 - row in the low 6 mantissa bits, one DPP max-reduce
+      double key = -1.0;
+      if (lane >= p && lane < k) {
+        const unsigned long long bits =
+            ((unsigned long long)__double_as_longlong(fabs(Tm[lane * k + p])) & ~0x3FULL) | (unsigned long long)(63 - lane);
+        key = __longlong_as_double((long long)bits);
       }
-      const int piv = ai;
+      key = wave_max(key);
+      const int piv = 63 - (int)((unsigned long long)__double_as_longlong(key) & 0x3FULL);
       if (piv != p) {
         if (lane < k) {
           const double t1 = Tm[p * k + lane];
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
       __syncthreads();
       const double d = Tm[p * k + p];
       if (d == 0.0) singular = true;
-      const double r = 1.0 / d;
+      const double r = fast_rcp(d);
       if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
       __syncthreads();
       const int m = k - p - 1;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li) {
     const double logdet = wave_sum(ld);
     // ---- back substitution, column oriented
     for (int p = k - 1; p >= 0; p--) {
-      const double r = 1.0 / Tm[p * k + p];
+      const double r = fast_rcp(Tm[p * k + p]);
       if (lane == 0) wv[p] *= r;
       if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
       __syncthreads();
