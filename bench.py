@@ -44,6 +44,21 @@ CONFIGS = {  # BASELINE.json "configs", per-GPU shard sizes
 }
 EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# dominant kernel per model (the pass over all N x S resident states) as rocprofv3 names it
+ROOFLINE_KERNEL = {"es3c": "void sssc_small_kernel<2, 0, 0, 1024>", "ebsc": "void bsc_lpj_gram_kernel<0>"}
+
+
+def pmc_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes
+    (profiles/<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % config)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d[kernel]["traffic_bytes_2xfetch_plus_write"])
+    except Exception:
+        return None
 
 
 def algorithmic_bytes_lpj(cfg, N):
@@ -195,10 +210,12 @@ def main():
                        "D": cfg["D"], "H": cfg["H"], "S": cfg["S"], "ea": "fit/randflip 10 parents x 1 child x 1 gen",
                        "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world, "free_energy_last": F,
                        "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms},
-            "roofline": {"bound": "hbm", "kernel": "sssc_small_kernel<4,0> (lpj over K^n)" if cfg["algo"] == "es3c"
-                         else "bsc_lpj_kernel (lpj over K^n)",
+            "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL[cfg["algo"]] + " (lpj of all N x S resident states)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.config, ROOFLINE_KERNEL[cfg["algo"]]),
+                         "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                         "2 x FETCH + WRITE (gfx950 read-side correction); committed under profiles/",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms},
         }
         if cpu is not None:

@@ -221,3 +221,39 @@ def test_device_mstep_matches_host(engine, name):
             scale = max(1.0, float(np.abs(ref).max()))
             np.testing.assert_allclose(d[3][k], h[3][k], rtol=1e-7, atol=1e-9 * scale, err_msg="%s vs host" % k)
             np.testing.assert_allclose(d[3][k], ref, rtol=1e-6, atol=1e-7 * scale, err_msg="%s vs reference" % k)
+
+
+def test_bench_path_with_rccl_communicator():
+    """The exact configuration bench.py runs per rank (rng='device', device M-step, K^n resident,
+    RcclComm) with a 1-rank RCCL communicator: same F trajectory as without a communicator."""
+    from evo_amd.engine import Engine
+    from evo_amd.models import SSSC
+    from evo_amd.utils import parallel
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(9)
+    D, H, S, N = 24, 40, 16, 200
+    Y = rng.normal(size=(N, D))
+    res = []
+    for use_comm in (False, True):
+        eng = Engine()
+        try:
+            comm = parallel.RcclComm(eng, 0, 1, Engine.comm_unique_id()) if use_comm else None
+            np.random.seed(4)
+            model = SSSC(D, H, S, comm=comm, rng="device", sync_host=False, engine=eng, seed=5, device_mstep=True)
+            my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 6, 1, 1)
+            Fs = []
+            for _ in range(4):
+                F, nu, nsub, theta = model.step(theta, suff, my_data)
+                Fs.append(F)
+            res.append(Fs)
+            assert np.isfinite(Fs).all() and Fs[-1] > Fs[0]
+            model.sync_to_host(suff)
+            for n in range(0, N, 37):
+                assert np.unique(np.packbits(suff["ss"][n], axis=-1), axis=0).shape[0] == S
+            if comm is not None:
+                comm.close()
+        finally:
+            eng.close()
+    np.testing.assert_allclose(res[1], res[0], rtol=1e-9)

@@ -60,6 +60,18 @@ def main(out):
             wl = w[0] / w[1] if w[1] else 0.0
             print("| %s | %d | %.1f | %.1f | %.3f |" % (n, max(f[1], w[1]), fl, wl, (2 * fl + wl) * 1024 / 1e6))
         print()
+    # machine-readable copy for bench.py's roofline.traffic (committed under profiles/)
+    if pmc:
+        import json
+        names = sorted(set(pmc.get("FETCH_SIZE", {})) | set(pmc.get("WRITE_SIZE", {})))
+        js = {}
+        for n in names:
+            f = pmc.get("FETCH_SIZE", {}).get(n, [0.0, 0])
+            w = pmc.get("WRITE_SIZE", {}).get(n, [0.0, 0])
+            fl = f[0] / f[1] if f[1] else 0.0
+            wl = w[0] / w[1] if w[1] else 0.0
+            js[n] = {"fetch_kib": fl, "write_kib": wl, "traffic_bytes_2xfetch_plus_write": (2 * fl + wl) * 1024}
+        json.dump(js, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for nm in ("bench_trace.json",):
         p = os.path.join(out, nm)
         if os.path.exists(p):
