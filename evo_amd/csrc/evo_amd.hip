@@ -305,6 +305,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)gjb_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   *out = c;
@@ -440,7 +441,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->tmpA, (size_t)H * H);
   ALLOC(c->tmpB, (size_t)H * H);
   ALLOC(c->tmpC, (size_t)H * H);
-  ALLOC(c->gjwork, (size_t)3 * H + 8);
+  ALLOC(c->gjwork, (size_t)(GJB + 3) * H + 8);  // unblocked: colp | rowp | perm; blocked: R (16 x H) | ipiv
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Es, (size_t)N * H);
   } else {
@@ -1301,6 +1302,21 @@ static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
   }
   double *mats[2] = {A, B};
   const dim3 ugrid(cdiv(n, 64), cdiv(n, 64));
+  if (n <= 1024) {  // blocked: panel (LDS, one workgroup) + interchange/copy + rank-16 MFMA update
+    int *ipiv = (int *)(c->gjwork + (size_t)GJB * n);
+    const size_t panel_lds = (size_t)GJB * n * sizeof(double);
+    for (int m = 0; m < 2; m++) {
+      if (!mats[m]) continue;
+      for (int p0 = 0; p0 < n; p0 += GJB) {
+        gjb_panel_kernel<<<1, MS_T, panel_lds, c->stream>>>(mats[m], n, p0, ipiv, c->dpar + DP_STATUS);
+        gjb_swap_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(mats[m], n, p0, ipiv, c->gjwork);
+        gjb_update_kernel<<<ugrid, 256, 0, c->stream>>>(mats[m], n, p0, c->gjwork);
+      }
+      gjb_unscramble_kernel<<<n, 256, (size_t)n * (sizeof(double) + sizeof(int)), c->stream>>>(mats[m], n, ipiv);
+      HIP_TRY(hipGetLastError());
+    }
+    return 0;
+  }
   for (int m = 0; m < 2; m++) {
     if (!mats[m]) continue;
     for (int p = 0; p < n; p++) {

@@ -280,6 +280,198 @@ __global__ __launch_bounds__(256) void gj_unscramble_kernel(double *__restrict__
   for (int k = t; k < n; k += 256) A[row + k] = rowbuf[k];
 }
 
+// ---------------------------------------------------------------------------------------
+// Blocked Gauss-Jordan inversion, 128 < n <= 1024: panels of GJB = 16 pivot columns.
+// The nb elementary steps of a panel are row operations that only use the nb pivot rows as sources,
+// so together they are  X <- X_sw + (E - I_J) X_sw[J, :]  for every column block X outside the panel,
+// where X_sw is X after the panel's row interchanges and E (n x nb) is what in-place elimination
+// leaves in the panel columns themselves.  Per panel:
+//   gjb_panel_kernel   one workgroup; the n x 16 panel lives in LDS (column major); unblocked
+//                      elimination with partial pivoting; writes E into A[:, J] and the pivot rows
+//   gjb_swap_kernel    applies the 16 row interchanges to the other columns, copies the pivot rows
+//                      R = X_sw[J, :] (zero in the panel's own columns)
+//   gjb_update_kernel  A += (E - I_J) R  on the f64 matrix cores (rank-16 update, one K slab)
+// 3 n / 16 + 1 launches per inverse instead of 2 n + 1 (n = 512: 97 instead of 1025).
+// ---------------------------------------------------------------------------------------
+#define GJB 16
+
+__global__ __launch_bounds__(MS_T) void gjb_panel_kernel(double *__restrict__ A, int n, int p0, int *__restrict__ ipiv,
+                                                         double *__restrict__ status) {
+  extern __shared__ double Pc[];  // GJB columns of n doubles (column major)
+  __shared__ double red_v[MS_T / 64];
+  __shared__ int piv_row;
+  const int t = threadIdx.x;
+  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
+  for (int e = t; e < n * nb; e += MS_T) {
+    const int i = e / nb, c = e - i * nb;
+    Pc[(size_t)c * n + i] = A[(size_t)i * n + p0 + c];
+  }
+  __syncthreads();
+  for (int q = 0; q < nb; q++) {
+    const int p = p0 + q;
+    double *col = Pc + (size_t)q * n;
+    // pivot: largest |col[i]|, i >= p; magnitude with 1023 - i in the low 10 mantissa bits
+    double key = -1.0;
+    for (int i = p + t; i < n; i += MS_T) {
+      const unsigned long long bits =
+          ((unsigned long long)__double_as_longlong(fabs(col[i])) & ~0x3FFULL) | (unsigned long long)(1023 - i);
+      key = fmax(key, __longlong_as_double((long long)bits));
+    }
+    key = wave_max(key);
+    if ((t & 63) == 0) red_v[t >> 6] = key;
+    __syncthreads();
+    if (t == 0) {
+      double k2 = red_v[0];
+      for (int w = 1; w < MS_T / 64; w++) k2 = fmax(k2, red_v[w]);
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(k2);
+      int r = 1023 - (int)(bits & 0x3FFULL);
+      const double mag = __longlong_as_double((long long)(bits & ~0x3FFULL));
+      if (!(mag > 0.0) || isinf(mag)) {
+        status[0] = 1.0;
+        r = p;
+      }
+      piv_row = r;
+      ipiv[p] = r;
+    }
+    __syncthreads();
+    const int r = piv_row;
+    if (r != p && t < nb) {  // interchange rows p and r inside the panel
+      const double x = Pc[(size_t)t * n + p];
+      Pc[(size_t)t * n + p] = Pc[(size_t)t * n + r];
+      Pc[(size_t)t * n + r] = x;
+    }
+    __syncthreads();
+    const double rinv = 1.0 / col[p];
+    // every thread keeps the column-q entries of its rows, then the pivot row is scaled
+    double f[(1024 + MS_T - 1) / MS_T];
+#pragma unroll
+    for (int j = 0; j < (1024 + MS_T - 1) / MS_T; j++) {
+      const int i = t + MS_T * j;
+      f[j] = (i < n) ? col[i] : 0.0;
+    }
+    __syncthreads();
+    if (t < nb) Pc[(size_t)t * n + p] = (t == q) ? rinv : Pc[(size_t)t * n + p] * rinv;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (1024 + MS_T - 1) / MS_T; j++) {
+      const int i = t + MS_T * j;
+      if (i < n && i != p) {
+        for (int c = 0; c < nb; c++) {
+          const double cur = (c == q) ? 0.0 : Pc[(size_t)c * n + i];
+          Pc[(size_t)c * n + i] = cur - f[j] * Pc[(size_t)c * n + p];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < n * nb; e += MS_T) {
+    const int i = e / nb, c = e - i * nb;
+    A[(size_t)i * n + p0 + c] = Pc[(size_t)c * n + i];
+  }
+}
+
+// one thread per column j: the panel's row interchanges in order, then R[q][j] = A[p0+q][j] (0 inside the panel)
+__global__ __launch_bounds__(256) void gjb_swap_kernel(double *__restrict__ A, int n, int p0,
+                                                       const int *__restrict__ ipiv, double *__restrict__ R) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
+  const bool inside = j >= p0 && j < p0 + nb;
+  if (!inside) {
+    for (int q = 0; q < nb; q++) {
+      const int p = p0 + q, r = ipiv[p];
+      if (r != p) {
+        const double x = A[(size_t)p * n + j];
+        A[(size_t)p * n + j] = A[(size_t)r * n + j];
+        A[(size_t)r * n + j] = x;
+      }
+    }
+  }
+  for (int q = 0; q < GJB; q++) R[(size_t)q * n + j] = (!inside && q < nb) ? A[(size_t)(p0 + q) * n + j] : 0.0;
+}
+
+// A (n x n) += D R with D = A[:, p0:p0+16] - I_J (n x 16, read before any tile of this launch is
+// written: the panel columns receive D * 0), R (16 x n).  64 x 64 tiles, one K slab of 16.
+__global__ __launch_bounds__(256) void gjb_update_kernel(double *__restrict__ A, int n, int p0,
+                                                         const double *__restrict__ R) {
+  __shared__ double Ds[GJB][80];
+  __shared__ double Rs[GJB][80];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
+  {
+    const int mi = t >> 2, k4 = (t & 3) * 4;  // D loader: row mi, 4 consecutive k
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k4 + q, i = m0 + mi;
+      double v = 0.0;
+      if (i < n && k < nb) v = A[(size_t)i * n + p0 + k] - ((i == p0 + k) ? 1.0 : 0.0);
+      Ds[k][mi] = v;
+    }
+    const int kr = t >> 4, c4 = (t & 15) * 4;  // R loader
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = n0 + c4 + q;
+      Rs[kr][c4 + q] = (j < n) ? R[(size_t)kr * n + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  // panel columns must not change: R is zero there, so those tiles' products vanish; skip the
+  // read-modify-write of tiles that lie completely inside the panel's columns anyway
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < GJB / 4; kk++) {
+    const int kl = kk * 4 + (lane >> 4);
+    double a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) a[i] = Ds[kl][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+    for (int j = 0; j < 2; j++) b[j] = Rs[kl][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (row < n && col < n && !(col >= p0 && col < p0 + nb)) A[(size_t)row * n + col] += acc[i][j][r];
+      }
+}
+
+// column permutation that undoes all recorded row interchanges (ipiv as ints)
+__global__ __launch_bounds__(256) void gjb_unscramble_kernel(double *__restrict__ A, int n,
+                                                             const int *__restrict__ ipiv) {
+  extern __shared__ double rowbuf[];  // n doubles + n ints
+  int *dest = (int *)(rowbuf + n);
+  const int t = threadIdx.x;
+  if (t == 0) {
+    for (int k = 0; k < n; k++) dest[k] = k;
+    for (int p = n - 1; p >= 0; p--) {
+      const int r = ipiv[p];
+      const int tmp = dest[p];
+      dest[p] = dest[r];
+      dest[r] = tmp;
+    }
+  }
+  __syncthreads();
+  const size_t row = (size_t)blockIdx.x * n;
+  for (int k = t; k < n; k += 256) rowbuf[k] = A[row + dest[k]];
+  __syncthreads();
+  for (int k = t; k < n; k += 256) A[row + k] = rowbuf[k];
+}
+
 // out (rows x cols) = in^T (cols x rows)
 __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, int rows_in, int cols_in,
                                                         double *__restrict__ out) {
