@@ -281,29 +281,72 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     const double *cl_n = cand_lpj + n * (i64)Cmax;
     int cnt = counts[n];
     if (cnt > Cmax) cnt = Cmax;
-    // --- de-duplicate: candidate c survives iff no equal row precedes it in [incl; K^n; cand[0:c]]
+    // --- de-duplicate: candidate c survives iff no equal row precedes it in [incl; K^n; cand[0:c]].
+    // Every lane hashes its own old states and its own candidates ONCE (the word loads are the only
+    // long-latency part); the scan over candidates then compares 64-bit hashes held in registers
+    // and falls back to the exact word compare only when two hashes agree.
+    u64 oh[SPL], ch[CPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) {
+      const int s = lane + 64 * q;
+      u64 h = 0;
+      if (s < S) {
+        const u64 *sw = st_n + (i64)s * HW;
+        for (int w = 0; w < HW; w++) h = (h ^ sw[w]) * 0x9E3779B97F4A7C15ull + (u64)w;
+      }
+      oh[q] = h;
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+      const int c = lane + 64 * q;
+      u64 h = 0;
+      if (c < cnt) {
+        const u64 *cw = cd_n + (i64)c * HW;
+        for (int w = 0; w < HW; w++) h = (h ^ cw[w]) * 0x9E3779B97F4A7C15ull + (u64)w;
+      }
+      ch[q] = h;
+    }
+    u64 zero_hash = 0;  // hash of the all-zero state (the permanent state when S_perm = 1)
+    for (int w = 0; w < HW; w++) zero_hash = (zero_hash ^ 0ull) * 0x9E3779B97F4A7C15ull + (u64)w;
     bool keep[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) keep[q] = false;
     for (int c = 0; c < cnt; c++) {
-      const u64 *cw = cd_n + (i64)c * HW;
+      // hash of candidate c, broadcast from its owner lane
+      u64 hc = 0;
+#pragma unroll
+      for (int q = 0; q < CPL; q++)
+        if ((c >> 6) == q) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(ch[q] & 0xffffffffull), c & 63);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(ch[q] >> 32), c & 63);
+          hc = ((u64)hi << 32) | lo;
+        }
+      bool maybe = false;
+#pragma unroll
+      for (int q = 0; q < SPL; q++) maybe = maybe || (lane + 64 * q < S && oh[q] == hc);
+#pragma unroll
+      for (int q = 0; q < CPL; q++) maybe = maybe || (lane + 64 * q < c && ch[q] == hc);
+      if (S_perm && lane == 0 && hc == zero_hash) maybe = true;
       bool dup = false;
-      for (int s = lane; s < S && !dup; s += 64) {
-        const u64 *sw = st_n + (i64)s * HW;
-        int w = 0;
-        while (w < HW && sw[w] == cw[w]) w++;  // almost always stops at the first differing word
-        dup = (w == HW);
-      }
-      for (int c2 = lane; c2 < c && !dup; c2 += 64) {
-        const u64 *sw = cd_n + (i64)c2 * HW;
-        int w = 0;
-        while (w < HW && sw[w] == cw[w]) w++;
-        dup = (w == HW);
-      }
-      if (S_perm && lane == 0 && !dup) {
-        bool zero = true;
-        for (int w = 0; w < HW; w++) zero = zero && (cw[w] == 0ull);
-        dup = zero;
+      if (__any(maybe)) {  // rare: confirm with the exact comparison
+        const u64 *cw = cd_n + (i64)c * HW;
+        for (int s = lane; s < S && !dup; s += 64) {
+          const u64 *sw = st_n + (i64)s * HW;
+          int w = 0;
+          while (w < HW && sw[w] == cw[w]) w++;
+          dup = (w == HW);
+        }
+        for (int c2 = lane; c2 < c && !dup; c2 += 64) {
+          const u64 *sw = cd_n + (i64)c2 * HW;
+          int w = 0;
+          while (w < HW && sw[w] == cw[w]) w++;
+          dup = (w == HW);
+        }
+        if (S_perm && lane == 0 && !dup) {
+          bool zero = true;
+          for (int w = 0; w < HW; w++) zero = zero && (cw[w] == 0ull);
+          dup = zero;
+        }
       }
       if (!__any(dup)) {
         n_uniq++;
