@@ -44,6 +44,7 @@ CONFIGS = {  # BASELINE.json "configs", per-GPU shard sizes
 }
 EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector peak
 # dominant kernel per model (the pass over all N x S resident states) as rocprofv3 names it
 ROOFLINE_KERNEL = {"es3c": "void sssc_small_kernel<2, 0, 0, 1024>", "ebsc": "void bsc_lpj_gram_kernel<0>"}
 
@@ -64,6 +65,15 @@ def pmc_traffic(config, kernel):
 def algorithmic_bytes_lpj(cfg, N):
     """lpj pass, per datapoint D*w + C*(ceil(H/8) + w) with w = 8, C = S."""
     return N * (cfg["D"] * 8 + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
+
+
+def gemm_flops_per_step(cfg):
+    """Dense f64 contractions of one EM iteration in steady state (the launches timed under
+    kernel class "gemm_f64"): the K = N statistics contraction, G = W^T W and B = Y W."""
+    N, D, H = cfg["N"], cfg["D"], cfg["H"]
+    if cfg["algo"] == "es3c":
+        return 2.0 * N * (D + 2 * H) * H + 2.0 * D * H * H + 2.0 * N * D * H
+    return 2.0 * N * H * D + 2.0 * D * H * H + 2.0 * N * D * H
 
 
 def make_problem(cfg, seed, model):
@@ -218,6 +228,13 @@ def main():
                                          "2 x FETCH + WRITE (gfx950 read-side correction); committed under profiles/",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms},
         }
+        g = kernel_ms.get("gemm_f64")
+        if g:
+            t_ms = g["avg_ms"] * g["launches_per_step"]
+            out["mfma"] = {"kernels": "gemm_tn_f64 + gemm_nn_f64 (v_mfma_f64_16x16x4_f64)", "flops_per_step": gemm_flops_per_step(cfg),
+                           "ms_per_step": t_ms, "achieved": gemm_flops_per_step(cfg) / (t_ms * 1e-3) / 1e12,
+                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": gemm_flops_per_step(cfg) / (t_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -150,6 +150,7 @@ struct evoamd_ctx {
   double *W = nullptr, *Wt = nullptr, *G = nullptr, *Psi = nullptr, *Bm = nullptr, *mus = nullptr,
          *pilbar_v = nullptr;
   double2 *GP = nullptr;
+  double4 *DG = nullptr;             // SSSC (H) {mu, pil_bar, G_hh, Psi_hh}
   double *pies = nullptr;            // SSSC (H)
   double *dpar = nullptr;            // device scalar block (DP_*), kernels read their scalars here
   double *h_dpar = nullptr;          // pinned mirror
@@ -315,7 +316,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
-                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,
+                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
@@ -460,6 +461,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->G, (size_t)H * H);
     ALLOC(c->Psi, (size_t)H * H);
     ALLOC(c->GP, (size_t)H * H);
+    ALLOC(c->DG, (size_t)H);
     ALLOC(c->Bm, (size_t)N * H);
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
@@ -677,7 +679,8 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   }
   int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
   if (r) return r;
-  interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP);
+  interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP, H, c->mus,
+                                                                      c->pilbar_v, c->DG);
   HIP_TRY(hipGetLastError());
   c->B_valid = false;
   if (c->have_data) {
@@ -756,6 +759,7 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.Bm = b.Bm;
   a.yy = b.yy;
   a.GP = c->GP;
+  a.DG = c->DG;
   a.mus = c->mus;
   a.pil_bar = c->pilbar_v;
   a.s2inv = 0.0;
@@ -1367,7 +1371,7 @@ static int update_params_device(evoamd_ctx *c, int learn) {
     if (r) return r;
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->acc + a.sz_sz, c->G, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar);
-    interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP);
+    interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP, H, c->mus, c->pilbar_v, c->DG);
     HIP_TRY(hipGetLastError());
     r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
     if (r) return r;

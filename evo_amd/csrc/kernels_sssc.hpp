@@ -30,6 +30,7 @@ struct SsscArgs {
   const double *Bm;      // (N,H)  b_n = W^T y_n
   const double *yy;      // (N)
   const double2 *GP;     // (H,H) interleaved {G_ij, Psi_ij}
+  const double4 *DG;     // (H) per-latent {mu_h, pil_bar_h, G_hh, Psi_hh}: one 32-byte gather per active latent
   const double *mus;     // (H)
   const double *pil_bar; // (H)
   double s2inv;          // filled in by the kernels from dpar[DP_S2INV]
@@ -241,20 +242,25 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
   for (int i = 0; i < K; i++) {
     const bool on = i < k;
     b[i] = on ? Bn[idx[i]] : 0.0;
-    mu[i] = on ? a.mus[idx[i]] : 0.0;
-    pb += on ? a.pil_bar[idx[i]] : 0.0;
+    double4 d = make_double4(0.0, 0.0, 0.0, 1.0);  // padding: mu 0, pil_bar 0, G_ii 0, Psi_ii 1
+    if (on) d = a.DG[idx[i]];
+    mu[i] = d.x;
+    pb += d.y;
+    G[i][i] = d.z;
+    P[i][i] = d.w;
   }
 #pragma unroll
   for (int i = 0; i < K; i++)
 #pragma unroll
     for (int j = 0; j < K; j++) {
+      if (i == j) continue;
       if (i < k && j < k) {
         const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
         G[i][j] = gp.x;
         P[i][j] = gp.y;
       } else {
         G[i][j] = 0.0;
-        P[i][j] = (i == j) ? 1.0 : 0.0;
+        P[i][j] = 0.0;
       }
     }
   double rr = a.yy[n];
@@ -687,7 +693,11 @@ __global__ __launch_bounds__(256) void set_diag_kernel(double *__restrict__ M, c
 // GP[i][j] = {G[i][j], Psi[i][j]}
 __global__ __launch_bounds__(256) void interleave_gp_kernel(const double *__restrict__ G,
                                                             const double *__restrict__ Psi, i64 n,
-                                                            double2 *__restrict__ GP) {
+                                                            double2 *__restrict__ GP, int H,
+                                                            const double *__restrict__ mus,
+                                                            const double *__restrict__ pil_bar,
+                                                            double4 *__restrict__ DG) {
   i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
   if (i < n) GP[i] = make_double2(G[i], Psi[i]);
+  if (i < H) DG[i] = make_double4(mus[i], pil_bar[i], G[i * H + i], Psi[i * H + i]);
 }
