@@ -127,6 +127,8 @@ struct evoamd_ctx {
   int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
                      // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
+  bool spd_inverse = true;  // M-step H x H systems: SPD block Gauss-Jordan first, pivoted path on a bad pivot
+  long spd_fallbacks = 0;   // how often the pivoted repeat was needed
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
   int model = 0;
   i64 N = 0;
@@ -306,7 +308,6 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
-  HIP_TRY(hipFuncSetAttribute((const void *)gjb_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   *out = c;
@@ -352,6 +353,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "bsc_direct") == 0) {
     c->bsc_direct = value != 0;
     c->have_params = false;  // G / B are (not) needed: set_params again
+    return 0;
+  }
+  if (strcmp(name, "inverse_spd") == 0) {
+    c->spd_inverse = value != 0;
     return 0;
   }
   return fail(EVOAMD_E_INVALID, "unknown option '%s'", name);
@@ -442,7 +447,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->tmpA, (size_t)H * H);
   ALLOC(c->tmpB, (size_t)H * H);
   ALLOC(c->tmpC, (size_t)H * H);
-  ALLOC(c->gjwork, (size_t)(GJB + 3) * H + 8);  // unblocked: colp | rowp | perm; blocked: R (16 x H) | ipiv
+  // two ping-pong H x H partners | pivoted path: D, Pn (2 x H x 32 each), ipiv, perm (unblocked,
+  // H > 1024: colp | rowp | perm in the same place) | SPD path: Pinv (2 x 2 x 256), diag (2 x H)
+  ALLOC(c->gjwork, (size_t)2 * H * H + (size_t)132 * H + 1040);
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Es, (size_t)N * H);
   } else {
@@ -1300,7 +1307,7 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
 // device-side Theta update
 // ---------------------------------------------------------------------------------------
 // Inverts A (and B, if not null) in place; the two are independent.
-static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
+static int launch_inverse_pivoted(evoamd_ctx *c, double *A, double *B, int n) {
   if (n <= GJR_N) {
     gj_inverse_reg_kernel<<<B ? 2 : 1, MS_T, 0, c->stream>>>(A, B, n, c->dpar + DP_STATUS);
     HIP_TRY(hipGetLastError());
@@ -1308,19 +1315,31 @@ static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
   }
   double *mats[2] = {A, B};
   const dim3 ugrid(cdiv(n, 64), cdiv(n, 64));
-  if (n <= 1024) {  // blocked: panel (LDS, one workgroup) + interchange/copy + rank-16 MFMA update
-    int *ipiv = (int *)(c->gjwork + (size_t)GJB * n);
-    const size_t panel_lds = (size_t)GJB * n * sizeof(double);
-    for (int m = 0; m < 2; m++) {
-      if (!mats[m]) continue;
-      for (int p0 = 0; p0 < n; p0 += GJB) {
-        gjb_panel_kernel<<<1, MS_T, panel_lds, c->stream>>>(mats[m], n, p0, ipiv, c->dpar + DP_STATUS);
-        gjb_swap_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(mats[m], n, p0, ipiv, c->gjwork);
-        gjb_update_kernel<<<ugrid, 256, 0, c->stream>>>(mats[m], n, p0, c->gjwork);
-      }
-      gjb_unscramble_kernel<<<n, 256, (size_t)n * (sizeof(double) + sizeof(int)), c->stream>>>(mats[m], n, ipiv);
-      HIP_TRY(hipGetLastError());
+  if (n <= 1024) {  // blocked: register panel + fused interchange / rank-NB MFMA update, both matrices per launch
+    const int nmat = B ? 2 : 1;
+    GjMats gm;
+    gm.a[0] = A;
+    gm.a[1] = B ? B : A;
+    gm.w[0] = c->gjwork;
+    gm.w[1] = c->gjwork + (size_t)n * n;
+    double *Dp = c->gjwork + (size_t)2 * n * n;  // 2 x n x NB (NB <= 32)
+    double *Pn = Dp + (size_t)64 * n;
+    int *ipiv = (int *)(Pn + (size_t)64 * n);
+    int *perm = ipiv + 2 * n;
+    const int rpt = n <= 256 ? 1 : 2;  // rows per thread of the panel kernel
+    const int pthreads = cdiv(cdiv(n, rpt), 64) * 64;
+    const dim3 ug(cdiv(n, 64), cdiv(n, 64), nmat);
+    int flip = 0;
+    for (int p0 = 0; p0 < n; p0 += 16, flip ^= 1) {
+      const int pf = flip | (p0 ? 0 : 4);
+      if (rpt == 1)
+        gjp_panel_kernel<16, 1><<<nmat, pthreads, 0, c->stream>>>(gm, n, p0, pf, ipiv, perm, Pn, Dp, c->dpar + DP_STATUS);
+      else
+        gjp_panel_kernel<16, 2><<<nmat, pthreads, 0, c->stream>>>(gm, n, p0, pf, ipiv, perm, Pn, Dp, c->dpar + DP_STATUS);
+      gjp_update_kernel<16><<<ug, 256, 0, c->stream>>>(gm, n, p0, flip, ipiv, Dp, Pn);
     }
+    gjp_unscramble_kernel<<<dim3(n, nmat), 256, 0, c->stream>>>(gm, n, flip, perm);
+    HIP_TRY(hipGetLastError());
     return 0;
   }
   for (int m = 0; m < 2; m++) {
@@ -1335,9 +1354,38 @@ static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n) {
   return 0;
 }
 
+// SPD block Gauss-Jordan (kernels_mstep.hpp: gjs_*): one launch per 16 columns, both matrices together.
+static int launch_inverse_spd(evoamd_ctx *c, double *A, double *B, int n) {
+  const int nmat = B ? 2 : 1;
+  GjMats gm;
+  gm.a[0] = A;
+  gm.a[1] = B ? B : A;
+  gm.w[0] = c->gjwork;
+  gm.w[1] = c->gjwork + (size_t)n * n;
+  double *Pinv = c->gjwork + (size_t)2 * n * n + (size_t)130 * n + 8;
+  double *d0 = Pinv + 2 * 2 * GJS_B * GJS_B;
+  gjs_first_kernel<<<nmat, 64, 0, c->stream>>>(gm, n, Pinv, d0, c->dpar + DP_STATUS);
+  const dim3 grid(cdiv(n, 64), cdiv(n, 64), nmat);
+  int flip = 0;
+  for (int p0 = 0; p0 < n; p0 += GJS_B, flip ^= 1)
+    gjs_step_kernel<<<grid, 256, 0, c->stream>>>(gm, n, p0, flip, Pinv, d0, c->dpar + DP_STATUS);
+  HIP_TRY(hipGetLastError());
+  if (flip) {  // odd number of block steps: the result sits in the partner buffers
+    for (int k = 0; k < nmat; k++)
+      HIP_TRY(hipMemcpyAsync(gm.a[k], gm.w[k], (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+
+// force_pivot: the caller saw status == 3 from the SPD path and repeats the solve
+static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n, bool force_pivot = false) {
+  if (c->spd_inverse && !force_pivot) return launch_inverse_spd(c, A, B, n);
+  return launch_inverse_pivoted(c, A, B, n);
+}
+
 // Theta^new from the device accumulator (which evoamd_stats / stats_compute left behind), clamps,
 // precompute and the dense G / B refresh; all stream-ordered, no host arithmetic.
-static int update_params_device(evoamd_ctx *c, int learn) {
+static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = false) {
   const AccLayout a = acc_layout(c);
   const int H = c->H, D = c->D;
   const i64 HH = (i64)H * H;
@@ -1355,11 +1403,11 @@ static int update_params_device(evoamd_ctx *c, int learn) {
       sssc_psi_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->mus, c->acc + a.xss, c->acc + a.xszsz,
                                                                     c->acc + a.s_sz, H, c->tmpC, c->tmpB);
     if ((learn & L_W) && (learn & L_PSI))
-      r = launch_inverse(c, c->tmpA, c->tmpB, H);
+      r = launch_inverse(c, c->tmpA, c->tmpB, H, force_pivot);
     else if (learn & L_W)
-      r = launch_inverse(c, c->tmpA, nullptr, H);
+      r = launch_inverse(c, c->tmpA, nullptr, H, force_pivot);
     else if (learn & L_PSI)
-      r = launch_inverse(c, c->tmpB, nullptr, H);
+      r = launch_inverse(c, c->tmpB, nullptr, H, force_pivot);
     if (r) return r;
     if (learn & L_W)
       gemm_nn_f64<<<dim3(cdiv(H, GEMM_BN), cdiv(D, GEMM_BM)), 256, 0, c->stream>>>(c->acc + a.sWp, H, c->tmpA, H, c->W,
@@ -1381,7 +1429,7 @@ static int update_params_device(evoamd_ctx *c, int learn) {
   } else {
     if (learn & L_W) {  // W^T = solve(Wq, Wp)  (bsc.py:237; lstsq == solve for a non-singular Wq)
       HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      r = launch_inverse(c, c->tmpA, nullptr, H);
+      r = launch_inverse(c, c->tmpA, nullptr, H, force_pivot);
       if (r) return r;
       gemm_nn_f64<<<dim3(cdiv(D, GEMM_BN), cdiv(H, GEMM_BM)), 256, 0, c->stream>>>(c->tmpA, H, c->acc + a.Wp, D, c->Wt,
                                                                                     D, H, D, H);
@@ -1418,6 +1466,22 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
   memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
   if (r) return r;
+  if (learn_mask && c->h_dpar[DP_STATUS] == 3.0) {
+    // the SPD block elimination met a non-positive pivot: repeat the Theta update with partial
+    // pivoting.  The statistics are still in acc; ljc moves back so that the update kernels shift
+    // it into ljc_prev again.
+    c->spd_fallbacks++;
+    HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    r = update_params_device(c, learn_mask, /*force_pivot=*/true);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(h, c->acc + a.tail, (8 + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    r = check_err(c);
+    memcpy(tail_out, h, 8 * sizeof(double));
+    memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
+    memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
+    if (r) return r;
+  }
   note_levels(c, c->h_dpar);
   if (c->h_dpar[DP_STATUS] != 0.0) {
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
@@ -1425,6 +1489,48 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
                 c->h_dpar[DP_STATUS] == 1.0 ? "singular H x H system (the reference falls back to pinv / lstsq here)"
                                             : "non-finite sigma / pi");
   }
+  return 0;
+}
+
+extern "C" int evoamd_inverse(evoamd_ctx *c, double *A, double *B, int n, double *timing_ms) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(A && n == c->H, "A must be H x H of the configured context");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = (size_t)n * n * sizeof(double);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double st = 0.0;
+  int r = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {  // second pass: pivoted repeat after an SPD failure
+    HIP_TRY(hipMemcpyAsync(c->tmpA, A, bytes, hipMemcpyHostToDevice, c->stream));
+    if (B) HIP_TRY(hipMemcpyAsync(c->tmpB, B, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    r = launch_inverse(c, c->tmpA, B ? c->tmpB : nullptr, n, attempt == 1);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    if (r) break;
+    HIP_TRY(hipMemcpyAsync(c->h_dpar + DP_COUNT, c->dpar + DP_STATUS, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    st = c->h_dpar[DP_COUNT];
+    if (st != 3.0) break;
+    c->spd_fallbacks++;
+  }
+  float ms = 0.f;
+  if (!r) {
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (st == 0.0) {
+      HIP_TRY(hipMemcpyAsync(A, c->tmpA, bytes, hipMemcpyDeviceToHost, c->stream));
+      if (B) HIP_TRY(hipMemcpyAsync(B, c->tmpB, bytes, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (timing_ms) *timing_ms = ms;
+  if (r) return r;
+  if (st != 0.0) return fail(EVOAMD_E_SINGULAR, "evoamd_inverse: singular %d x %d system", n, n);
   return 0;
 }
 

@@ -280,152 +280,282 @@ __global__ __launch_bounds__(256) void gj_unscramble_kernel(double *__restrict__
   for (int k = t; k < n; k += 256) A[row + k] = rowbuf[k];
 }
 
-// ---------------------------------------------------------------------------------------
-// Blocked Gauss-Jordan inversion, 128 < n <= 1024: panels of GJB = 16 pivot columns.
-// The nb elementary steps of a panel are row operations that only use the nb pivot rows as sources,
-// so together they are  X <- X_sw + (E - I_J) X_sw[J, :]  for every column block X outside the panel,
-// where X_sw is X after the panel's row interchanges and E (n x nb) is what in-place elimination
-// leaves in the panel columns themselves.  Per panel:
-//   gjb_panel_kernel   one workgroup; the n x 16 panel lives in LDS (column major); unblocked
-//                      elimination with partial pivoting; writes E into A[:, J] and the pivot rows
-//   gjb_swap_kernel    applies the 16 row interchanges to the other columns, copies the pivot rows
-//                      R = X_sw[J, :] (zero in the panel's own columns)
-//   gjb_update_kernel  A += (E - I_J) R  on the f64 matrix cores (rank-16 update, one K slab)
-// 3 n / 16 + 1 launches per inverse instead of 2 n + 1 (n = 512: 97 instead of 1025).
-// ---------------------------------------------------------------------------------------
 #define GJB 16
 
-__global__ __launch_bounds__(MS_T) void gjb_panel_kernel(double *__restrict__ A, int n, int p0, int *__restrict__ ipiv,
-                                                         double *__restrict__ status) {
-  extern __shared__ double Pc[];  // GJB columns of n doubles (column major)
-  __shared__ double red_v[MS_T / 64];
-  __shared__ int piv_row;
-  const int t = threadIdx.x;
-  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
-  for (int e = t; e < n * nb; e += MS_T) {
-    const int i = e / nb, c = e - i * nb;
-    Pc[(size_t)c * n + i] = A[(size_t)i * n + p0 + c];
+// ---------------------------------------------------------------------------------------
+// Blocked Gauss-Jordan with partial pivoting (general matrices, 128 < n <= 1024; the M-step only
+// comes here when the SPD path below reports a bad pivot): up to two
+// independent matrices per launch (ES3C inverts xpt_szsz and xpt_ss + eps I in the same M-step),
+// ping-pong buffers so that the row interchanges are a gather fused into the rank-NB update, and a
+// panel kernel that keeps one matrix row per thread in registers (one barrier per pivot).
+//   gjp_panel_kernel<NB>   one workgroup per matrix, thread i owns row i of the n x NB panel; per
+//                          pivot: DPP wave arg-max, the candidate rows of all waves parked in LDS,
+//                          ONE barrier, every thread picks the winner and eliminates its own row
+//                          (pivot row broadcast lane -> SGPR with v_readlane, not 64-wide LDS reads).
+//                          All its global traffic is compact and coalesced: it reads the panel
+//                          from Pn (n x NB, written by the previous update) and writes
+//                          D = E - I_J (n x NB), ipiv and the running column permutation.
+//   gjp_update_kernel<NB>  dst = src[sigma(.), :] + D * src[sigma(J), :] on the f64 matrix cores;
+//                          sigma = the panel's NB interchanges composed, rebuilt per workgroup.
+//                          Also scatters E into dst[:, J] and gathers the NEXT panel's columns
+//                          into Pn, so the single-CU panel kernel never touches a strided column
+//                          (that alone was 13-30 us of its 29-53 us).
+//   gjp_unscramble_kernel  column permutation undoing all interchanges, src -> dst (may alias).
+// 2 launches per panel for both matrices together (was 3 per panel per matrix).
+// ---------------------------------------------------------------------------------------
+struct GjMats {
+  double *a[2];  // the matrices (input, and output of the inverse)
+  double *w[2];  // ping-pong partners
+};
+
+__device__ __forceinline__ double readlane_f64_dyn(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v, unsigned o) { return v > o ? v : o; }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_move_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+// max over the 16 lanes of each DPP row (every lane of the row gets it)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  v = dpp_max_u32(v, dpp_move_u32<0xB1, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x4E, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x141, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x140, 0xF>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = row16_max_u32(v);
+  v = dpp_max_u32(v, dpp_move_u32<0x142, 0xA>(v));  // lanes outside the row mask see their own value
+  v = dpp_max_u32(v, dpp_move_u32<0x143, 0xC>(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Pivot key: exponent and the top 11 mantissa bits of |x| above 1023 - row, one 32-bit integer, so
+// the arg-max is integer DPP (a dependent f64 op costs 32 cycles on gfx950, an integer one 4-8).
+// The pivot is then the largest candidate up to a factor 1 + 2^-11 (ties: the smallest row), which
+// is all partial pivoting needs.  0 = not a candidate (zero, denormal, NaN, inf, row < p).
+__device__ __forceinline__ unsigned pivot_key(double x, int row) {
+  const unsigned hi = (unsigned)__double2hiint(x) & 0x7FFFFFFFu;
+  const unsigned top = hi >> 9;  // 11 + 11 bits
+  if (top == 0u || (hi >> 20) == 0x7FFu) return 0u;
+  return (top << 10) | (unsigned)(1023 - row);
+}
+
+// flip bit 0: ping-pong direction; bit 2: first panel, read the columns from the matrix itself.
+// RPT rows per thread (row i belongs to thread i % T, slot i / T, T = blockDim.x).
+template <int NB, int RPT>
+__global__ __launch_bounds__(MS_T / RPT) void gjp_panel_kernel(GjMats m, int n, int p0, int flip, int *__restrict__ ipiv_all,
+                                                         int *__restrict__ perm_all, const double *__restrict__ Pn_all,
+                                                         double *__restrict__ Dp_all, double *__restrict__ status) {
+  static_assert(NB <= 64, "one lane per panel column");
+  const int mat = blockIdx.x;
+  const double *__restrict__ src = (flip & 1) ? m.w[mat] : m.a[mat];
+  int *__restrict__ ipiv = ipiv_all + (size_t)mat * n;
+  const double *__restrict__ Pn = Pn_all + (size_t)mat * n * NB;
+  double *__restrict__ Dp = Dp_all + (size_t)mat * n * NB;
+  __shared__ unsigned wkey[2][MS_T / 64];
+  __shared__ double wrow[2][MS_T / 64][NB + 2];  // candidate row of each wave, [NB] = 1 / its pivot element
+  __shared__ double krow[2][NB + 2];             // row p before the interchange
+  __shared__ int lpiv[NB];
+  const int T = (int)blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = T >> 6;
+  const int nb = (p0 + NB <= n) ? NB : n - p0;
+  double a[RPT][NB];
+  int cur[RPT];
+  int *__restrict__ perm = perm_all + (size_t)mat * n;
+#pragma unroll
+  for (int s = 0; s < RPT; s++) {
+    const int i = t + s * T;
+    if (flip & 4) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) a[s][c] = (i < n && c < nb) ? src[(size_t)i * n + p0 + c] : 0.0;
+    } else {
+#pragma unroll
+      for (int c = 0; c < NB; c++) a[s][c] = (i < n) ? Pn[(size_t)i * NB + c] : 0.0;  // zero beyond nb (update kernel)
+    }
+    // perm[k]: which column of the eliminated matrix becomes column k of the inverse.  The serial
+    // rule "dest = id; for p = n-1..0: swap(dest[p], dest[ipiv[p]])" read backwards from position k
+    // visits the interchanges in increasing p, so every panel advances it by its own nb pivots.
+    cur[s] = (p0 == 0 || i >= n) ? i : perm[i];
   }
-  __syncthreads();
-  for (int q = 0; q < nb; q++) {
-    const int p = p0 + q;
-    double *col = Pc + (size_t)q * n;
-    // pivot: largest |col[i]|, i >= p; magnitude with 1023 - i in the low 10 mantissa bits
-    double key = -1.0;
-    for (int i = p + t; i < n; i += MS_T) {
-      const unsigned long long bits =
-          ((unsigned long long)__double_as_longlong(fabs(col[i])) & ~0x3FFULL) | (unsigned long long)(1023 - i);
-      key = fmax(key, __longlong_as_double((long long)bits));
-    }
-    key = wave_max(key);
-    if ((t & 63) == 0) red_v[t >> 6] = key;
-    __syncthreads();
-    if (t == 0) {
-      double k2 = red_v[0];
-      for (int w = 1; w < MS_T / 64; w++) k2 = fmax(k2, red_v[w]);
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(k2);
-      int r = 1023 - (int)(bits & 0x3FFULL);
-      const double mag = __longlong_as_double((long long)(bits & ~0x3FFULL));
-      if (!(mag > 0.0) || isinf(mag)) {
-        status[0] = 1.0;
-        r = p;
-      }
-      piv_row = r;
-      ipiv[p] = r;
-    }
-    __syncthreads();
-    const int r = piv_row;
-    if (r != p && t < nb) {  // interchange rows p and r inside the panel
-      const double x = Pc[(size_t)t * n + p];
-      Pc[(size_t)t * n + p] = Pc[(size_t)t * n + r];
-      Pc[(size_t)t * n + r] = x;
-    }
-    __syncthreads();
-    const double rinv = 1.0 / col[p];
-    // every thread keeps the column-q entries of its rows, then the pivot row is scaled
-    double f[(1024 + MS_T - 1) / MS_T];
+  if (t < NB) lpiv[t] = p0 + t;
+  // The pivot loop is a REAL loop (a fully unrolled body is ~6000 instructions executed once per
+  // launch, and the kernel then runs at instruction-fetch speed: measured 38 us per panel whatever
+  // the arithmetic).  To keep register indices static the panel columns rotate: the column being
+  // eliminated is always a[.][0], and after NB steps every column is back in its place.
+#pragma unroll 1
+  for (int q = 0; q < NB; q++) {
+    if (q < nb) {  // uniform
+      const int p = p0 + q, b = q & 1;
+      unsigned key = 0u;
+      int sb = 0;
 #pragma unroll
-    for (int j = 0; j < (1024 + MS_T - 1) / MS_T; j++) {
-      const int i = t + MS_T * j;
-      f[j] = (i < n) ? col[i] : 0.0;
-    }
-    __syncthreads();
-    if (t < nb) Pc[(size_t)t * n + p] = (t == q) ? rinv : Pc[(size_t)t * n + p] * rinv;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < (1024 + MS_T - 1) / MS_T; j++) {
-      const int i = t + MS_T * j;
-      if (i < n && i != p) {
-        for (int c = 0; c < nb; c++) {
-          const double cur = (c == q) ? 0.0 : Pc[(size_t)c * n + i];
-          Pc[(size_t)c * n + i] = cur - f[j] * Pc[(size_t)c * n + p];
+      for (int s = 0; s < RPT; s++) {
+        const int i = t + s * T;
+        const unsigned k = (i >= p && i < n) ? pivot_key(a[s][0], i) : 0u;
+        if (k > key) {
+          key = k;
+          sb = s;
         }
       }
-    }
-    __syncthreads();
-  }
-  for (int e = t; e < n * nb; e += MS_T) {
-    const int i = e / nb, c = e - i * nb;
-    A[(size_t)i * n + p0 + c] = Pc[(size_t)c * n + i];
-  }
-}
-
-// one thread per column j: the panel's row interchanges in order, then R[q][j] = A[p0+q][j] (0 inside the panel)
-__global__ __launch_bounds__(256) void gjb_swap_kernel(double *__restrict__ A, int n, int p0,
-                                                       const int *__restrict__ ipiv, double *__restrict__ R) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
-  const bool inside = j >= p0 && j < p0 + nb;
-  if (!inside) {
-    for (int q = 0; q < nb; q++) {
-      const int p = p0 + q, r = ipiv[p];
-      if (r != p) {
-        const double x = A[(size_t)p * n + j];
-        A[(size_t)p * n + j] = A[(size_t)r * n + j];
-        A[(size_t)r * n + j] = x;
+      double cand[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        cand[c] = a[0][c];
+#pragma unroll
+        for (int s = 1; s < RPT; s++)
+          if (sb == s) cand[c] = a[s][c];
+      }
+      const double rl = fast_rcp(cand[0]);  // independent of the reduction below: overlaps with it
+      const unsigned wm = wave_max_u32(key);
+      if (wm != 0u) {
+        if (key == wm) {  // exactly one lane: the tags are distinct
+          wkey[b][wave] = key;
+#pragma unroll
+          for (int c = 0; c < NB; c++) wrow[b][wave][c] = cand[c];
+          wrow[b][wave][NB] = rl;
+        }
+      } else if (lane == 0) {
+        wkey[b][wave] = 0u;
+      }
+#pragma unroll
+      for (int s = 0; s < RPT; s++) {
+        if (t + s * T == p) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) krow[b][c] = a[s][c];
+          krow[b][NB] = 1.0;
+        }
+      }
+      __syncthreads();
+      const unsigned k16 = row16_max_u32(((lane & 15) < nw) ? wkey[b][lane & 15] : 0u);
+      const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)k16);
+      const bool bad = (best >> 10) == 0u;
+      const int r = bad ? p : 1023 - (int)(best & 0x3FFu);
+      // no global stores inside the loop: __syncthreads() waits for their acknowledgement
+      if (t == 0) lpiv[q] = bad ? -1 - r : r;
+      const int sr = r / T, tr = r - sr * T;
+      // lane c fetches element c of the pivot row (one 8-byte LDS read per lane instead of NB
+      // wave-wide broadcasts); the values then travel lane -> SGPR
+      const double *__restrict__ prp = bad ? krow[b] : wrow[b][tr >> 6];
+      const double prl = prp[lane & (NB - 1)];
+      const double rinv = prp[NB];
+      double prc[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) prc[c] = readlane_f64_dyn(prl, c);
+#pragma unroll
+      for (int s = 0; s < RPT; s++) {
+        const int i = t + s * T;
+        if (cur[s] == p) cur[s] = r;
+        else if (cur[s] == r) cur[s] = p;
+        if (i == r && r != p) {  // this row takes over what row p held
+#pragma unroll
+          for (int c = 0; c < NB; c++) a[s][c] = krow[b][c];
+        }
+        const double g = a[s][0] * rinv;  // LAPACK's getf2 order: scale the column, then the rank-1 update
+        a[s][0] = (i == p) ? rinv : -g;
+#pragma unroll
+        for (int c = 1; c < NB; c++) a[s][c] = (i == p) ? prc[c] * rinv : fma(-g, prc[c], a[s][c]);
       }
     }
+#pragma unroll
+    for (int s = 0; s < RPT; s++) {  // rotate: next column to the front
+      const double first = a[s][0];
+#pragma unroll
+      for (int c = 0; c + 1 < NB; c++) a[s][c] = a[s][c + 1];
+      a[s][NB - 1] = first;
+    }
   }
-  for (int q = 0; q < GJB; q++) R[(size_t)q * n + j] = (!inside && q < nb) ? A[(size_t)(p0 + q) * n + j] : 0.0;
+  if (t == 0) {  // lpiv was written by this same thread
+    bool any_bad = false;
+    for (int q = 0; q < nb; q++) {
+      int r = lpiv[q];
+      if (r < 0) {
+        any_bad = true;
+        r = -1 - r;
+      }
+      ipiv[p0 + q] = r;
+    }
+    if (any_bad) status[0] = 1.0;
+  }
+#pragma unroll
+  for (int s = 0; s < RPT; s++) {
+    const int i = t + s * T;
+    if (i < n) {
+      perm[i] = cur[s];
+#pragma unroll
+      for (int c = 0; c < NB; c++) Dp[(size_t)i * NB + c] = (c < nb) ? a[s][c] - ((i == p0 + c) ? 1.0 : 0.0) : 0.0;
+    }
+  }
 }
 
-// A (n x n) += D R with D = A[:, p0:p0+16] - I_J (n x 16, read before any tile of this launch is
-// written: the panel columns receive D * 0), R (16 x n).  64 x 64 tiles, one K slab of 16.
-__global__ __launch_bounds__(256) void gjb_update_kernel(double *__restrict__ A, int n, int p0,
-                                                         const double *__restrict__ R) {
-  __shared__ double Ds[GJB][80];
-  __shared__ double Rs[GJB][80];
+template <int NB>
+__global__ __launch_bounds__(256) void gjp_update_kernel(GjMats m, int n, int p0, int flip,
+                                                         const int *__restrict__ ipiv_all,
+                                                         const double *__restrict__ Dp_all,
+                                                         double *__restrict__ Pn_all) {
+  const int mat = blockIdx.z;
+  const double *__restrict__ src = (flip & 1) ? m.w[mat] : m.a[mat];
+  double *__restrict__ dst = (flip & 1) ? m.a[mat] : m.w[mat];
+  const int *__restrict__ ipiv = ipiv_all + (size_t)mat * n;
+  const double *__restrict__ Dp = Dp_all + (size_t)mat * n * NB;
+  double *__restrict__ Pn = Pn_all + (size_t)mat * n * NB;
+  __shared__ double Ds[NB][80];
+  __shared__ double Rs[NB][80];
+  __shared__ int piv[NB];
+  __shared__ int srow[64 + NB];  // source rows of the tile's 64 rows, then of the NB pivot rows
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nb = (p0 + GJB <= n) ? GJB : n - p0;
+  const int nb = (p0 + NB <= n) ? NB : n - p0;
+  if (t < NB) piv[t] = (t < nb) ? ipiv[p0 + t] : p0 + t;
+  __syncthreads();
+  if (t < 64 + NB) {
+    int s = (t < 64) ? m0 + t : p0 + (t - 64);
+    for (int q = nb - 1; q >= 0; q--) {  // X_sw[i] = X[T_0(T_1(...T_{nb-1}(i)))]
+      const int p = p0 + q, r = piv[q];
+      if (s == p) s = r;
+      else if (s == r) s = p;
+    }
+    srow[t] = s;
+  }
   {
-    const int mi = t >> 2, k4 = (t & 3) * 4;  // D loader: row mi, 4 consecutive k
+    const int mi = t >> 2, k0 = (t & 3) * (NB / 4);  // D loader: row mi, NB/4 consecutive k
+    const int i = m0 + mi;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int k = k4 + q, i = m0 + mi;
-      double v = 0.0;
-      if (i < n && k < nb) v = A[(size_t)i * n + p0 + k] - ((i == p0 + k) ? 1.0 : 0.0);
-      Ds[k][mi] = v;
-    }
-    const int kr = t >> 4, c4 = (t & 15) * 4;  // R loader
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int j = n0 + c4 + q;
-      Rs[kr][c4 + q] = (j < n) ? R[(size_t)kr * n + j] : 0.0;
-    }
+    for (int q = 0; q < NB / 4; q++) Ds[k0 + q][mi] = (i < n) ? Dp[(size_t)i * NB + k0 + q] : 0.0;
   }
   __syncthreads();
-  // panel columns must not change: R is zero there, so those tiles' products vanish; skip the
-  // read-modify-write of tiles that lie completely inside the panel's columns anyway
+  {
+    const int c4 = (t & 15) * 4;  // R loader: pivot rows after the interchanges, zero inside the panel's columns
+#pragma unroll
+    for (int kr = t >> 4; kr < NB; kr += 16) {
+      const size_t rb = (size_t)srow[64 + kr] * n;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = n0 + c4 + q;
+        const bool inside = j >= p0 && j < p0 + nb;
+        Rs[kr][c4 + q] = (j < n && kr < nb && !inside) ? src[rb + j] : 0.0;
+      }
+    }
+  }
   v4f64 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-  for (int kk = 0; kk < GJB / 4; kk++) {
+      for (int r = 0; r < 4; r++) {
+        const int lr = wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        const bool inside = col >= p0 && col < p0 + nb;
+        acc[i][j][r] = (m0 + lr < n && col < n && !inside) ? src[(size_t)srow[lr] * n + col] : 0.0;
+      }
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; kk++) {
     const int kl = kk * 4 + (lane >> 4);
     double a[2], b[2];
 #pragma unroll
@@ -444,32 +574,233 @@ __global__ __launch_bounds__(256) void gjb_update_kernel(double *__restrict__ A,
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int lr = wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int row = m0 + lr;
         const int col = n0 + wn * 32 + j * 16 + (lane & 15);
-        if (row < n && col < n && !(col >= p0 && col < p0 + nb)) A[(size_t)row * n + col] += acc[i][j][r];
+        if (row < n && col < n) {
+          double v = acc[i][j][r];
+          if (col >= p0 && col < p0 + nb) v = Ds[col - p0][lr] + ((row == col) ? 1.0 : 0.0);  // E = D + I_J
+          dst[(size_t)row * n + col] = v;
+          const int cn = col - (p0 + NB);  // the next panel's columns, compact for the panel kernel
+          if (cn >= 0 && cn < NB) Pn[(size_t)row * NB + cn] = v;
+        }
       }
+  // columns of the next panel that do not exist (ragged last panel) read as zero
+  if (p0 + NB < n && p0 + 2 * NB > n && blockIdx.x == 0) {
+    for (int e = t; e < 64 * NB; e += 256) {
+      const int row = m0 + e / NB, cn = e % NB;
+      if (row < n && p0 + NB + cn >= n) Pn[(size_t)row * NB + cn] = 0.0;
+    }
+  }
 }
 
-// column permutation that undoes all recorded row interchanges (ipiv as ints)
-__global__ __launch_bounds__(256) void gjb_unscramble_kernel(double *__restrict__ A, int n,
-                                                             const int *__restrict__ ipiv) {
-  extern __shared__ double rowbuf[];  // n doubles + n ints
-  int *dest = (int *)(rowbuf + n);
-  const int t = threadIdx.x;
-  if (t == 0) {
-    for (int k = 0; k < n; k++) dest[k] = k;
-    for (int p = n - 1; p >= 0; p--) {
-      const int r = ipiv[p];
-      const int tmp = dest[p];
-      dest[p] = dest[r];
-      dest[r] = tmp;
+// ---------------------------------------------------------------------------------------
+// Block Gauss-Jordan for SYMMETRIC POSITIVE DEFINITE matrices -- what the M-step actually inverts:
+// Wq = sum q s s^T (bsc.py:212), xpt_szsz = sum q (Lambda + kappa kappa^T) (sssc.py:600) and
+// xpt_ss + eps I (sssc.py:738) are Gram-type moment matrices.  For SPD matrices every diagonal
+// block of every Schur complement is SPD, so the 16 x 16 DIAGONAL BLOCK is the pivot and no row
+// interchanges are needed: the n sequential pivot searches over whole columns (1.2-1.6 us each on
+// one CU, 3.0 ms for n = 1024) shrink to a 16 x 16 inversion by a single wave, and everything else
+// is a rank-16 MFMA update.  One launch per block step:
+//   E[:, J] = [ -A[i, J] P^-1  (i not in J) ;  P^-1  (i in J) ],   A <- A + (E - I_J) A[J, :]
+// (in-place block Gauss-Jordan written out of place, src -> dst ping-pong).  The workgroup that
+// owns the NEXT diagonal block inverts it right after its own tile update and leaves it in Pinv,
+// so the next launch starts with the pivot ready.  A pivot that is not > 1e-13 x its original
+// diagonal entry (zero, negative, NaN) sets status = 3 and the caller repeats the solve with the
+// partially pivoted path above -- the reference's np.linalg.inv is partial pivoting LU.
+// ---------------------------------------------------------------------------------------
+#define GJS_B 16
+
+// In-place inverse of the SPD 16 x 16 block M (LDS, row stride 17) by ONE wave: lane l owns row
+// l & 15, columns 4 (l >> 4) .. +3.  No pivoting, no barriers (one wave's LDS operations execute in
+// order).  d0[q] = original diagonal entries for the singularity test.  Returns false on a bad pivot.
+__device__ __forceinline__ bool inv16_spd_wave(double (*M)[GJS_B + 1], const double *d0) {
+  const int l = lane_id(), i = l & 15, c0 = (l >> 4) * 4;
+  bool ok = true;
+  double a[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) a[j] = M[i][c0 + j];
+#pragma unroll 1
+  for (int q = 0; q < GJS_B; q++) {
+    const double piv = M[q][q];
+    const double f = M[i][q];
+    double pr[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pr[j] = M[q][c0 + j];
+    if (!(piv > 1e-13 * d0[q])) ok = false;
+    const double rinv = fast_rcp(piv);
+    const double g = f * rinv;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = c0 + j;
+      double v;
+      if (i == q) v = (c == q) ? rinv : pr[j] * rinv;
+      else v = (c == q) ? -g : fma(-g, pr[j], a[j]);
+      a[j] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; j++) M[i][c0 + j] = a[j];
+    __builtin_amdgcn_wave_barrier();
+  }
+  return __all(ok);
+}
+
+// Stashes diag(A) (the singularity scale) and inverts the first diagonal block: <<<nmat, 64>>>.
+__global__ __launch_bounds__(64) void gjs_first_kernel(GjMats m, int n, double *__restrict__ Pinv_all,
+                                                       double *__restrict__ d0_all, double *__restrict__ status) {
+  const int mat = blockIdx.x, l = threadIdx.x;
+  const double *__restrict__ A = m.a[mat];
+  double *__restrict__ d0 = d0_all + (size_t)mat * n;
+  double *__restrict__ Pinv = Pinv_all + (size_t)mat * 2 * GJS_B * GJS_B;
+  __shared__ double M[GJS_B][GJS_B + 1];
+  __shared__ double dd[GJS_B];
+  for (int k = l; k < n; k += 64) d0[k] = A[(size_t)k * n + k];
+  const int nb = n < GJS_B ? n : GJS_B;
+  for (int e = l; e < GJS_B * GJS_B; e += 64) {
+    const int r = e >> 4, c = e & 15;
+    M[r][c] = (r < nb && c < nb) ? A[(size_t)r * n + c] : ((r == c) ? 1.0 : 0.0);
+  }
+  if (l < GJS_B) dd[l] = (l < nb) ? A[(size_t)l * n + l] : 1.0;
+  __syncthreads();
+  const bool ok = inv16_spd_wave(M, dd);
+  for (int e = l; e < GJS_B * GJS_B; e += 64) Pinv[e] = M[e >> 4][e & 15];
+  if (!ok && l == 0) status[0] = 3.0;
+}
+
+__global__ __launch_bounds__(256) void gjs_step_kernel(GjMats m, int n, int p0, int flip, double *__restrict__ Pinv_all,
+                                                       const double *__restrict__ d0_all,
+                                                       double *__restrict__ status) {
+  const int mat = blockIdx.z;
+  const double *__restrict__ src = (flip & 1) ? m.w[mat] : m.a[mat];
+  double *__restrict__ dst = (flip & 1) ? m.a[mat] : m.w[mat];
+  const int kstep = p0 / GJS_B;
+  const double *__restrict__ Pin = Pinv_all + ((size_t)mat * 2 + (kstep & 1)) * GJS_B * GJS_B;
+  double *__restrict__ Pout = Pinv_all + ((size_t)mat * 2 + ((kstep + 1) & 1)) * GJS_B * GJS_B;
+  const double *__restrict__ d0 = d0_all + (size_t)mat * n;
+  __shared__ double Pi[GJS_B][GJS_B + 1];
+  __shared__ double Ar[64][GJS_B + 1];
+  __shared__ double Ds[GJS_B][80];
+  __shared__ double Rs[GJS_B][80];
+  __shared__ double Pn[GJS_B][GJS_B + 1];
+  __shared__ double dn[GJS_B];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nb = (p0 + GJS_B <= n) ? GJS_B : n - p0;
+  Pi[t >> 4][t & 15] = Pin[t];
+  {
+    const int mi = t >> 2, c4 = (t & 3) * 4, i = m0 + mi;
+#pragma unroll
+    for (int q = 0; q < 4; q++) Ar[mi][c4 + q] = (i < n && c4 + q < nb) ? src[(size_t)i * n + p0 + c4 + q] : 0.0;
+    const int kr = t >> 4, r4 = (t & 15) * 4;  // pivot rows, zero inside the block's own columns
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int j = n0 + r4 + q;
+      const bool inside = j >= p0 && j < p0 + nb;
+      Rs[kr][r4 + q] = (j < n && kr < nb && !inside) ? src[(size_t)(p0 + kr) * n + j] : 0.0;
+    }
+  }
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        const bool inside = col >= p0 && col < p0 + nb;
+        acc[i][j][r] = (row < n && col < n && !inside) ? src[(size_t)row * n + col] : 0.0;
+      }
+  __syncthreads();
+  {  // D = E - I_J for the tile's 64 rows: thread -> row mi, 4 of the 16 columns
+    const int mi = t & 63, k0 = (t >> 6) * 4, row = m0 + mi;
+    const bool inJ = row >= p0 && row < p0 + nb;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = k0 + kk;
+      double v;
+      if (inJ) {
+        v = Pi[row - p0][k] - ((row - p0 == k) ? 1.0 : 0.0);
+      } else {
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < GJS_B; j++) sacc = fma(Ar[mi][j], Pi[j][k], sacc);
+        v = -sacc;
+      }
+      Ds[k][mi] = (k < nb) ? v : 0.0;
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < GJS_B / 4; kk++) {
+    const int kl = kk * 4 + (lane >> 4);
+    double a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) a[i] = Ds[kl][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+    for (int j = 0; j < 2; j++) b[j] = Rs[kl][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  // next diagonal block: rows / columns p1 .. p1 + 15 form exactly one 16 x 16 MFMA sub-tile
+  const int p1 = p0 + GJS_B;
+  const bool diag_tile = p1 < n && m0 == (p1 / 64) * 64 && n0 == m0;
+  const int dl = p1 - m0;  // local offset of the next block inside this tile (multiple of 16)
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const bool mine = diag_tile && dl == wm * 32 + i * 16 && dl == wn * 32 + j * 16;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int lr = wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int row = m0 + lr;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        double v = acc[i][j][r];
+        if (col >= p0 && col < p0 + nb) v = Ds[col - p0][lr] + ((row == col) ? 1.0 : 0.0);  // E = D + I_J
+        if (row < n && col < n) dst[(size_t)row * n + col] = v;
+        if (mine) {
+          const int rr = (lane >> 4) + 4 * r, cc = lane & 15;
+          Pn[rr][cc] = (row < n && col < n) ? v : ((rr == cc) ? 1.0 : 0.0);
+        }
+      }
+      if (mine) {  // wave-uniform: this wave holds the whole block
+        if (lane < GJS_B) dn[lane] = (p1 + lane < n) ? d0[p1 + lane] : 1.0;
+        __builtin_amdgcn_wave_barrier();
+        const bool ok = inv16_spd_wave(Pn, dn);
+        for (int e = lane; e < GJS_B * GJS_B; e += 64) Pout[e] = Pn[e >> 4][e & 15];
+        if (!ok && lane == 0) status[0] = 3.0;
+      }
+    }
+}
+
+// column permutation that undoes all recorded interchanges (perm from the panel kernels); one
+// workgroup per (row, matrix).  The row passes through registers, so src == dst is fine.
+__global__ __launch_bounds__(256) void gjp_unscramble_kernel(GjMats m, int n, int from_w,
+                                                             const int *__restrict__ perm_all) {
+  const int mat = blockIdx.y;
+  const double *src = from_w ? m.w[mat] : m.a[mat];
+  double *dst = m.a[mat];
+  const int *__restrict__ perm = perm_all + (size_t)mat * n;
+  const int t = threadIdx.x;
   const size_t row = (size_t)blockIdx.x * n;
-  for (int k = t; k < n; k += 256) rowbuf[k] = A[row + dest[k]];
+  double v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = t + 256 * j;
+    v[j] = (k < n) ? src[row + perm[k]] : 0.0;
+  }
   __syncthreads();
-  for (int k = t; k < n; k += 256) A[row + k] = rowbuf[k];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = t + 256 * j;
+    if (k < n) dst[row + k] = v[j];
+  }
 }
 
 // out (rows x cols) = in^T (cols x rows)

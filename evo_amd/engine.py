@@ -187,6 +187,15 @@ class Engine:
         d["ljc_estep"] = d["ljc_prev"] if mask else d["ljc"]
         return dict(zip(TAIL, tail)), d
 
+    def inverse(self, A, B=None):
+        """The M-step's H x H solver: returns (inv(A), inv(B) or None, device milliseconds)."""
+        A = np.array(A, dtype=np.float64, order="C")
+        assert A.shape == (self.H, self.H)
+        Bc = None if B is None else np.array(B, dtype=np.float64, order="C")
+        ms = ctypes.c_double()
+        check(self.lib.evoamd_inverse(self._h, dptr(A), None if Bc is None else dptr(Bc), self.H, ctypes.byref(ms)))
+        return A, Bc, ms.value
+
     def get_params_bsc(self):
         W = np.empty((self.D, self.H))
         pi, sigma = ctypes.c_double(), ctypes.c_double()

@@ -163,6 +163,12 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
  * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
+/* The M-step's H x H solver on its own: A (and B if not NULL) are replaced by their inverses
+ * (row-major n x n, n == H of the configured context).  This is the Gauss-Jordan code path that
+ * evoamd_mstep_device uses in place of np.linalg.inv (sssc.py:693,738) / lstsq (bsc.py:237);
+ * exported so that the parity tests can drive it with pivoting and near-singular cases.
+ * timing_ms (may be NULL) receives the device time of the inversion. */
+int evoamd_inverse(evoamd_ctx *ctx, double *A, double *B, int n, double *timing_ms);
 /* Current parameters of the context back to the host (after evoamd_mstep_device). */
 int evoamd_get_params_bsc(evoamd_ctx *ctx, double *W, double *pi, double *sigma);
 int evoamd_get_params_sssc(evoamd_ctx *ctx, double *W, double *pies, double *mus, double *Psi,

@@ -213,3 +213,58 @@ def test_rccl_single_rank_allreduce(engine):
         comm.close()
     finally:
         eng.close()
+
+
+def _moment_matrix(rng, n, cond_boost=0.05):
+    X = rng.standard_normal((n, 3 * n))
+    return X @ X.T / (3 * n) + cond_boost * np.eye(n)
+
+
+@pytest.mark.parametrize("n", [7, 16, 40, 100, 128, 130, 200, 500])
+def test_inverse_spd_block_path(engine, n):
+    """The M-step's H x H solver on Gram-type (SPD) matrices -- the shape np.linalg.inv is given
+    at sssc.py:693,738 and lstsq at bsc.py:237 -- against numpy, two matrices per call."""
+    rng = np.random.default_rng(100 + n)
+    engine.configure("bsc", 8, 4, n, 4, 0, 4)
+    A, B = _moment_matrix(rng, n), _moment_matrix(rng, n, 1e-3) + np.diag(rng.uniform(0, 2, n))
+    engine.set_option("inverse_spd", 1)
+    Ai, Bi, _ = engine.inverse(A, B)
+    for M, Mi in ((A, Ai), (B, Bi)):
+        ref = np.linalg.inv(M)
+        assert np.abs(Mi - ref).max() <= 1e-10 * np.abs(ref).max()
+        assert np.abs(Mi @ M - np.eye(n)).max() < 1e-9
+    # the partially pivoted path gives the same inverse to rounding
+    engine.set_option("inverse_spd", 0)
+    Ap, Bp, _ = engine.inverse(A, B)
+    engine.set_option("inverse_spd", 1)
+    assert np.abs(Ap - Ai).max() <= 1e-11 * np.abs(Ai).max()
+    assert np.abs(Bp - Bi).max() <= 1e-11 * np.abs(Bi).max()
+
+
+@pytest.mark.parametrize("n", [33, 128, 200, 300])
+def test_inverse_falls_back_to_pivoting(engine, n):
+    """A matrix that is not SPD (zero leading entry, general entries) makes the block path report a
+    bad pivot; the library repeats with partial pivoting and still returns the inverse."""
+    rng = np.random.default_rng(7 + n)
+    engine.configure("bsc", 8, 4, n, 4, 0, 4)
+    G = rng.standard_normal((n, n))
+    G[0, 0] = 0.0
+    A = _moment_matrix(rng, n)
+    engine.set_option("inverse_spd", 1)
+    Ai, Gi, _ = engine.inverse(A, G)
+    assert np.abs(Gi @ G - np.eye(n)).max() < 1e-8
+    assert np.abs(Ai @ A - np.eye(n)).max() < 1e-9
+    ref = np.linalg.inv(G)
+    assert np.abs(Gi - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_inverse_singular_is_reported(engine):
+    from evo_amd._lib import EvoAmdError
+    n = 48
+    rng = np.random.default_rng(3)
+    engine.configure("bsc", 8, 4, n, 4, 0, 4)
+    A = _moment_matrix(rng, n)
+    A[:, 5] = 0.0
+    A[5, :] = 0.0  # a latent that never occurs: exactly singular moment matrix
+    with pytest.raises(EvoAmdError):
+        engine.inverse(A)
