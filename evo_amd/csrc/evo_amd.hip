@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,11 @@ struct evoamd_ctx {
   int ldY = 0;
   double *h_acc = nullptr, *h_par = nullptr;  // pinned host staging (accumulator D2H, Theta H2D)
   size_t h_par_n = 0;
+  double *h_theta = nullptr;  // host mailbox (kernels_mstep.hpp: mailbox_kernel): seq | err | tail | dpar | Theta
+  double *h_theta_dev = nullptr;  // the same memory as the device sees it
+  bool h_theta_fresh = false;
+  unsigned long long mbox_seq = 0;
+  unsigned *mbox_counter = nullptr;
   int *h_err = nullptr;
   // variational state
   u64 *states = nullptr, *cand = nullptr;
@@ -176,6 +182,7 @@ struct evoamd_ctx {
   int rank = 0, world = 1;
   // timing
   bool timing = false;
+  unsigned timing_mask = 0xFFFFFFFFu;  // which kernel classes record events (each record costs ~5 us of stream time)
   std::vector<TimedSpan> spans;
   std::vector<hipEvent_t> pool;
   double t_ms[KID_COUNT] = {0};
@@ -187,7 +194,7 @@ struct SpanGuard {
   int kid;
   hipEvent_t a = nullptr, b = nullptr;
   SpanGuard(evoamd_ctx *ctx, int k) : c(ctx), kid(k) {
-    if (!c->timing) return;
+    if (!c->timing || !((c->timing_mask >> k) & 1u)) return;
     auto get = [&]() {
       hipEvent_t e;
       if (!c->pool.empty()) {
@@ -325,6 +332,8 @@ static void free_all(evoamd_ctx *c) {
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
+  if (c->h_theta) (void)hipHostFree(c->h_theta);
+  c->h_theta = nullptr;
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->h_dpar) (void)hipHostFree(c->h_dpar);
 }
@@ -485,6 +494,16 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->h_par_n = (size_t)D * H + (size_t)H * H + 3 * (size_t)H;
   HIP_TRY(hipHostMalloc((void **)&c->h_acc, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&c->h_par, c->h_par_n * sizeof(double), hipHostMallocDefault));
+  if (c->h_theta) (void)hipHostFree(c->h_theta);
+  HIP_TRY(hipHostMalloc((void **)&c->h_theta, (c->h_par_n + MAILBOX_HDR) * sizeof(double),
+                        hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c->h_theta, 0, MAILBOX_HDR * sizeof(double));
+  HIP_TRY(hipHostGetDevicePointer((void **)&c->h_theta_dev, c->h_theta, 0));
+  if (!c->mbox_counter) {
+    HIP_TRY(hipMalloc((void **)&c->mbox_counter, sizeof(unsigned)));
+    HIP_TRY(hipMemset(c->mbox_counter, 0, sizeof(unsigned)));
+  }
+  c->h_theta_fresh = false;
   HIP_TRY(hipMemsetAsync(c->Y, 0, (size_t)N * c->ldY * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
@@ -637,6 +656,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
     }
   }
   c->have_params = true;
+  c->h_theta_fresh = false;
   return 0;
 }
 
@@ -696,6 +716,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
     c->B_valid = true;
   }
   c->have_params = true;
+  c->h_theta_fresh = false;
   return 0;
 }
 
@@ -1449,24 +1470,71 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
   return 0;
 }
 
+// Everything an EM iteration returns to the host goes through the mailbox kernel; the host polls
+// the sequence number (falls back to a blocking synchronise after 20 ms of spinning).
+static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta) {
+  const AccLayout a = acc_layout(c);
+  const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
+  MailboxSegs segs = {};
+  if (with_theta) {
+    segs.src[0] = c->W;
+    segs.n[0] = (long long)DH;
+    if (c->model == EVOAMD_MODEL_SSSC) {
+      segs.src[1] = c->Psi;
+      segs.n[1] = (long long)HH;
+      segs.src[2] = c->mus;
+      segs.n[2] = (long long)H;
+      segs.src[3] = c->pies;
+      segs.n[3] = (long long)H;
+    }
+  }
+  const unsigned long long seq = ++c->mbox_seq;
+  const long long total = MAILBOX_HDR + (with_theta ? (long long)(DH + HH + 2 * H) : 0);
+  const int grid = (int)std::min<long long>(64, cdiv(total, 256 * 8));
+  mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, c->stream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
+                                                              c->mbox_counter, seq);
+  HIP_TRY(hipGetLastError());
+  volatile unsigned long long *flag = (volatile unsigned long long *)c->h_theta;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*flag != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFu) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (*flag != seq) return fail(EVOAMD_E_HIP, "mailbox kernel finished without publishing its sequence number");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return 0;
+}
+
+static int mailbox_errors(evoamd_ctx *c) {
+  const int *e = (const int *)(c->h_theta + 1);
+  if (e[0]) {
+    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), c->stream));
+    if (e[0] & 4) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow level was skipped although its list was not empty");
+    if (e[0] & 1) return fail(EVOAMD_E_KLIMIT, "ES3C: a state has more than %d active latents", SSSC_KCAP);
+    return fail(EVOAMD_E_SINGULAR, "ES3C: exactly singular k x k system (the reference takes pinv here)");
+  }
+  return 0;
+}
+
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
   int r = stats_compute(c);
   if (r) return r;
-  const AccLayout a = acc_layout(c);
+  c->h_theta_fresh = false;
   if (learn_mask) {
     r = update_params_device(c, learn_mask);
     if (r) return r;
   }
-  // accumulator tail (8) and the scalar block (16) are adjacent: one copy
-  double *h = c->h_acc + a.tail;
-  HIP_TRY(hipMemcpyAsync(h, c->acc + a.tail, (8 + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  r = check_err(c);  // synchronises
-  memcpy(tail_out, h, 8 * sizeof(double));
-  memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
-  memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
+  // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
+  // the reference's step() hands Theta^new back, so it rides along
+  r = mailbox_roundtrip(c, learn_mask != 0);
   if (r) return r;
-  if (learn_mask && c->h_dpar[DP_STATUS] == 3.0) {
+  const double *h = c->h_theta + 8;
+  if (learn_mask && h[8 + DP_STATUS] == 3.0) {
     // the SPD block elimination met a non-positive pivot: repeat the Theta update with partial
     // pivoting.  The statistics are still in acc; ljc moves back so that the update kernels shift
     // it into ljc_prev again.
@@ -1475,14 +1543,16 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     r = update_params_device(c, learn_mask, /*force_pivot=*/true);
     if (r) return r;
-    HIP_TRY(hipMemcpyAsync(h, c->acc + a.tail, (8 + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    r = check_err(c);
-    memcpy(tail_out, h, 8 * sizeof(double));
-    memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
-    memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
+    r = mailbox_roundtrip(c, true);
     if (r) return r;
   }
+  memcpy(tail_out, h, 8 * sizeof(double));
+  memcpy(dpar_out, h + 8, DP_COUNT * sizeof(double));
+  memcpy(c->h_dpar, h + 8, DP_COUNT * sizeof(double));
+  r = mailbox_errors(c);
+  if (r) return r;
   note_levels(c, c->h_dpar);
+  c->h_theta_fresh = learn_mask != 0 && c->h_dpar[DP_STATUS] == 0.0;
   if (c->h_dpar[DP_STATUS] != 0.0) {
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
     return fail(EVOAMD_E_SINGULAR, "device Theta update: %s",
@@ -1537,6 +1607,12 @@ extern "C" int evoamd_inverse(evoamd_ctx *c, double *A, double *B, int n, double
 extern "C" int evoamd_get_params_bsc(evoamd_ctx *c, double *W, double *pi, double *sigma) {
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC && c->have_params, "no BSC parameters on the device");
   REQUIRE(W && pi && sigma, "NULL output");
+  if (c->h_theta_fresh) {  // evoamd_mstep_device already brought Theta over
+    memcpy(W, c->h_theta + MAILBOX_HDR, (size_t)c->D * c->H * sizeof(double));
+    *pi = c->h_dpar[DP_PI];
+    *sigma = c->h_dpar[DP_SIGMA];
+    return 0;
+  }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_par, c->W, (size_t)c->D * c->H * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1551,6 +1627,16 @@ extern "C" int evoamd_get_params_bsc(evoamd_ctx *c, double *W, double *pi, doubl
 extern "C" int evoamd_get_params_sssc(evoamd_ctx *c, double *W, double *pies, double *mus, double *Psi, double *sigma2) {
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_SSSC && c->have_params, "no SSSC parameters on the device");
   REQUIRE(W && pies && mus && Psi && sigma2, "NULL output");
+  if (c->h_theta_fresh) {  // evoamd_mstep_device already brought Theta over
+    const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
+    const double *th = c->h_theta + MAILBOX_HDR;
+    memcpy(W, th, DH * sizeof(double));
+    memcpy(Psi, th + DH, HH * sizeof(double));
+    memcpy(mus, th + DH + HH, H * sizeof(double));
+    memcpy(pies, th + DH + HH + H, H * sizeof(double));
+    *sigma2 = c->h_dpar[DP_SIGMA2];
+    return 0;
+  }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
@@ -1653,6 +1739,7 @@ extern "C" int evoamd_timing_enable(evoamd_ctx *c, int on) {
     if (r) return r;
   }
   c->timing = on != 0;
+  c->timing_mask = (unsigned)on;  // bit k = kernel class k; 1-bits beyond EVOAMD_K_COUNT are harmless
   return 0;
 }
 

@@ -803,6 +803,47 @@ __global__ __launch_bounds__(256) void gjp_unscramble_kernel(GjMats m, int n, in
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Host mailbox: what an EM iteration hands back to the host (accumulator tail + scalar block, the
+// error words and Theta^new) is written by ONE kernel straight into pinned, host-coherent memory;
+// the last workgroup to finish publishes a sequence number the host spins on.  This replaces five
+// copy-engine commands plus an interrupt-driven stream synchronisation (~50 us of idle stream per
+// iteration at the c2 size) by one launch and a cache-line poll.
+//   out[0]        sequence number (uint64), written last
+//   out[1..2]     err[0..3] (int32 x 4)
+//   out[8..31]    tail (8) | dpar (16)
+//   out[32..]     up to four segments, back to back (W | Psi | mus | pies for ES3C; W for EBSC)
+// ---------------------------------------------------------------------------------------
+struct MailboxSegs {
+  const double *src[4];
+  long long n[4];
+};
+#define MAILBOX_HDR 32
+__global__ __launch_bounds__(256) void mailbox_kernel(double *__restrict__ out, const double *__restrict__ tail24,
+                                                      const int *__restrict__ err, MailboxSegs segs,
+                                                      unsigned *__restrict__ counter, unsigned long long seq) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < 24) out[8 + t] = tail24[t];
+  if (t < 4) ((int *)(out + 1))[t] = err[t];
+  long long base = MAILBOX_HDR;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    for (long long i = t; i < segs.n[k]; i += stride) out[base + i] = segs.src[k][i];
+    base += segs.n[k];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = atomicAdd(counter, 1u);
+    if (done == gridDim.x - 1) {
+      *counter = 0u;  // ready for the next launch (stream-ordered)
+      __threadfence_system();
+      __hip_atomic_store((unsigned long long *)out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // out (rows x cols) = in^T (cols x rows)
 __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, int rows_in, int cols_in,
                                                         double *__restrict__ out) {

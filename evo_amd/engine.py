@@ -243,7 +243,16 @@ class Engine:
 
     # ---- timing --------------------------------------------------------------------------
     def timing(self, on=True):
-        check(self.lib.evoamd_timing_enable(self._h, 1 if on else 0))
+        """on: True (all kernel classes), False, or an iterable of class names (_lib.KERNEL_IDS)."""
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            mask = 0
+            for name in on:
+                mask |= 1 << _lib.KERNEL_IDS[name]
+        check(self.lib.evoamd_timing_enable(self._h, mask))
 
     def timing_reset(self):
         check(self.lib.evoamd_timing_reset(self._h))

@@ -103,6 +103,7 @@ class Model:
         self._engine = engine
         self._device = device
         self._y_token = None
+        self._x_infr_token = None
         self._resident = False   # K^n on the device is authoritative (sync_host=False only)
         self._acc = None         # statistics computed by E_step for the M_step of the same step()
         self._n_steps = 0
@@ -124,8 +125,12 @@ class Model:
     def _prepare(self, my_suff_stat, my_data, upload_states=True):
         """Configure the engine for this rank's shard and make Y / K^n resident."""
         Y = my_data["y"]
-        if not my_data["x_infr"].all():
-            raise NotImplementedError("missing data (x_infr) is outside the accelerated path (SURVEY 8f rank 3)")
+        xi = my_data["x_infr"]
+        xi_token = (id(xi), xi.shape)
+        if self._x_infr_token != xi_token:  # checked once per array object, like the Y upload below
+            if not xi.all():
+                raise NotImplementedError("missing data (x_infr) is outside the accelerated path (SURVEY 8f rank 3)")
+            self._x_infr_token = xi_token
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])

@@ -205,6 +205,9 @@ enum {
   EVOAMD_K_MSTEP_DEVICE = 10,  /* device Theta update (inverse, GEMMs, precompute) */
   EVOAMD_K_COUNT = 11
 };
+/* on = bit mask of kernel classes to time (bit k = class k; -1 = all, 0 = off).  Each timed span
+ * records two HIP events on the compute stream, which costs about 10 us of stream time per span:
+ * a throughput run times only the class it needs. */
 int evoamd_timing_enable(evoamd_ctx *ctx, int on);
 int evoamd_timing_reset(evoamd_ctx *ctx);
 int evoamd_kernel_time_ms(evoamd_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/quick_${CFG}
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --steps 12 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/trace.log
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
