@@ -159,6 +159,8 @@ struct evoamd_ctx {
          *pilbar_v = nullptr;
   double2 *GP = nullptr;
   double4 *DG = nullptr;             // SSSC (H) {mu, pil_bar, G_hh, Psi_hh}
+  double4 *D1 = nullptr;             // SSSC (H) singleton state terms (sssc_tables_kernel)
+  PairEntry *PT = nullptr;           // SSSC (H,H) pair state terms
   double *pies = nullptr;            // SSSC (H)
   double *dpar = nullptr;            // device scalar block (DP_*), kernels read their scalars here
   double *h_dpar = nullptr;          // pinned mirror
@@ -324,7 +326,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
-                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,
+                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
@@ -478,6 +480,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->Psi, (size_t)H * H);
     ALLOC(c->GP, (size_t)H * H);
     ALLOC(c->DG, (size_t)H);
+    ALLOC(c->D1, (size_t)H);
+    ALLOC(c->PT, (size_t)H * H);
     ALLOC(c->Bm, (size_t)N * H);
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
@@ -708,6 +712,8 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   if (r) return r;
   interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP, H, c->mus,
                                                                       c->pilbar_v, c->DG);
+  sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
+                                                                     c->PT);
   HIP_TRY(hipGetLastError());
   c->B_valid = false;
   if (c->have_data) {
@@ -788,6 +794,8 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.yy = b.yy;
   a.GP = c->GP;
   a.DG = c->DG;
+  a.D1 = c->D1;
+  a.PT = c->PT;
   a.mus = c->mus;
   a.pil_bar = c->pilbar_v;
   a.s2inv = 0.0;
@@ -849,6 +857,8 @@ static int zero_lists(evoamd_ctx *c) {
   return 0;
 }
 
+#define MAIN_LPJ_LDS_MAX (40 * 1024)  // four 512-thread workgroups per CU
+
 template <int TAG>
 static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const bool need[3]) {
   const i64 total = a.N * (i64)a.C;
@@ -862,8 +872,23 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
   {
     SpanGuard g(c, kid_main);
     // 512-thread workgroups: measured 13.8-17.5 us without overflow and 20.0 us at 8 % overflow on
-    // the c2 shape (256: 13.0 / 24.3 us, 1024: 16.3 / 20.5 us)
-    sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1);
+    // the c2 shape (256: 13.0 / 24.3 us, 1024: 16.3 / 20.5 us).  The B rows of the workgroup's
+    // datapoints (and the per-latent table while it is small) are staged in LDS when they fit.
+    const int rows_cap = 512 / a.C + 2;
+    const int stage_dg = a.H <= 512;
+    const size_t lds = ((size_t)rows_cap * a.H + (stage_dg ? (size_t)4 * a.H : 0)) * sizeof(double);
+    const int grid = (int)cdiv(total, 512);
+    if (!a.shared && (a.H % 2) == 0 && lds <= MAIN_LPJ_LDS_MAX) {
+      switch (a.HW) {
+        case 1: sssc_main_lpj_kernel<TAG, 512, 1><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 2: sssc_main_lpj_kernel<TAG, 512, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 4: sssc_main_lpj_kernel<TAG, 512, 4><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 8: sssc_main_lpj_kernel<TAG, 512, 8><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 16: sssc_main_lpj_kernel<TAG, 512, 16><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        default: sssc_main_lpj_kernel<TAG, 512, 0><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+      }
+    } else
+      sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1);
     HIP_TRY(hipGetLastError());
   }
   if (need[0] || need[1] || need[2]) {
@@ -1443,6 +1468,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->acc + a.sz_sz, c->G, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar);
     interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP, H, c->mus, c->pilbar_v, c->DG);
+    sssc_tables_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1, c->PT);
     HIP_TRY(hipGetLastError());
     r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
     if (r) return r;

@@ -24,6 +24,16 @@
 #include "common.hpp"
 #include "kernels_mstep.hpp"
 
+// State terms that depend on the active set only (the reference memoises exactly these per state id
+// in `storage`, sssc.py:268-318): for |A| = 2, one 64-byte entry per latent pair.
+struct PairEntry {
+  double g01;                 // G[h0][h1]
+  double L;                   // pil_bar_h0 + pil_bar_h1 - log|det T_A| / 2
+  double l00, l01, l10, l11;  // Lam_A = T_A^-1 Psi_A  ( = M_s^-1 of sssc.py:300 )
+  double singular;            // != 0: det T_A == 0 (the reference would take pinv)
+  double pad;
+};
+
 struct SsscArgs {
   const u64 *states;     // (shared ? 1 : N) x C x HW
   const int *counts;     // (N) or nullptr
@@ -31,6 +41,8 @@ struct SsscArgs {
   const double *yy;      // (N)
   const double2 *GP;     // (H,H) interleaved {G_ij, Psi_ij}
   const double4 *DG;     // (H) per-latent {mu_h, pil_bar_h, G_hh, Psi_hh}: one 32-byte gather per active latent
+  const double4 *D1;     // (H) state terms of singletons {mu, pil_bar - log|T|/2, G_hh, Lam} (sssc_tables_kernel)
+  const PairEntry *PT;   // (H,H), h0 < h1 used: state terms of pairs
   const double *mus;     // (H)
   const double *pil_bar; // (H)
   double s2inv;          // filled in by the kernels from dpar[DP_S2INV]
@@ -220,7 +232,8 @@ __device__ __forceinline__ int list_fetch(const ListIn &li, const int *prefix, i
 // MODE 0: returns lpj in `val`.  MODE 1: also leaves kappa in `kap` and Lam = T^-1 Psi in `P`.
 template <int K, int MODE>
 __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u64 *sp, int (&idx)[K], int &k,
-                                               double &val, double (&kap)[K], double (&P)[K][K], bool &singular) {
+                                               double &val, double (&kap)[K], double (&P)[K][K], bool &singular,
+                                               const double *Bn, const double4 *DGt) {
 #pragma unroll
   for (int i = 0; i < K; i++) idx[i] = 0;
   k = 0;
@@ -237,13 +250,12 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
   double b[K], mu[K], v[K], wv[K];
   double G[K][K], T[K][K];
   double pb = 0.0;
-  const double *Bn = a.Bm + n * a.H;
 #pragma unroll
   for (int i = 0; i < K; i++) {
     const bool on = i < k;
     b[i] = on ? Bn[idx[i]] : 0.0;
     double4 d = make_double4(0.0, 0.0, 0.0, 1.0);  // padding: mu 0, pil_bar 0, G_ii 0, Psi_ii 1
-    if (on) d = a.DG[idx[i]];
+    if (on) d = DGt[idx[i]];
     mu[i] = d.x;
     pb += d.y;
     G[i][i] = d.z;
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
     int idx[K], k;
     double val = 0.0, kap[K], P[K][K];
     bool singular = false;
-    sssc_eval_regs<K, MODE>(a, n, sp, idx, k, val, kap, P, singular);
+    sssc_eval_regs<K, MODE>(a, n, sp, idx, k, val, kap, P, singular, a.Bm + n * a.H, a.DG);
     if (singular) atomicOr(a.err, 2);
     if (MODE == 0) {
       unsigned fl = 0;
@@ -386,6 +398,186 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
       sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
     }
   }
+}
+
+// block_append in two halves so that the global reservation (one returning atomic per workgroup,
+// 2-3 us under load) overlaps with the evaluation instead of stalling every wave at a barrier.
+// append_begin: LDS compaction, then thread 0 issues the atomic and parks the result in ctl[1].
+// append_end (every thread, after the evaluation): barrier, copy the compacted entries out.
+template <int BS>
+__device__ __forceinline__ void append_begin(const ListOut &lo, int shard, int value, bool over, int *buf, int *ctl) {
+  if (threadIdx.x == 0) ctl[0] = 0;
+  __syncthreads();
+  const u64 mask = __ballot(over);
+  if (mask != 0ull) {
+    const int lane = lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&ctl[0], __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (over) buf[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = ctl[0];
+    ctl[1] = n ? atomicAdd(&lo.counts[shard], n) : 0;
+  }
+}
+template <int BS>
+__device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl) {
+  __syncthreads();
+  const int n = ctl[0], start = ctl[1];
+  if (n == 0 || start < 0 || start + n > lo.cap) return;  // never write past the shard
+  const i64 dst = (i64)shard * lo.cap + start;
+  for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
+}
+
+// Main lpj pass in natural order.  A workgroup owns BS consecutive (n, state) pairs, i.e. at most
+// BS / C + 2 consecutive datapoints.  What bounds this pass is neither HBM nor arithmetic but the
+// dependent-latency chain of a workgroup times the number of workgroups a CU can hold (measured at
+// H = 512: ~10 us per workgroup generation, 2 workgroups per CU), so the kernel is built to keep
+// that chain short and the LDS footprint small:
+//   * the state words go straight to registers with 16-byte loads (HWT = words per state, a
+//     template parameter so the registers are indexed statically); per-lane 8-byte loads cost a
+//     full pass of the address coalescer per word;
+//   * the rows of B = Y W of the workgroup's datapoints (one contiguous chunk) and the singleton
+//     table D1 are staged in LDS by coalesced loads issued together with the state loads;
+//   * everything that depends on the active set only (log-determinant, Lam = T^-1 Psi) comes from
+//     the tables of sssc_tables_kernel: the per-pair work is two gathers and ~25 flops;
+//   * states with k > 2 are compacted into the overflow list; the workgroup's global reservation
+//     overlaps with the evaluation (append_begin / append_end).
+// Dynamic LDS: rows_cap x H doubles, then H double4 if `stage_dg`.  HWT == 0: any HW, word loop.
+template <int TAG, int BS, int HWT>
+__global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut lo, int rows_cap, int stage_dg) {
+  a.s2inv = a.dpar[DP_S2INV];
+  extern __shared__ double smem[];
+  __shared__ int ovf_buf[BS];
+  __shared__ int ovf_ctl[2];
+  double *Bs = smem;
+  double4 *DGs = (double4 *)(smem + (size_t)rows_cap * a.H);
+  const i64 total = a.N * (i64)a.C;
+  const i64 t0 = (i64)blockIdx.x * BS;
+  const i64 t = t0 + threadIdx.x;
+  const i64 n_first = t0 / a.C;
+  i64 n_last = (t0 + BS - 1) / a.C;
+  if (n_last > a.N - 1) n_last = a.N - 1;
+  const int rows = (int)(n_last - n_first + 1);  // <= rows_cap by construction (host)
+  bool live = t < total;
+  i64 n = 0;
+  int c = 0, ktot = 0;
+  constexpr int NW = HWT > 0 ? HWT : 1;
+  u64 w[NW];
+#pragma unroll
+  for (int i = 0; i < NW; i++) w[i] = 0;
+  const u64 *sp = nullptr;
+  if (live) {
+    // t = n C + c with n_first <= n <= n_first + rows: short search instead of a 32-bit division
+    const int off = (int)(t - n_first * a.C);  // < C + BS
+    int r = (int)(((float)off + 0.5f) * (1.0f / (float)a.C));
+    if (r * a.C > off) r--;
+    if ((r + 1) * a.C <= off) r++;
+    n = n_first + r;
+    c = off - r * a.C;
+    live = !(a.counts && c >= a.counts[n]);
+  }
+  if (live) {
+    sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
+    if (HWT == 1) {
+      w[0] = sp[0];
+    } else if (HWT > 1) {
+      const ulonglong2 *sp2 = (const ulonglong2 *)sp;  // HWT is even: 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < NW / 2; i++) {
+        const ulonglong2 v = sp2[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+      }
+    }
+    if (HWT > 0) {
+#pragma unroll
+      for (int i = 0; i < NW; i++) ktot += __popcll(w[i]);
+    } else {
+      for (int i = 0; i < a.HW; i++) ktot += __popcll(sp[i]);
+    }
+  }
+  {  // stage B rows n_first .. n_last (contiguous) and the singleton table
+    const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
+    double2 *dst = (double2 *)Bs;
+    const int n2 = rows * a.H / 2;
+    for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
+    if (stage_dg)
+      for (int i = threadIdx.x; i < a.H; i += BS) DGs[i] = a.D1[i];
+  }
+  const double yyn = live ? a.yy[n] : 0.0;
+  const bool over = live && ktot > 2;
+  const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
+  append_begin<BS>(lo, shard, (int)t, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
+  if (live && !over) {
+    // the (at most two) active latents, MSB-first, without divergent bit loops
+    int idx0 = 0, idx1 = 0, k = 0;
+    if (HWT > 0) {
+#pragma unroll
+      for (int i = 0; i < NW; i++) {
+        u64 bits = w[i];
+        const int cw = __popcll(bits);
+        const int h0 = __clzll((long long)bits);
+        const u64 rest = bits & ~(0x8000000000000000ull >> (h0 & 63));
+        const int h1 = __clzll((long long)rest);
+        if (cw >= 1) {
+          if (k == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+        }
+        if (cw == 2) idx1 = i * 64 + h1;
+        k += cw;
+      }
+    } else {
+      for (int i = 0; i < a.HW; i++) {
+        u64 bits = sp[i];
+        const int cw = __popcll(bits);
+        if (cw) {
+          const int h0 = __clzll((long long)bits);
+          if (k == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+          if (cw == 2) idx1 = i * 64 + __clzll((long long)(bits & ~(0x8000000000000000ull >> h0)));
+          k += cw;
+        }
+      }
+    }
+    const double *Bn = Bs + (size_t)(n - n_first) * a.H;
+    const double4 *D1t = stage_dg ? DGs : a.D1;
+    // identity padding makes the k = 2 expressions exact for k < 2
+    double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
+    double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
+    if (k >= 1) {
+      d0 = D1t[idx0];
+      b0 = Bn[idx0];
+      L = d0.y;
+      l00 = d0.w;
+    }
+    if (k == 2) {
+      d1 = D1t[idx1];
+      b1 = Bn[idx1];
+      const PairEntry pe = a.PT[(i64)idx0 * a.H + idx1];  // idx0 < idx1
+      g01 = pe.g01;
+      L = pe.L;
+      l00 = pe.l00;
+      l01 = pe.l01;
+      l10 = pe.l10;
+      l11 = pe.l11;
+      if (pe.singular != 0.0) atomicOr(a.err, 2);
+    }
+    const double s = a.s2inv;
+    const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
+    const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
+    const double rr = yyn - d0.x * (b0 + v0) - d1.x * (b1 + v1);
+    const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
+    const double val = L - 0.5 * s * (rr - s * quad);
+    unsigned fl = 0;
+    a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
+    if (fl) {
+      atomicOr(&a.flags[n], fl);
+      atomicOr(&a.err[1], 1);
+    }
+  }
+  append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
 }
 
 // Main statistics pass over the resident K^n (sssc.py:553-611): workgroups own whole datapoints
@@ -428,7 +620,7 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, Li
     int idx[K], k;
     double val = 0.0, kap[K], P[K][K];
     bool singular = false;
-    sssc_eval_regs<K, 1>(a, n, sp, idx, k, val, kap, P, singular);
+    sssc_eval_regs<K, 1>(a, n, sp, idx, k, val, kap, P, singular, a.Bm + n * a.H, a.DG);
     if (singular) atomicOr(a.err, 2);
     double *es = rows + (size_t)r * 3 * a.H, *ez = es + a.H, *ed = ez + a.H;
 #pragma unroll
@@ -691,6 +883,45 @@ __global__ __launch_bounds__(256) void set_diag_kernel(double *__restrict__ M, c
 }
 
 // GP[i][j] = {G[i][j], Psi[i][j]}
+// Tables of the state terms for |A| <= 2 (one thread per ordered pair h0 <= h1); with T = I + Psi_A
+// G_A / sigma2 (file header): L = sum pil_bar - log|det T| / 2 and Lam = T^-1 Psi_A.  Runs once per
+// Theta (H^2 / 2 tiny systems) instead of once per (datapoint, state) pair.
+__global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restrict__ G, const double *__restrict__ Psi,
+                                                          const double *__restrict__ mus,
+                                                          const double *__restrict__ pil_bar,
+                                                          const double *__restrict__ dpar, int H,
+                                                          double4 *__restrict__ D1, PairEntry *__restrict__ PT) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)H * H) return;
+  const int h0 = (int)(t / H), h1 = (int)(t - (i64)h0 * H);
+  const double s = dpar[DP_S2INV];
+  if (h0 == h1) {
+    const double g = G[t], p = Psi[t];
+    const double T = 1.0 + s * p * g;
+    D1[h0] = make_double4(mus[h0], pil_bar[h0] - 0.5 * log(fabs(T)), g, p / T);
+    return;
+  }
+  if (h0 > h1) return;
+  const double G00 = G[(i64)h0 * H + h0], G11 = G[(i64)h1 * H + h1], G01 = G[t], G10 = G[(i64)h1 * H + h0];
+  const double P00 = Psi[(i64)h0 * H + h0], P11 = Psi[(i64)h1 * H + h1], P01 = Psi[t], P10 = Psi[(i64)h1 * H + h0];
+  const double T00 = 1.0 + s * (P00 * G00 + P01 * G10);
+  const double T01 = s * (P00 * G01 + P01 * G11);
+  const double T10 = s * (P10 * G00 + P11 * G10);
+  const double T11 = 1.0 + s * (P10 * G01 + P11 * G11);
+  const double det = T00 * T11 - T01 * T10;
+  const double rdet = 1.0 / det;
+  PairEntry e;
+  e.g01 = G01;
+  e.L = pil_bar[h0] + pil_bar[h1] - 0.5 * log(fabs(det));
+  e.l00 = (T11 * P00 - T01 * P10) * rdet;
+  e.l01 = (T11 * P01 - T01 * P11) * rdet;
+  e.l10 = (T00 * P10 - T10 * P00) * rdet;
+  e.l11 = (T00 * P11 - T10 * P01) * rdet;
+  e.singular = (det == 0.0) ? 1.0 : 0.0;
+  e.pad = 0.0;
+  PT[t] = e;
+}
+
 __global__ __launch_bounds__(256) void interleave_gp_kernel(const double *__restrict__ G,
                                                             const double *__restrict__ Psi, i64 n,
                                                             double2 *__restrict__ GP, int H,

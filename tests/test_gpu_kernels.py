@@ -268,3 +268,32 @@ def test_inverse_singular_is_reported(engine):
     A[5, :] = 0.0  # a latent that never occurs: exactly singular moment matrix
     with pytest.raises(EvoAmdError):
         engine.inverse(A)
+
+
+@pytest.mark.parametrize("H,S", [(256, 40), (384, 24), (512, 200)])
+def test_lpj_sssc_wide_states(engine, H, S):
+    """ES3C lpj of resident states with several 64-bit words per state (the LDS-staged main kernel,
+    closed 2 x 2 form, plus the overflow levels) against the oracle's sssc.py:241-326 restatement."""
+    from oracle import evo_oracle as orc
+    rng = np.random.RandomState(H + S)
+    N, D = 12, 24
+    Y = rng.normal(size=(N, D))
+    A = rng.normal(size=(H, H)) * 0.05
+    theta = {"W": rng.normal(size=(D, H)) * 0.3, "pies": rng.uniform(0.05, 0.4, H), "mus": rng.normal(size=H),
+             "Psi": np.eye(H) + A + 0.3 * A.T, "sigma2": np.float64(0.7)}   # Psi deliberately not symmetric (Q2)
+    orc.sssc_precompute(theta, D)
+    ks = rng.choice([0, 1, 1, 2, 2, 2, 3, 5, 9], size=(N, S))
+    ss = np.zeros((N, S, H), dtype=bool)
+    for n in range(N):
+        for s in range(S):
+            ss[n, s, rng.choice(H, ks[n, s], replace=False)] = True
+    engine.configure("sssc", N, D, H, S, 0, 4)
+    engine.upload_data(Y)
+    engine.upload_states(ss)
+    engine.set_params_sssc(theta["W"], theta["pies"], theta["mus"], theta["Psi"], theta["sigma2"])
+    engine.lpj_resident()
+    got = engine.download_lpj()
+    want = np.empty((N, S))
+    for n in range(N):
+        want[n] = orc.sssc_lpj(theta, ss[n], Y[n], orc.new_counters(), {})
+    _close(got, want, LPJ_RTOL, "wide-state ES3C lpj")
