@@ -464,7 +464,7 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   const int rows = (int)(n_last - n_first + 1);  // <= rows_cap by construction (host)
   bool live = t < total;
   i64 n = 0;
-  int c = 0, ktot = 0;
+  int c = 0, ktot = 0, idx0 = 0, idx1 = 0;  // idx0 < idx1: the active latents when ktot <= 2
   constexpr int NW = HWT > 0 ? HWT : 1;
   u64 w[NW];
 #pragma unroll
@@ -493,11 +493,33 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
         w[2 * i + 1] = v.y;
       }
     }
+    // popcount and the (at most two) active latents, MSB-first, without divergent bit loops; done
+    // here so that the state words are dead before the barriers
     if (HWT > 0) {
 #pragma unroll
-      for (int i = 0; i < NW; i++) ktot += __popcll(w[i]);
+      for (int i = 0; i < NW; i++) {
+        const u64 bits = w[i];
+        const int cw = __popcll(bits);
+        const int h0 = __clzll((long long)bits);
+        const u64 rest = bits & ~(0x8000000000000000ull >> (h0 & 63));
+        const int h1 = __clzll((long long)rest);
+        if (cw >= 1) {
+          if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+        }
+        if (cw >= 2 && ktot == 0) idx1 = i * 64 + h1;
+        ktot += cw;
+      }
     } else {
-      for (int i = 0; i < a.HW; i++) ktot += __popcll(sp[i]);
+      for (int i = 0; i < a.HW; i++) {
+        const u64 bits = sp[i];
+        const int cw = __popcll(bits);
+        if (cw) {
+          const int h0 = __clzll((long long)bits);
+          if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+          if (cw >= 2 && ktot == 0) idx1 = i * 64 + __clzll((long long)(bits & ~(0x8000000000000000ull >> h0)));
+          ktot += cw;
+        }
+      }
     }
   }
   {  // stage B rows n_first .. n_last (contiguous) and the singleton table
@@ -513,34 +535,7 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
   append_begin<BS>(lo, shard, (int)t, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
   if (live && !over) {
-    // the (at most two) active latents, MSB-first, without divergent bit loops
-    int idx0 = 0, idx1 = 0, k = 0;
-    if (HWT > 0) {
-#pragma unroll
-      for (int i = 0; i < NW; i++) {
-        u64 bits = w[i];
-        const int cw = __popcll(bits);
-        const int h0 = __clzll((long long)bits);
-        const u64 rest = bits & ~(0x8000000000000000ull >> (h0 & 63));
-        const int h1 = __clzll((long long)rest);
-        if (cw >= 1) {
-          if (k == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
-        }
-        if (cw == 2) idx1 = i * 64 + h1;
-        k += cw;
-      }
-    } else {
-      for (int i = 0; i < a.HW; i++) {
-        u64 bits = sp[i];
-        const int cw = __popcll(bits);
-        if (cw) {
-          const int h0 = __clzll((long long)bits);
-          if (k == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
-          if (cw == 2) idx1 = i * 64 + __clzll((long long)(bits & ~(0x8000000000000000ull >> h0)));
-          k += cw;
-        }
-      }
-    }
+    const int k = ktot;
     const double *Bn = Bs + (size_t)(n - n_first) * a.H;
     const double4 *D1t = stage_dg ? DGs : a.D1;
     // identity padding makes the k = 2 expressions exact for k < 2
