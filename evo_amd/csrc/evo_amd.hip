@@ -1272,7 +1272,15 @@ static int stats_compute(evoamd_ctx *c) {
       if (npb > lim) npb = lim < 1 ? 1 : lim;
       const size_t lds = (size_t)npb * 3 * H * sizeof(double);
       SpanGuard g(c, KID_STATS);
-      sssc_stats_kernel<2><<<cdiv(N, npb), 256, lds, c->stream>>>(sa, npb, o1);
+      const int sgrid = (int)cdiv(N, npb);
+      switch (c->HW) {
+        case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+      }
       HIP_TRY(hipGetLastError());
     }
     if (need[0] || need[1] || need[2]) {

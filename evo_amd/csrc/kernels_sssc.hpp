@@ -575,13 +575,62 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
 }
 
+// Loads the HWT state words of one state with 16-byte loads and returns popcount and the first two
+// active latents (MSB-first); HWT == 0: runtime word loop.  Shared by the main lpj and statistics
+// kernels.
+template <int HWT>
+__device__ __forceinline__ void load_state_k2(const u64 *sp, int HW, int &ktot, int &idx0, int &idx1) {
+  constexpr int NW = HWT > 0 ? HWT : 1;
+  ktot = idx0 = idx1 = 0;
+  if (HWT > 0) {
+    u64 w[NW];
+    if (HWT == 1) {
+      w[0] = sp[0];
+    } else {
+      const ulonglong2 *sp2 = (const ulonglong2 *)sp;  // HWT is even: 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < NW / 2; i++) {
+        const ulonglong2 v = sp2[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const u64 bits = w[i];
+      const int cw = __popcll(bits);
+      const int h0 = __clzll((long long)bits);
+      const u64 rest = bits & ~(0x8000000000000000ull >> (h0 & 63));
+      const int h1 = __clzll((long long)rest);
+      if (cw >= 1) {
+        if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+      }
+      if (cw >= 2 && ktot == 0) idx1 = i * 64 + h1;
+      ktot += cw;
+    }
+  } else {
+    for (int i = 0; i < HW; i++) {
+      const u64 bits = sp[i];
+      const int cw = __popcll(bits);
+      if (cw) {
+        const int h0 = __clzll((long long)bits);
+        if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
+        if (cw >= 2 && ktot == 0) idx1 = i * 64 + __clzll((long long)(bits & ~(0x8000000000000000ull >> h0)));
+        ktot += cw;
+      }
+    }
+  }
+}
+
 // Main statistics pass over the resident K^n (sssc.py:553-611): workgroups own whole datapoints
 // (npb = max(1, 256 / S) per workgroup), so the first moments xpt_s / xpt_sz of a datapoint are
 // accumulated in LDS and written as complete rows of Es / Ez with plain coalesced stores -- no
 // memset, no global atomics; only the H x H second moments use global f64 atomics.  States with
-// more than K active latents go to list_out and are added by the overflow kernels afterwards
-// (stream order guarantees their atomics land after the row stores).
-template <int K>
+// more than 2 active latents go to list_out and are added by the overflow kernels afterwards
+// (stream order guarantees their atomics land after the row stores).  kappa and Lam of the states
+// with |A| <= 2 come from the same tables as the lpj pass (no elimination per pair), the state
+// words are read with 16-byte loads, and the overflow reservation overlaps with the arithmetic.
+template <int HWT>
 __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, ListOut lo) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double rows[];  // npb x 3 x H : xpt_s | xpt_sz | diag(xpt_szsz)
@@ -590,45 +639,68 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, Li
   const i64 n0 = (i64)blockIdx.x * npb;
   const int nrows = (int)((n0 + npb <= a.N) ? npb : (a.N - n0));
   for (int i = threadIdx.x; i < nrows * 3 * a.H; i += 256) rows[i] = 0.0;
-  __syncthreads();
   const int work = nrows * a.C;
+  const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
   for (int t0 = 0; t0 < work; t0 += 256) {
     const int t = t0 + threadIdx.x;
     const bool live = t < work;
-    int r = 0, c = 0, ktot = 0;
+    int r = 0, c = 0, k = 0, idx0 = 0, idx1 = 0;
     i64 n = n0;
-    const u64 *sp = nullptr;
+    double l = 0.0, rmax = 0.0, rsum = 1.0;
     if (live) {
-      r = t / a.C;
+      r = (int)(((float)t + 0.5f) * (1.0f / (float)a.C));  // t < 2^20: float quotient, then exact
+      if (r * a.C > t) r--;
+      if ((r + 1) * a.C <= t) r++;
       c = t - r * a.C;
       n = n0 + r;
-      sp = a.states + (n * (i64)a.C + c) * a.HW;
-      for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+      load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k, idx0, idx1);
+      l = a.lpj_in[n * a.ldo + a.col0 + c];
+      rmax = a.rowmax[n];
+      rsum = a.rowsum[n];
     }
-    const bool over = live && ktot > K;
-    block_append<256>(lo, (int)(blockIdx.x & (LIST_SHARDS - 1)), (int)(n * a.C + c), over, ovf_buf, ovf_ctl);
-    if (!live || over) continue;
-    const double l = a.lpj_in[n * a.ldo + a.col0 + c];
-    const double q = exp(l + (0.0 - a.rowmax[n]));
-    if (q == 0.0) continue;
-    const double qn = q / (a.rowsum[n] + EVO_F64_TINY);
-    int idx[K], k;
-    double val = 0.0, kap[K], P[K][K];
-    bool singular = false;
-    sssc_eval_regs<K, 1>(a, n, sp, idx, k, val, kap, P, singular, a.Bm + n * a.H, a.DG);
-    if (singular) atomicOr(a.err, 2);
-    double *es = rows + (size_t)r * 3 * a.H, *ez = es + a.H, *ed = ez + a.H;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      if (i < k) {
-        unsafeAtomicAdd(&es[idx[i]], qn);
-        unsafeAtomicAdd(&ez[idx[i]], qn * kap[i]);
-        unsafeAtomicAdd(&ed[idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
+    const bool over = live && k > 2;
+    append_begin<256>(lo, shard, (int)(n * a.C + c), over, ovf_buf, ovf_ctl);  // first barrier also covers the row zeroing
+    if (live && !over) {
+      const double q = exp(l + (0.0 - rmax));
+      if (q != 0.0 && k > 0) {
+        const double qn = q / (rsum + EVO_F64_TINY);
+        const double *Bn = a.Bm + n * a.H;
+        double4 d0 = a.D1[idx0], d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
+        double b0 = Bn[idx0], b1 = 0.0, g01 = 0.0, l00 = d0.w, l01 = 0.0, l10 = 0.0, l11 = 0.0;
+        if (k == 2) {
+          d1 = a.D1[idx1];
+          b1 = Bn[idx1];
+          const PairEntry pe = a.PT[(i64)idx0 * a.H + idx1];
+          g01 = pe.g01;
+          l00 = pe.l00;
+          l01 = pe.l01;
+          l10 = pe.l10;
+          l11 = pe.l11;
+          if (pe.singular != 0.0) atomicOr(a.err, 2);
+        }
+        const double s = a.s2inv;
+        const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
+        const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
+        const double k0 = s * (l00 * v0 + l01 * v1) + d0.x;  // kappa = Lam v / sigma2 + mu  (sssc.py:574-575)
+        const double k1 = s * (l10 * v0 + l11 * v1) + d1.x;
+        double *es = rows + (size_t)r * 3 * a.H, *ez = es + a.H, *ed = ez + a.H;
+        unsafeAtomicAdd(&es[idx0], qn);
+        unsafeAtomicAdd(&ez[idx0], qn * k0);
+        unsafeAtomicAdd(&ed[idx0], qn * (l00 + k0 * k0));
+        if (k == 2) {
+          unsafeAtomicAdd(&es[idx1], qn);
+          unsafeAtomicAdd(&ez[idx1], qn * k1);
+          unsafeAtomicAdd(&ed[idx1], qn * (l11 + k1 * k1));
+          const i64 o01 = (i64)idx0 * a.H + idx1, o10 = (i64)idx1 * a.H + idx0;
+          unsafeAtomicAdd(&a.xss[o01], qn);  // strict upper triangle only (finish_sym_kernel mirrors)
+          unsafeAtomicAdd(&a.xszsz[o01], qn * (l01 + k0 * k1));
+          unsafeAtomicAdd(&a.xszsz[o10], qn * (l10 + k1 * k0));
+        }
       }
     }
-    sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
+    append_end<256>(lo, shard, ovf_buf, ovf_ctl);
+    __syncthreads();  // ovf_ctl / ovf_buf are reused by the next chunk
   }
-  __syncthreads();
   for (int i = threadIdx.x; i < nrows * a.H; i += 256) {
     const int r = i / a.H, h = i - r * a.H;
     a.Es[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + h];
