@@ -590,26 +590,52 @@ extern "C" int evoamd_download_lpj(evoamd_ctx *c, double *lpj) {
 // ---------------------------------------------------------------------------------------
 // dense helpers
 // ---------------------------------------------------------------------------------------
+// 16-byte row pieces need an even leading dimension and a 16-byte aligned base
+static bool gemm_vec_ok(const double *p, int ld) { return (ld % 2) == 0 && ((uintptr_t)p % 16) == 0; }
+
+static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                               i64 M, int Nc, int K) {
+  const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
+  const int rows_per_xcd = (gy + 7) / 8;
+  const unsigned grid = (unsigned)(8 * rows_per_xcd * gx);
+  if (gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (K % 2) == 0 && (Nc % 2) == 0 && K >= 2 && Nc >= 2 && M >= 1)
+    gemm_nn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, gx, gy, rows_per_xcd);
+  else
+    gemm_nn_f64<false><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, gx, gy, rows_per_xcd);
+}
+
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
-                          int M, int Nc, i64 K, bool deterministic = false) {
-  const unsigned gx = cdiv(Nc, GEMM_BN), gy = cdiv(M, GEMM_BM);
-  // no prefetch in the tile loop yet, so latency is hidden by parallelism: aim for >= 512
-  // workgroups, at least 64 rows of K per split
-  i64 splits = 1;
+                          int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1) {
+  // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of 64):
+  // only its upper tiles are computed, the rest is mirrored
+  const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
   const i64 tiles = (i64)gx * gy;
+  // enough workgroups to fill the chip (>= 512), at least 64 rows of K per chunk; the kernel
+  // spreads the K chunks over the 8 XCDs, so a split uses a multiple of 8 chunks
+  i64 splits = 1;
   if (K >= 128 && !deterministic) {  // split-K sums with atomics: order (hence last bits) varies
     splits = (512 + tiles - 1) / tiles;
     const i64 maxs = (K + 63) / 64;
     if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
+    if (splits > 1) splits = ((splits + 7) / 8) * 8;
   }
-  i64 kps = (K + splits - 1) / splits;
-  kps = ((kps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-  splits = (K + kps - 1) / kps;
-  if (splits > 1) HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
+  const int split = splits > 1;
+  i64 kps = K;
+  if (split) {
+    kps = (K + splits - 1) / splits;
+    kps = ((kps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+    HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
+  }
+  const unsigned grid = (unsigned)(tiles * (split ? splits : 1));
+  const bool vec = gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (M % 2) == 0 && (Nc % 2) == 0 && M >= 2 && Nc >= 2;
   SpanGuard g(c, KID_GEMM);
-  gemm_tn_f64<<<dim3(gx, gy, (unsigned)splits), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps);
+  if (vec)
+    gemm_tn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
+  else
+    gemm_tn_f64<false><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
+  if (sym_row0 >= 0)
+    mirror_lower_kernel<<<cdiv((i64)Nc * Nc, 256), 256, 0, c->stream>>>(C + (size_t)sym_row0 * ldc, Nc, ldc);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -617,7 +643,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
 static int launch_gemm_nn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                           i64 M, int Nc, int K) {
   SpanGuard g(c, KID_GEMM);
-  gemm_nn_f64<<<dim3(cdiv(Nc, GEMM_BN), cdiv(M, GEMM_BM)), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K);
+  launch_gemm_nn_raw(c, A, lda, B, ldb, C, ldc, M, Nc, K);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1319,7 +1345,9 @@ static int stats_compute(evoamd_ctx *c) {
       HIP_TRY(hipGetLastError());
     }
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
-    r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N);
+    // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
+    r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
+                       ((D + H) % GEMM_BM) == 0 ? D + H : -1);
     if (r) return r;
   }
   {
@@ -1464,8 +1492,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       r = launch_inverse(c, c->tmpB, nullptr, H, force_pivot);
     if (r) return r;
     if (learn & L_W)
-      gemm_nn_f64<<<dim3(cdiv(H, GEMM_BN), cdiv(D, GEMM_BM)), 256, 0, c->stream>>>(c->acc + a.sWp, H, c->tmpA, H, c->W,
-                                                                                    H, D, H, H);
+      launch_gemm_nn_raw(c, c->acc + a.sWp, H, c->tmpA, H, c->W, H, D, H, H);
     if (learn & L_PSI)
       sssc_psi_finish_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->tmpC, c->tmpB, H, c->Psi);
     else
@@ -1486,8 +1513,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       r = launch_inverse(c, c->tmpA, nullptr, H, force_pivot);
       if (r) return r;
-      gemm_nn_f64<<<dim3(cdiv(D, GEMM_BN), cdiv(H, GEMM_BM)), 256, 0, c->stream>>>(c->tmpA, H, c->acc + a.Wp, D, c->Wt,
-                                                                                    D, H, D, H);
+      launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H);
       transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
     }
     bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar);

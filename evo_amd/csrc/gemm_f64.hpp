@@ -28,15 +28,32 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // round trip (a 4-workgroup G = W^T W launch took 28 us for 16 slabs).
 //
 // C (M x Nc) (+)= A^T B with A: K x M (lda), B: K x Nc (ldb).  gridDim.z splits K; with more than
-// one split the tile is accumulated with hardware f64 atomics into a zeroed C.
+// one split the tile is accumulated with hardware f64 atomics into a zeroed C.  1-D grid of
+// 8 * tiles * (splits / 8) workgroups (see the decode below).
+// VEC: rows of A and B are read as 16-byte pieces with consecutive lanes on consecutive pieces
+// (needs even lda / ldb, 16-byte aligned bases).  With 8-byte loads the kernel issued 8 load
+// instructions per thread and K slab and ran at ~50 % of the MFMA rate: the address coalescer, not
+// the matrix cores, was the busy unit.
+template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A, int lda,
                                                    const double *__restrict__ B, int ldb,
                                                    double *__restrict__ C, int ldc, int M, int Nc,
-                                                   i64 K, i64 k_per_split) {
+                                                   i64 K, i64 k_per_split, int gx, int gy, int split, int sym_row0) {
   __shared__ double As[2][GEMM_BK][GEMM_LDS];
   __shared__ double Bs[2][GEMM_BK][GEMM_LDS];
-  const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
-  const i64 kbeg = (i64)blockIdx.z * k_per_split;
+  // XCD-aware decode of the 1-D grid (workgroup id mod 8 = XCD on gfx950): all output tiles of one
+  // K chunk run on the same XCD, so its slice of A and B is fetched into that XCD's L2 once and
+  // shared by the tiles; with the natural (x, y, z) order every XCD streamed the whole of A.
+  // splits is a multiple of 8 (host); chunk z = xcd + 8 (j / tiles), tile = j % tiles.
+  const int tiles = gx * gy;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int zc = split ? xcd + 8 * (jj / tiles) : 0;
+  const int tile = split ? jj % tiles : (int)blockIdx.x;
+  const int m0 = (tile / gx) * GEMM_BM, n0 = (tile % gx) * GEMM_BN;
+  // rows >= sym_row0 of C are a symmetric Nc x Nc block (X^T X): its strictly lower tiles are left
+  // to mirror_lower_kernel
+  if (sym_row0 >= 0 && m0 >= sym_row0 && m0 - sym_row0 > n0) return;  // uniform
+  const i64 kbeg = (i64)zc * k_per_split;
   const i64 kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -45,34 +62,62 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  const int lr = t >> 4, lc = (t & 15) * 4;  // loader: row of the K slab, 4 consecutive columns
-  double ra[4], rb[4];
-  auto fetch = [&](i64 k0) {
-    const i64 kr = k0 + lr;
-    const bool kin = kr < kend;
+  // loader, scalar form: row lr of the K slab, 4 consecutive columns from lc.  VEC form: piece
+  // p = t + 256 i (i = 0, 1) of the 16 x 32 grid of 16-byte pieces: row p >> 5, columns 2 (p & 31) ..
+  const int lr = t >> 4, lc = (t & 15) * 4;
+  // Register prefetch three K slabs deep: one slab of MFMAs is 16 x 64 = 1024 matrix-core cycles
+  // per wave, a loaded HBM round trip is several thousand, so a one-slab lookahead left the waves
+  // waiting at the LDS hand-over (measured 42 of 77 TFLOP/s).
+  double ra[3][4], rb[3][4];
+  auto fetch = [&](double(&qa)[4], double(&qb)[4], i64 k0) {
+    if (VEC) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int m = m0 + lc + q, n = n0 + lc + q;
-      ra[q] = (kin && m < M) ? A[kr * lda + m] : 0.0;
-      rb[q] = (kin && n < Nc) ? B[kr * ldb + n] : 0.0;
+      for (int i = 0; i < 2; i++) {
+        const int p = t + 256 * i;
+        const i64 kr = k0 + (p >> 5);
+        const int cc = (p & 31) * 2;
+        const bool kin = kr < kend;
+        // branch-free: always load from a clamped (valid, aligned) address, then zero what lies
+        // outside; M and Nc are even in the VEC instantiation, so a piece is inside or outside as a whole
+        const i64 krc = kin ? kr : kend - 1;
+        const int ma = m0 + cc, nb = n0 + cc;
+        double2 va = *(const double2 *)(A + krc * lda + (ma < M ? ma : M - 2));
+        double2 vb = *(const double2 *)(B + krc * ldb + (nb < Nc ? nb : Nc - 2));
+        if (!(kin && ma < M)) va = make_double2(0.0, 0.0);
+        if (!(kin && nb < Nc)) vb = make_double2(0.0, 0.0);
+        qa[2 * i] = va.x;
+        qa[2 * i + 1] = va.y;
+        qb[2 * i] = vb.x;
+        qb[2 * i + 1] = vb.y;
+      }
+    } else {
+      const i64 kr = k0 + lr;
+      const bool kin = kr < kend;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int m = m0 + lc + q, n = n0 + lc + q;
+        qa[q] = (kin && m < M) ? A[kr * lda + m] : 0.0;
+        qb[q] = (kin && n < Nc) ? B[kr * ldb + n] : 0.0;
+      }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const double(&qa)[4], const double(&qb)[4], int buf) {
+    if (VEC) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      As[buf][lr][lc + q] = ra[q];
-      Bs[buf][lr][lc + q] = rb[q];
+      for (int i = 0; i < 2; i++) {
+        const int p = t + 256 * i, r = p >> 5, cc = (p & 31) * 2;
+        *(double2 *)&As[buf][r][cc] = make_double2(qa[2 * i], qa[2 * i + 1]);
+        *(double2 *)&Bs[buf][r][cc] = make_double2(qb[2 * i], qb[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        As[buf][lr][lc + q] = qa[q];
+        Bs[buf][lr][lc + q] = qb[q];
+      }
     }
   };
-  if (kbeg < kend) {
-    fetch(kbeg);
-    stash(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (i64 k0 = kbeg; k0 < kend; k0 += GEMM_BK, buf ^= 1) {
-    const bool more = k0 + GEMM_BK < kend;
-    if (more) fetch(k0 + GEMM_BK);  // in flight during the MFMAs below
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
       const int kl = kk * 4 + (lane >> 4);
@@ -87,10 +132,30 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
         for (int j = 0; j < 2; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
-    __syncthreads();
+  };
+  const i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+  if (nslab > 0) {
+    fetch(ra[0], rb[0], kbeg);
+    stash(ra[0], rb[0], 0);
+    if (nslab > 1) fetch(ra[0], rb[0], kbeg + GEMM_BK);
+    if (nslab > 2) fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+    if (nslab > 3) fetch(ra[2], rb[2], kbeg + 3 * GEMM_BK);
   }
-  const bool split = gridDim.z > 1;
+  __syncthreads();
+  // slab s is in LDS buffer s & 1; slab s + 1 + j waits in register set j (rotating)
+  for (i64 s0 = 0; s0 < nslab; s0 += 3) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const i64 sl = s0 + j;
+      if (sl < nslab) {  // uniform
+        const int buf = (int)(sl & 1);
+        compute(buf);
+        if (sl + 1 < nslab) stash(ra[j], rb[j], buf ^ 1);                                   // slab sl + 1
+        if (sl + 4 < nslab) fetch(ra[j], rb[j], kbeg + (sl + 4) * GEMM_BK);                 // refill the set
+        __syncthreads();
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -109,14 +174,20 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
 }
 
 // C (M x Nc) = A B with A: M x K (lda) row-major, B: K x Nc (ldb).  No K split (K = D or H is small).
+template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A, int lda,
                                                    const double *__restrict__ B, int ldb,
                                                    double *__restrict__ C, int ldc, i64 M, int Nc,
-                                                   int K) {
+                                                   int K, int gx, int gy, int rows_per_xcd) {
   __shared__ double As[2][GEMM_BK][GEMM_LDS];
   __shared__ double Bs[2][GEMM_BK][GEMM_LDS];
-  const i64 m0 = (i64)blockIdx.y * GEMM_BM;
-  const int n0 = blockIdx.x * GEMM_BN;
+  // XCD-aware decode: XCD x owns a contiguous band of row tiles (all column tiles of a row tile run
+  // on the same XCD, so the rows of A are fetched into one L2 only)
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const i64 ry = (i64)xcd * rows_per_xcd + jj / gx;
+  if (jj / gx >= rows_per_xcd || ry >= gy) return;  // uniform: padding of the 1-D grid
+  const i64 m0 = ry * GEMM_BM;
+  const int n0 = (jj % gx) * GEMM_BN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   v4f64 acc[2][2];
@@ -129,19 +200,45 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
   double ra[4], rb[4];
   auto fetch = [&](int k0) {
     const i64 m = m0 + am;
-    const int kb = k0 + br;
+    if (VEC) {
+      // A: 4 consecutive k of row m as two 16-byte pieces; B: pieces p = t + 256 i of the 16 x 32 grid
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int k = k0 + ak + q, n = n0 + bc + q;
-      ra[q] = (m < M && k < K) ? A[m * lda + k] : 0.0;
-      rb[q] = (kb < K && n < Nc) ? B[(i64)kb * ldb + n] : 0.0;
+      for (int i = 0; i < 2; i++) {
+        const int k = k0 + ak + 2 * i;
+        // branch-free clamped loads (K and Nc are even in the VEC instantiation)
+        const i64 mc = m < M ? m : M - 1;
+        double2 va = *(const double2 *)(A + mc * lda + (k < K ? k : K - 2));
+        if (!(m < M && k < K)) va = make_double2(0.0, 0.0);
+        ra[2 * i] = va.x;
+        ra[2 * i + 1] = va.y;
+        const int p = t + 256 * i, kb = k0 + (p >> 5), cc = (p & 31) * 2, nb = n0 + cc;
+        double2 vb = *(const double2 *)(B + (i64)(kb < K ? kb : K - 1) * ldb + (nb < Nc ? nb : Nc - 2));
+        if (!(kb < K && nb < Nc)) vb = make_double2(0.0, 0.0);
+        rb[2 * i] = vb.x;
+        rb[2 * i + 1] = vb.y;
+      }
+    } else {
+      const int kb = k0 + br;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int k = k0 + ak + q, n = n0 + bc + q;
+        ra[q] = (m < M && k < K) ? A[m * lda + k] : 0.0;
+        rb[q] = (kb < K && n < Nc) ? B[(i64)kb * ldb + n] : 0.0;
+      }
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      As[buf][ak + q][am] = ra[q];
-      Bs[buf][br][bc + q] = rb[q];
+    for (int q = 0; q < 4; q++) As[buf][ak + q][am] = ra[q];
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int p = t + 256 * i, r = p >> 5, cc = (p & 31) * 2;
+        *(double2 *)&Bs[buf][r][cc] = make_double2(rb[2 * i], rb[2 * i + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) Bs[buf][br][bc + q] = rb[q];
     }
   };
   if (K > 0) {
@@ -180,6 +277,15 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
         int col = n0 + wn * 32 + j * 16 + (lane & 15);
         if (row < M && col < Nc) C[row * ldc + col] = acc[i][j][r];
       }
+}
+
+// S (n x n, ld) <- upper triangle mirrored into the lower one (the SYRK-style launch above computed
+// only tiles with row tile <= column tile; inside diagonal tiles both halves exist already).
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ S, int n, int ld) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)n * n) return;
+  const int i = (int)(t / n), j = (int)(t - (i64)i * n);
+  if ((i / GEMM_BM) > (j / GEMM_BN)) S[(i64)i * ld + j] = S[(i64)j * ld + i];
 }
 
 // out[c] += sum_r X[r][c]   (column sums of an (R x Cn) row-major matrix; optional square).

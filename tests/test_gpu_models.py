@@ -257,3 +257,45 @@ def test_bench_path_with_rccl_communicator():
         finally:
             eng.close()
     np.testing.assert_allclose(res[1], res[0], rtol=1e-9)
+
+
+@pytest.mark.parametrize("D,H,S,N,device_mstep", [(64, 64, 20, 300, False), (64, 64, 20, 300, True),
+                                                    (192, 128, 24, 160, True)])
+def test_es3c_tile_aligned_shapes_against_oracle(engine, D, H, S, N, device_mstep):
+    """ES3C EM steps at shapes whose accumulator blocks are 64-aligned (D + H a multiple of 64), which
+    switches the Ez^T Ez contraction to its upper-tiles-plus-mirror form and the GEMM loaders to their
+    16-byte form; the golden fixtures have ragged shapes and never reach those paths.  Oracle =
+    oracle.evo_oracle.sssc_step (sssc.py:407-813) on the same seeds."""
+    from oracle import evo_oracle as orc
+    from evo_amd.models import SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(D + H)
+    gen = {"W": rng.normal(size=(D, H)), "pies": np.full(H, 2.0 / H), "mus": rng.normal(size=H) + 2.0,
+           "Psi": np.eye(H), "sigma2": np.float64(0.5)}
+    np.random.seed(5)
+    Y = orc.sssc_generate(gen, N)[0]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    np.random.seed(6)
+    theta0 = orc.sssc_standard_init(Y, H)
+    np.random.seed(7)
+    suff_a = init_states(N, S, H, "fit", "randflip", 6, 2, 1)
+    np.random.seed(7)
+    suff_o = orc.init_states(N, S, H, "fit", "randflip", 6, 2, 1)
+    assert np.array_equal(suff_a["ss"], suff_o["ss"])
+    model = SSSC(D, H, S, engine=engine, device_mstep=device_mstep)
+    th_a = {k: np.array(v) for k, v in theta0.items()}
+    th_o = {k: np.array(v) for k, v in theta0.items()}
+    for k in ("sigma2",):
+        th_a[k], th_o[k] = np.float64(th_a[k]), np.float64(th_o[k])
+    for t in range(2):
+        np.random.seed(100 + t)
+        Fa, nua, nsa, th_a = model.step(th_a, suff_a, my_data)
+        np.random.seed(100 + t)
+        Fo, nuo, nso, th_o, _ = orc.sssc_step(th_o, suff_o, Y)
+        np.testing.assert_allclose(Fa, Fo, rtol=1e-9, err_msg="F step %d" % t)
+        assert (nua, nsa) == (nuo, nso)
+        assert np.array_equal(suff_a["ss"], suff_o["ss"]), "K^n differs at step %d" % t
+        for k in ("W", "pies", "mus", "Psi", "sigma2"):
+            ref = np.asarray(th_o[k])
+            np.testing.assert_allclose(th_a[k], ref, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg="%s step %d" % (k, t))

@@ -2,8 +2,9 @@
 usage: python tools/gaps.py <dir with *_kernel_trace.csv> [anchor kernel substring]"""
 import csv, glob, sys
 d = sys.argv[1]
-anchor = sys.argv[2] if len(sys.argv) > 2 else "lpj_gram_kernel<0>|small_kernel<2, 0, 0"
-f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
+anchor = sys.argv[2] if len(sys.argv) > 2 else "lpj_gram_kernel<0>|sssc_main_lpj_kernel<0"
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if any(a in r["Kernel_Name"] for a in anchor.split("|"))]
