@@ -125,7 +125,7 @@ def cpu_baseline(cfg, budget_s=20.0):
     cores = min(os.cpu_count() or 1, 16)
     # probe one datapoint-step cost on one core, then size the sample
     t_probe = _cpu_worker((cfg["algo"], cfg["D"], cfg["H"], cfg["S"], 2, 99, 1)) / 2
-    per_core = int(max(2, min(64, (budget_s / 2.0) / max(t_probe, 1e-4))))
+    per_core = int(max(2, min(2048, (budget_s / 2.0) / max(t_probe, 1e-4))))  # two timed steps per worker
     os.environ["OPENBLAS_NUM_THREADS"] = "1"
     ctx = mp.get_context("spawn")
     jobs = [(cfg["algo"], cfg["D"], cfg["H"], cfg["S"], per_core, 1234 + i, 2) for i in range(cores)]
