@@ -784,6 +784,33 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     const i64 total = b.N * (i64)b.C;
     unsigned grid = cdiv(total, 256);
     SpanGuard g(c, b.kid);
+    // second-generation kernel (register state words, B rows in LDS) when the shape allows it
+    const int rows_cap = 512 / b.C + 2;
+    const size_t lds = (size_t)rows_cap * c->H * sizeof(double);
+    const bool hw_ok = c->HW == 1 || c->HW == 2 || c->HW == 4 || c->HW == 8 || c->HW == 16;
+    if (!b.shared && hw_ok && (c->H % 2) == 0 && lds <= 40 * 1024) {
+      const unsigned g2 = cdiv(total, 512);
+#define GRAM2(TAG, HWT)                                                                                      \
+  bsc_lpj_gram2_kernel<TAG, HWT><<<g2, 512, lds, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, c->H, \
+                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
+#define GRAM2_HW(TAG)                    \
+  switch (c->HW) {                       \
+    case 1: GRAM2(TAG, 1); break;        \
+    case 2: GRAM2(TAG, 2); break;        \
+    case 4: GRAM2(TAG, 4); break;        \
+    case 8: GRAM2(TAG, 8); break;        \
+    default: GRAM2(TAG, 16); break;      \
+  }
+      if (b.tag == 0) {
+        GRAM2_HW(0)
+      } else {
+        GRAM2_HW(1)
+      }
+#undef GRAM2_HW
+#undef GRAM2
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
 #define GRAM_LAUNCH(TAG)                                                                                       \
   bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
                                                         c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)

@@ -155,6 +155,121 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
   }
 }
 
+// Gram-form lpj, second generation (same expression, same summation order over the latents as
+// bsc_lpj_gram_kernel): a workgroup owns 512 consecutive (n, state) pairs; the HWT state words of a
+// pair arrive in registers through 16-byte loads (a lane reading its words 8 bytes at a time costs
+// one address-coalescer pass per word: 16 passes per wave at H = 1024), the rows of B = Y W of the
+// workgroup's <= 512 / C + 2 datapoints (one contiguous chunk) are staged in LDS by coalesced loads
+// issued together with them, and the first KR active latents are kept in registers so that the
+// O(k^2) gathers from G issue back to back.  States with more than KR active latents (rare at the
+// sparsities EVO works at) take the word-loop path of the first kernel.  Dynamic LDS: rows_cap x H.
+#define BSC_KR 4
+template <int TAG, int HWT>
+__global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
+    const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
+    const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int H, int HW,
+    const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
+    int *__restrict__ err) {
+  extern __shared__ double Bs[];
+  const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
+  const i64 total = N * (i64)C;
+  const i64 t0 = (i64)blockIdx.x * 512;
+  const i64 t = t0 + threadIdx.x;
+  const i64 n_first = t0 / C;
+  i64 n_last = (t0 + 511) / C;
+  if (n_last > N - 1) n_last = N - 1;
+  const int rows = (int)(n_last - n_first + 1);
+  bool live = t < total;
+  i64 n = 0;
+  int c = 0;
+  if (live) {
+    const int off = (int)(t - n_first * C);  // < C + 512: float quotient, then exact
+    int r = (int)(((float)off + 0.5f) * (1.0f / (float)C));
+    if (r * C > off) r--;
+    if ((r + 1) * C <= off) r++;
+    n = n_first + r;
+    c = off - r * C;
+    live = !(counts && c >= counts[n]);
+  }
+  int k = 0, idx[BSC_KR];
+#pragma unroll
+  for (int i = 0; i < BSC_KR; i++) idx[i] = 0;
+  const u64 *sp = states + (n * (i64)C + c) * HW;
+  if (live) {
+    u64 w[HWT];
+    if (HWT == 1) {
+      w[0] = sp[0];
+    } else {
+      const ulonglong2 *sp2 = (const ulonglong2 *)sp;  // HWT is even: 16-byte aligned
+#pragma unroll
+      for (int i = 0; i < HWT / 2; i++) {
+        const ulonglong2 v = sp2[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HWT; i++) {
+      u64 bits = w[i];
+      while (bits) {
+        const int h = i * 64 + pop_msb(bits);
+#pragma unroll
+        for (int j = 0; j < BSC_KR; j++)
+          if (j == k) idx[j] = h;
+        k++;
+      }
+    }
+  }
+  {
+    const double2 *src = (const double2 *)(Bm + n_first * H);  // H is even (host)
+    double2 *dst = (double2 *)Bs;
+    const int n2 = rows * H / 2;
+    for (int i = threadIdx.x; i < n2; i += 512) dst[i] = src[i];
+  }
+  const double yyn = live ? yy[n] : 0.0;
+  __syncthreads();
+  if (!live) return;
+  const double *Bn = Bs + (size_t)(n - n_first) * H;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (k <= BSC_KR) {
+#pragma unroll
+    for (int i = 0; i < BSC_KR; i++) {
+      if (i < k) {
+        const double *Gh = G + (i64)idx[i] * H;
+        s1 += Bn[idx[i]];
+        s3 += Gh[idx[i]];
+#pragma unroll
+        for (int j = i + 1; j < BSC_KR; j++)
+          if (j < k) s2 += Gh[idx[j]];
+      }
+    }
+  } else {  // dense state: word loop (same order of additions)
+    for (int w1 = 0; w1 < HW; w1++) {
+      u64 bits = sp[w1];
+      while (bits) {
+        const int h = w1 * 64 + pop_msb(bits);
+        const double *Gh = G + (i64)h * H;
+        s1 += Bn[h];
+        s3 += Gh[h];
+        u64 b2 = bits;
+        int w2 = w1;
+        for (;;) {
+          while (b2) s2 += Gh[w2 * 64 + pop_msb(b2)];
+          if (++w2 >= HW) break;
+          b2 = sp[w2];
+        }
+      }
+    }
+  }
+  const double res = ((yyn - 2.0 * s1) + s3) + 2.0 * s2;
+  unsigned fl = 0;
+  lpj_out[n * ldo + col0 + c] = clamp_lpj(pre1 * res + pil_bar * (double)k, fl);
+  if (fl) {
+    atomicOr(&flags[n], fl);
+    atomicOr(&err[1], 1);
+  }
+}
+
 // Permanent all-zero state: lpj = pre * ||y_n||^2 (bsc.py:72 with pre = pre1; sssc.py:237 with
 // pre = -0.5*sigma2_inv).  yy (N) is the precomputed squared norm.  One thread per n.
 __global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N,
