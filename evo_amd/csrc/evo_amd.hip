@@ -1278,9 +1278,19 @@ static int stats_compute(evoamd_ctx *c) {
   if (c->model == EVOAMD_MODEL_BSC) {
     {
       SpanGuard g(c, KID_STATS);
-      bsc_stats_kernel<<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(
-          c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->dpar, c->Es,
-          c->acc + a.Wq, c->partial2);
+#define BSC_STATS(HWT)                                                                                   \
+  bsc_stats_kernel<HWT><<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                 \
+      c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->dpar, c->Es,      \
+      c->acc + a.Wq, c->partial2)
+      switch (c->HW) {
+        case 1: BSC_STATS(1); break;
+        case 2: BSC_STATS(2); break;
+        case 4: BSC_STATS(4); break;
+        case 8: BSC_STATS(8); break;
+        case 16: BSC_STATS(16); break;
+        default: BSC_STATS(0); break;
+      }
+#undef BSC_STATS
       HIP_TRY(hipGetLastError());
     }
     {

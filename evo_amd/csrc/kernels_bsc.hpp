@@ -312,6 +312,8 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double *__restric
 //                (exact inverse of the lpj kernel's last line; no second pass over W)
 //   plus the all-zero permanent state's q_0 ||y||^2 (bsc.py:206-207).
 // States with q_s == 0 contribute exact zeros and are skipped.
+// HWT = words per state (register-resident, 16-byte loads; 0 = any HW, 8-byte word loop).
+template <int HWT>
 __global__ __launch_bounds__(256) void bsc_stats_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
     const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H,
@@ -339,6 +341,49 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
       const u64 *sp = states + (n * (i64)S + s) * HW;
       const double qn = q * inv;
       int k = 0;
+      if (HWT > 0) {
+        constexpr int NW = HWT > 0 ? HWT : 1;
+        u64 w[NW];
+        if (HWT == 1) {
+          w[0] = sp[0];
+        } else {
+          const ulonglong2 *sp2 = (const ulonglong2 *)sp;
+#pragma unroll
+          for (int i = 0; i < NW / 2; i++) {
+            const ulonglong2 v = sp2[i];
+            w[2 * i] = v.x;
+            w[2 * i + 1] = v.y;
+          }
+        }
+        int idx[BSC_KR];
+#pragma unroll
+        for (int i = 0; i < BSC_KR; i++) idx[i] = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+          u64 bits = w[i];
+          while (bits) {
+            const int h = i * 64 + pop_msb(bits);
+#pragma unroll
+            for (int j = 0; j < BSC_KR; j++)
+              if (j == k) idx[j] = h;
+            k++;
+          }
+        }
+        if (k <= BSC_KR) {
+#pragma unroll
+          for (int i = 0; i < BSC_KR; i++) {
+            if (i < k) {
+              unsafeAtomicAdd(&es[idx[i]], q);
+#pragma unroll
+              for (int j = i + 1; j < BSC_KR; j++)
+                if (j < k) unsafeAtomicAdd(&Wq[(i64)idx[i] * H + idx[j]], qn);  // strict upper triangle
+            }
+          }
+          sig += q * ((l - pil_bar * (double)k) / pre1);
+          continue;
+        }
+        k = 0;  // dense state: fall through to the word loop
+      }
       for (int w = 0; w < HW; w++) {
         u64 bits = sp[w];
         k += __popcll(bits);
