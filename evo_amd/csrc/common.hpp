@@ -59,6 +59,29 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_move<0x143, 0xC>(v));
   return lane63_f64(v);
 }
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v, unsigned o) { return v > o ? v : o; }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_move_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+// max over the 16 lanes of each DPP row (every lane of the row gets it)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  v = dpp_max_u32(v, dpp_move_u32<0xB1, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x4E, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x141, 0xF>(v));
+  v = dpp_max_u32(v, dpp_move_u32<0x140, 0xF>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = row16_max_u32(v);
+  v = dpp_max_u32(v, dpp_move_u32<0x142, 0xA>(v));  // lanes outside the row mask see their own value
+  v = dpp_max_u32(v, dpp_move_u32<0x143, 0xC>(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+__device__ __forceinline__ double wave_min(double v);  // below
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -115,3 +138,4 @@ struct LogDetAcc {
 };
 
 __device__ __forceinline__ double wave_max_dpp(double v) { return wave_max(v); }
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }

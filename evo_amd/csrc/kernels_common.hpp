@@ -236,6 +236,23 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const unsigned *__rest
 // Deterministic tie rule (NumPy's introselect/quicksort order is unspecified): equal lpj
 // never swaps; among equal candidates / equal old values the lowest index goes first.
 // ---------------------------------------------------------------------------------------
+// 64-bit hash of the HW words of one state; 16-byte loads when HW is even (rows are then 16-byte
+// aligned): per-lane 8-byte loads cost one pass of the address coalescer per word.
+__device__ __forceinline__ u64 hash_state(const u64 *sw, int HW) {
+  u64 h = 0;
+  if ((HW & 1) == 0) {
+    const ulonglong2 *s2 = (const ulonglong2 *)sw;
+    for (int w = 0; w < HW; w += 2) {
+      const ulonglong2 v = s2[w >> 1];
+      h = (h ^ v.x) * 0x9E3779B97F4A7C15ull + (u64)w;
+      h = (h ^ v.y) * 0x9E3779B97F4A7C15ull + (u64)(w + 1);
+    }
+  } else {
+    for (int w = 0; w < HW; w++) h = (h ^ sw[w]) * 0x9E3779B97F4A7C15ull + (u64)w;
+  }
+  return h;
+}
+
 #define VK_MAX_S_PER_LANE 16  // S <= 1024
 #define VK_MAX_C_PER_LANE 4   // Cmax <= 256
 
@@ -290,20 +307,14 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     for (int q = 0; q < SPL; q++) {
       const int s = lane + 64 * q;
       u64 h = 0;
-      if (s < S) {
-        const u64 *sw = st_n + (i64)s * HW;
-        for (int w = 0; w < HW; w++) h = (h ^ sw[w]) * 0x9E3779B97F4A7C15ull + (u64)w;
-      }
+      if (s < S) h = hash_state(st_n + (i64)s * HW, HW);
       oh[q] = h;
     }
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
       const int c = lane + 64 * q;
       u64 h = 0;
-      if (c < cnt) {
-        const u64 *cw = cd_n + (i64)c * HW;
-        for (int w = 0; w < HW; w++) h = (h ^ cw[w]) * 0x9E3779B97F4A7C15ull + (u64)w;
-      }
+      if (c < cnt) h = hash_state(cd_n + (i64)c * HW, HW);
       ch[q] = h;
     }
     u64 zero_hash = 0;  // hash of the all-zero state (the permanent state when S_perm = 1)
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     }
     // --- values owned by this lane
     double nv[CPL], ov[SPL];
-    int nrank[CPL], orank[SPL];
+    int nrank[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
       const int c = lane + 64 * q;
@@ -368,7 +379,6 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     for (int q = 0; q < SPL; q++) {
       const int s = lane + 64 * q;
       ov[q] = (s < S) ? lpj_n[s] : 0.0;
-      orank[q] = 0;
     }
     const int M = n_uniq < Mprime ? n_uniq : Mprime;
     if (M > 0) {
@@ -388,18 +398,31 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
           }
         }
       }
-      // ascending rank of each old state (ties: lower index first)
+      // the M worst old states in ascending order (ties: lower index first).  M <= Cmax is small,
+      // so M rounds of a wave-wide arg-min replace the full O(S^2 / 64) ranking of all S states
+      // (S = 256: ~4000 instructions per wave, most of this kernel's time at c5).
+      {
+        double ow[SPL];
 #pragma unroll
-      for (int q2 = 0; q2 < SPL; q2++) {
-        for (int l2 = 0; l2 < 64; l2++) {
-          const int s2 = q2 * 64 + l2;
-          if (s2 >= S) break;
-          const double v2 = readlane_f64(ov[q2], l2);
+        for (int q = 0; q < SPL; q++) ow[q] = (lane + 64 * q < S) ? ov[q] : INFINITY;
+        for (int j = 0; j < M; j++) {
+          double lm = INFINITY;
+          unsigned li = 0xFFFFFFFFu;
 #pragma unroll
-          for (int q = 0; q < SPL; q++) {
-            const int s = lane + 64 * q;
-            orank[q] += (v2 < ov[q] || (v2 == ov[q] && s2 < s)) ? 1 : 0;
+          for (int q = 0; q < SPL; q++)
+            if (ow[q] < lm) {
+              lm = ow[q];
+              li = (unsigned)(lane + 64 * q);
+            }
+          const double gm = wave_min(lm);
+          const unsigned gi = wave_min_u32((lm == gm) ? li : 0xFFFFFFFFu);
+          if (lane == 0) {
+            old_v[wave][j] = gm;
+            old_i[wave][j] = (int)gi;
           }
+#pragma unroll
+          for (int q = 0; q < SPL; q++)
+            if ((unsigned)(lane + 64 * q) == gi) ow[q] = INFINITY;
         }
       }
       // rank-j owners publish (value, index)
@@ -409,14 +432,6 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
         if (c < cnt && keep[q] && nrank[q] < M) {
           new_v[wave][nrank[q]] = nv[q];
           new_i[wave][nrank[q]] = c;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < SPL; q++) {
-        const int s = lane + 64 * q;
-        if (s < S && orank[q] < M) {
-          old_v[wave][orank[q]] = ov[q];
-          old_i[wave][orank[q]] = s;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -446,9 +461,13 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
           lpj_n[wi] = new_v[wave][j];
         }
       }
+      for (int j = 0; j < g; j++) {  // the register copy of the row follows the swaps
+        const int wi = old_i[wave][j];
+        const double v = new_v[wave][j];
 #pragma unroll
-      for (int q = 0; q < SPL; q++)
-        if (lane + 64 * q < S && orank[q] < g) ov[q] = new_v[wave][orank[q]];
+        for (int q = 0; q < SPL; q++)
+          if (lane + 64 * q == wi) ov[q] = v;
+      }
     }
     // --- row statistics of the updated row (row_lse_kernel's arithmetic)
     double m = -INFINITY;

@@ -314,26 +314,6 @@ __device__ __forceinline__ double readlane_f64_dyn(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ unsigned dpp_max_u32(unsigned v, unsigned o) { return v > o ? v : o; }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned dpp_move_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false);
-}
-// max over the 16 lanes of each DPP row (every lane of the row gets it)
-__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
-  v = dpp_max_u32(v, dpp_move_u32<0xB1, 0xF>(v));
-  v = dpp_max_u32(v, dpp_move_u32<0x4E, 0xF>(v));
-  v = dpp_max_u32(v, dpp_move_u32<0x141, 0xF>(v));
-  v = dpp_max_u32(v, dpp_move_u32<0x140, 0xF>(v));
-  return v;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  v = row16_max_u32(v);
-  v = dpp_max_u32(v, dpp_move_u32<0x142, 0xA>(v));  // lanes outside the row mask see their own value
-  v = dpp_max_u32(v, dpp_move_u32<0x143, 0xC>(v));
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // Pivot key: exponent and the top 11 mantissa bits of |x| above 1023 - row, one 32-bit integer, so
 // the arg-max is integer DPP (a dependent f64 op costs 32 cycles on gfx950, an integer one 4-8).
 // The pivot is then the largest candidate up to a factor 1 + 2^-11 (ties: the smallest row), which
