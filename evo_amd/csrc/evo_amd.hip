@@ -1537,7 +1537,12 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     HIP_TRY(hipGetLastError());
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, /*deterministic=*/true);  // G = W^T W (new W)
     if (r) return r;
-    sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->acc + a.sz_sz, c->G, H, Nptr, learn,
+    const int n_part = (int)std::min<i64>(1024, cdiv(HH, 1024));
+    r = ensure_colpart(c, (size_t)n_part);
+    if (r) return r;
+    if (learn & L_SIGMA2)
+      sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
+    sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, n_part, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar);
     interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP, H, c->mus, c->pilbar_v, c->DG);
     sssc_tables_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1, c->PT);

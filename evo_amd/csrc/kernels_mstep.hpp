@@ -901,19 +901,38 @@ __global__ __launch_bounds__(256) void psi_floor_kernel(double *__restrict__ Psi
 
 // sigma2 = (sum y2 - trace(sz_sz . W^T W)) / N / D + eps (sssc.py:759-768), then the precompute
 // (sssc.py:340-353): pil_bar, ljc, sigma2_inv.  Single workgroup.
+// partial sums of trace(sz_sz . G) = sum_ij sz_sz[i][j] G[j][i] over contiguous element ranges, one
+// partial per workgroup (fixed order => the same bits on every rank); a single workgroup walking
+// the H^2 products with a strided G took 0.24 ms at H = 512.
+__global__ __launch_bounds__(256) void sssc_trace_partial_kernel(const double *__restrict__ sz_sz,
+                                                                 const double *__restrict__ G, int H,
+                                                                 i64 per_block, double *__restrict__ part) {
+  __shared__ double sh[256];
+  const i64 e0 = (i64)blockIdx.x * per_block;
+  const i64 e1 = (e0 + per_block < (i64)H * H) ? e0 + per_block : (i64)H * H;
+  double s = 0.0;
+  for (i64 e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int i = (int)(e / H), j = (int)(e - (i64)i * H);
+    s += sz_sz[e] * G[(i64)j * H + i];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
 __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
-    const double *__restrict__ y2, int D, const double *__restrict__ sz_sz, const double *__restrict__ G, int H,
+    const double *__restrict__ y2, int D, const double *__restrict__ trace_part, int n_part, int H,
     const double *__restrict__ Nptr, int learn, const double *__restrict__ pies, double *__restrict__ pil_bar,
     double *__restrict__ dpar) {
   __shared__ double sh[MS_T];
   const int t = threadIdx.x;
-  // trace(sz_sz . G) = sum_ij sz_sz[i][j] G[j][i]
   double s = 0.0;
   if (learn & L_SIGMA2) {
-    for (i64 e = t; e < (i64)H * H; e += MS_T) {
-      const int i = (int)(e / H), j = (int)(e - (i64)i * H);
-      s -= sz_sz[e] * G[(i64)j * H + i];
-    }
+    for (int b = t; b < n_part; b += MS_T) s -= trace_part[b];
     for (int d = t; d < D; d += MS_T) s += y2[d];
   }
   sh[t] = s;
