@@ -319,6 +319,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM128_LDS_BYTES));
   *out = c;
   return 0;
 }
@@ -607,15 +609,29 @@ static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const do
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                           int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1) {
-  // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of 64):
-  // only its upper tiles are computed, the rest is mirrored
-  const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
+  // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of the
+  // tile size): only its upper tiles are computed, the rest is mirrored
+  const bool vec = gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (M % 2) == 0 && (Nc % 2) == 0 && M >= 2 && Nc >= 2;
+  // long-K, wide outputs: 128 x 128 tiles (half the L2 traffic per flop)
+  const bool big = vec && !deterministic && K >= 8192 && M >= 256 && Nc >= 256 &&
+                   (sym_row0 < 0 || (sym_row0 % GEMM_T) == 0);
+  const int T = big ? GEMM_T : GEMM_BM;
+  if (sym_row0 >= 0 && (sym_row0 % T) != 0) sym_row0 = -1;
+  const int gx = (int)cdiv(Nc, T), gy = (int)cdiv(M, T);
   const i64 tiles = (i64)gx * gy;
-  // enough workgroups to fill the chip (>= 512), at least 64 rows of K per chunk; the kernel
-  // spreads the K chunks over the 8 XCDs, so a split uses a multiple of 8 chunks
+  // enough workgroups to fill the chip, at least 64 rows of K per chunk; the kernel spreads the K
+  // chunks over the 8 XCDs, so a split uses a multiple of 8 chunks.  64-tiles: >= 512 workgroups;
+  // 128-tiles (2 per CU, 64 per XCD): chunks per XCD chosen so that the last round of an XCD is
+  // at least 90 % full
   i64 splits = 1;
-  if (K >= 128 && !deterministic) {  // split-K sums with atomics: order (hence last bits) varies
-    splits = (512 + tiles - 1) / tiles;
+  if (K >= 128 && !deterministic) {
+    if (big) {
+      i64 per_xcd = 1;
+      while (per_xcd < 16 && (double)(tiles * per_xcd) / (64.0 * (double)cdiv(tiles * per_xcd, 64)) < 0.9) per_xcd++;
+      splits = 8 * per_xcd;
+    } else {
+      splits = (512 + tiles - 1) / tiles;
+    }
     const i64 maxs = (K + 63) / 64;
     if (splits > maxs) splits = maxs;
     if (splits > 1) splits = ((splits + 7) / 8) * 8;
@@ -628,14 +644,15 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
   }
   const unsigned grid = (unsigned)(tiles * (split ? splits : 1));
-  const bool vec = gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (M % 2) == 0 && (Nc % 2) == 0 && M >= 2 && Nc >= 2;
   SpanGuard g(c, KID_GEMM);
-  if (vec)
+  if (big)
+    gemm_tn128_f64<<<grid, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
+  else if (vec)
     gemm_tn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   else
     gemm_tn_f64<false><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   if (sym_row0 >= 0)
-    mirror_lower_kernel<<<cdiv((i64)Nc * Nc, 256), 256, 0, c->stream>>>(C + (size_t)sym_row0 * ldc, Nc, ldc);
+    mirror_lower_kernel<<<cdiv((i64)Nc * Nc, 256), 256, 0, c->stream>>>(C + (size_t)sym_row0 * ldc, Nc, ldc, T);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1384,7 +1401,7 @@ static int stats_compute(evoamd_ctx *c) {
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
     // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
     r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
-                       ((D + H) % GEMM_BM) == 0 ? D + H : -1);
+                       ((D + H) % GEMM_BM) == 0 ? D + H : -1);  // launch_gemm_tn drops the hint if its tile does not divide it
     if (r) return r;
   }
   {
@@ -1662,6 +1679,28 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
                                             : "non-finite sigma / pi");
   }
   return 0;
+}
+
+extern "C" int evoamd_gemm_tn(evoamd_ctx *c, const double *A, const double *B, double *C, int64_t K, int M, int Nc,
+                              int sym_row0) {
+  REQUIRE(c && A && B && C && K > 0 && M > 0 && Nc > 0, "bad arguments");
+  REQUIRE(sym_row0 < 0 || (sym_row0 + Nc == M), "sym_row0: the symmetric block must be the last Nc rows of C");
+  HIP_TRY(hipSetDevice(c->device));
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipError_t e = hipMalloc((void **)&dA, (size_t)K * M * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&dB, (size_t)K * Nc * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&dC, (size_t)M * Nc * sizeof(double));
+  int r = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(dA, A, (size_t)K * M * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dB, B, (size_t)K * Nc * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) r = launch_gemm_tn(c, dA, M, dB, Nc, dC, Nc, M, Nc, K, false, sym_row0);
+  if (e == hipSuccess && !r) e = hipMemcpyAsync(C, dC, (size_t)M * Nc * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  if (e != hipSuccess) return fail(EVOAMD_E_HIP, "evoamd_gemm_tn: %s", hipGetErrorString(e));
+  return r;
 }
 
 extern "C" int evoamd_inverse(evoamd_ctx *c, double *A, double *B, int n, double *timing_ms) {

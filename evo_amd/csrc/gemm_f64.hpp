@@ -173,6 +173,117 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
       }
 }
 
+// 128 x 128 output tile variant of gemm_tn_f64<true> for the long-K contractions of the M-step
+// ([Y|Es|Ez]^T Ez with K = N): each wave owns 64 x 64 (4 x 4 MFMA tiles, 128 accumulator registers),
+// so a K slab of 16 carries 64 MFMAs per wave for 8 LDS fragment reads and the tile pulls half as
+// many bytes per flop through L2 as the 64 x 64 kernel.  Same XCD-aware 1-D grid, 2-deep register
+// prefetch (<= 256 registers: 2 workgroups per CU), same SYRK-style skip.  LDS 2 x 2 x 16 x 144 doubles = 72 KB (2 workgroups / CU).
+#define GEMM_T 128
+#define GEMM_LDS2 144
+#define GEMM128_LDS_BYTES (2 * 2 * GEMM_BK * GEMM_LDS2 * sizeof(double))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_f64(const double *__restrict__ A, int lda,
+                                                      const double *__restrict__ B, int ldb,
+                                                      double *__restrict__ C, int ldc, int M, int Nc, i64 K,
+                                                      i64 k_per_split, int gx, int gy, int split, int sym_row0) {
+  extern __shared__ double lds128[];
+  double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
+  double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int tiles = gx * gy;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int zc = split ? xcd + 8 * (jj / tiles) : 0;
+  const int tile = split ? jj % tiles : (int)blockIdx.x;
+  const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+  if (sym_row0 >= 0 && m0 >= sym_row0 && m0 - sym_row0 > n0) return;  // uniform
+  const i64 kbeg = (i64)zc * k_per_split;
+  const i64 kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  // loader: the 16 x 64 grid of 16-byte pieces of a slab (16 rows x 128 columns), pieces p = t + 256 i
+  double2 ra[2][4], rb[2][4];  // two slabs ahead (a slab is 4096 matrix-core cycles per wave here)
+  auto fetch = [&](double2(&qa)[4], double2(&qb)[4], i64 k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = t + 256 * i;
+      const i64 kr = k0 + (p >> 6);
+      const int cc = (p & 63) * 2;
+      const bool kin = kr < kend;
+      const i64 krc = kin ? kr : kend - 1;
+      const int ma = m0 + cc, nb = n0 + cc;
+      double2 va = *(const double2 *)(A + krc * lda + (ma < M ? ma : M - 2));
+      double2 vb = *(const double2 *)(B + krc * ldb + (nb < Nc ? nb : Nc - 2));
+      if (!(kin && ma < M)) va = make_double2(0.0, 0.0);
+      if (!(kin && nb < Nc)) vb = make_double2(0.0, 0.0);
+      qa[i] = va;
+      qb[i] = vb;
+    }
+  };
+  auto stash = [&](const double2(&qa)[4], const double2(&qb)[4], int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int p = t + 256 * i, r = p >> 6, cc = (p & 63) * 2;
+      *(double2 *)&As[buf][r][cc] = qa[i];
+      *(double2 *)&Bs[buf][r][cc] = qb[i];
+    }
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+      const int kl = kk * 4 + (lane >> 4);
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = As[buf][kl][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[buf][kl][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  const i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+  if (nslab > 0) {
+    fetch(ra[0], rb[0], kbeg);
+    stash(ra[0], rb[0], 0);
+    if (nslab > 1) fetch(ra[0], rb[0], kbeg + GEMM_BK);
+    if (nslab > 2) fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+  }
+  __syncthreads();
+  for (i64 s0 = 0; s0 < nslab; s0 += 2) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const i64 sl = s0 + j;
+      if (sl < nslab) {  // uniform
+        const int buf = (int)(sl & 1);
+        compute(buf);
+        if (sl + 1 < nslab) stash(ra[j], rb[j], buf ^ 1);
+        if (sl + 3 < nslab) fetch(ra[j], rb[j], kbeg + (sl + 3) * GEMM_BK);
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (row < M && col < Nc) {
+          if (split)
+            unsafeAtomicAdd(&C[(i64)row * ldc + col], acc[i][j][r]);
+          else
+            C[(i64)row * ldc + col] = acc[i][j][r];
+        }
+      }
+}
+
 // C (M x Nc) = A B with A: M x K (lda) row-major, B: K x Nc (ldb).  No K split (K = D or H is small).
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A, int lda,
@@ -281,11 +392,11 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
 
 // S (n x n, ld) <- upper triangle mirrored into the lower one (the SYRK-style launch above computed
 // only tiles with row tile <= column tile; inside diagonal tiles both halves exist already).
-__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ S, int n, int ld) {
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ S, int n, int ld, int tile) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)n * n) return;
   const int i = (int)(t / n), j = (int)(t - (i64)i * n);
-  if ((i / GEMM_BM) > (j / GEMM_BN)) S[(i64)i * ld + j] = S[(i64)j * ld + i];
+  if ((i / tile) > (j / tile)) S[(i64)i * ld + j] = S[(i64)j * ld + i];
 }
 
 // out[c] += sum_r X[r][c]   (column sums of an (R x Cn) row-major matrix; optional square).

@@ -196,6 +196,15 @@ class Engine:
         check(self.lib.evoamd_inverse(self._h, dptr(A), None if Bc is None else dptr(Bc), self.H, ctypes.byref(ms)))
         return A, Bc, ms.value
 
+    def gemm_tn(self, A, B, sym_row0=-1):
+        """C = A^T B through the statistics pass's f64 MFMA dispatch (A: K x M, B: K x Nc)."""
+        A, B = as_f64(A), as_f64(B)
+        assert A.shape[0] == B.shape[0]
+        C = np.empty((A.shape[1], B.shape[1]))
+        check(self.lib.evoamd_gemm_tn(self._h, dptr(A), dptr(B), dptr(C), A.shape[0], A.shape[1], B.shape[1],
+                                      int(sym_row0)))
+        return C
+
     def get_params_bsc(self):
         W = np.empty((self.D, self.H))
         pi, sigma = ctypes.c_double(), ctypes.c_double()

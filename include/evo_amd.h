@@ -169,6 +169,13 @@ int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, doubl
  * exported so that the parity tests can drive it with pivoting and near-singular cases.
  * timing_ms (may be NULL) receives the device time of the inversion. */
 int evoamd_inverse(evoamd_ctx *ctx, double *A, double *B, int n, double *timing_ms);
+/* The M-step's dense contraction on its own: C (M x Nc, row-major) = A^T B with A (K x M) and B (K x Nc)
+ * row-major host arrays -- the f64 MFMA path behind Wp = Es^T Y (bsc.py:211 summed over n) and
+ * [Y | Es | Ez]^T Ez (sssc.py:634,637,646), with the same tile-size / K-split / XCD dispatch as the
+ * statistics pass.  sym_row0 >= 0 declares rows sym_row0.. of C symmetric (X^T X).  Exported for the
+ * parity tests (the long-K tile variants only run at sizes no oracle fixture reaches). */
+int evoamd_gemm_tn(evoamd_ctx *ctx, const double *A, const double *B, double *C, int64_t K, int M, int Nc,
+                   int sym_row0);
 /* Current parameters of the context back to the host (after evoamd_mstep_device). */
 int evoamd_get_params_bsc(evoamd_ctx *ctx, double *W, double *pi, double *sigma);
 int evoamd_get_params_sssc(evoamd_ctx *ctx, double *W, double *pies, double *mus, double *Psi,

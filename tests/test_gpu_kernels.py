@@ -297,3 +297,21 @@ def test_lpj_sssc_wide_states(engine, H, S):
     for n in range(N):
         want[n] = orc.sssc_lpj(theta, ss[n], Y[n], orc.new_counters(), {})
     _close(got, want, LPJ_RTOL, "wide-state ES3C lpj")
+
+
+@pytest.mark.parametrize("K,M,Nc,sym", [(9000, 384, 256, False), (8200, 640, 256, True), (300, 192, 64, True),
+                                        (8192, 258, 256, False), (130, 70, 34, False)])
+def test_gemm_tn_dispatch(engine, K, M, Nc, sym):
+    """C = A^T B through the statistics pass's MFMA dispatch: 64- and 128-tile kernels, split K over
+    the XCDs, 16-byte and scalar loaders, upper-tiles-plus-mirror for a trailing X^T X block."""
+    rng = np.random.default_rng(K + M)
+    A = rng.standard_normal((K, M))
+    B = rng.standard_normal((K, Nc))
+    if sym:
+        A[:, M - Nc:] = B
+    C = engine.gemm_tn(A, B, M - Nc if sym else -1)
+    ref = A.T @ B
+    assert np.abs(C - ref).max() <= 1e-11 * np.abs(ref).max()
+    if sym:
+        blk = C[M - Nc:]
+        assert np.abs(blk - blk.T).max() <= 1e-11 * np.abs(ref).max()
