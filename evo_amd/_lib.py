@@ -54,6 +54,7 @@ SIGNATURES = {
     "evoamd_acc_size": (_I64, [_vp]),
     "evoamd_stats": (_I, [_vp, _c_dp]),
     "evoamd_mstep_device": (_I, [_vp, _I, _c_dp, _c_dp]),
+    "evoamd_reconstruct": (_I, [_vp, _c_dp]),
     "evoamd_inverse": (_I, [_vp, _c_dp, _c_dp, _I, _c_dp]),
     "evoamd_gemm_tn": (_I, [_vp, _c_dp, _c_dp, _c_dp, _I64, _I, _I, _I]),
     "evoamd_get_params_bsc": (_I, [_vp, _c_dp, _c_dp, _c_dp]),

@@ -128,6 +128,10 @@ struct evoamd_ctx {
   int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
                      // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
+  double *yhat = nullptr, *tmpWt = nullptr;  // reconstruction (N x D) and W^T scratch (ES3C)
+  size_t yhat_n = 0;
+  bool yhat_valid = false;
+  bool stats_rows_valid = false;  // Es / Ez rows describe the current K^n and Theta
   bool spd_inverse = true;  // M-step H x H systems: SPD block Gauss-Jordan first, pivoted path on a bad pivot
   long spd_fallbacks = 0;   // how often the pivoted repeat was needed
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
@@ -328,7 +332,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
-                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,
+                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
@@ -518,6 +522,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
   c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
+  if (c->tmpWt) (void)hipFree(c->tmpWt);  // sized by (H, D): rebuilt on demand
+  c->tmpWt = nullptr;
+  c->yhat_valid = c->stats_rows_valid = false;
   c->lists_clean = c->need_known = c->cand_from_device = false;  // fresh (uninitialised) overflow counters
   return 0;
 }
@@ -704,6 +711,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   }
   c->have_params = true;
   c->h_theta_fresh = false;
+  c->yhat_valid = c->stats_rows_valid = false;
   return 0;
 }
 
@@ -766,6 +774,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   }
   c->have_params = true;
   c->h_theta_fresh = false;
+  c->yhat_valid = c->stats_rows_valid = false;
   return 0;
 }
 
@@ -1283,6 +1292,7 @@ static int stats_compute(evoamd_ctx *c) {
   const i64 N = c->N;
   const int H = c->H, D = c->D;
   HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
+  c->yhat_valid = c->stats_rows_valid = false;
   int r = ensure_B(c);
   if (r) return r;
   if (!c->rows_fresh) {  // otherwise vary_kn left rowmax / rowsum / dpar[DP_FS] behind
@@ -1414,6 +1424,7 @@ static int stats_compute(evoamd_ctx *c) {
   if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
+  c->stats_rows_valid = true;
   return 0;
 }
 
@@ -1589,6 +1600,43 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
   return 0;
 }
 
+// y_hat = E W^T with E = Es (EBSC) / Ez (ES3C) rows of the last statistics pass (see evoamd_reconstruct)
+static int compute_reconstruction(evoamd_ctx *c) {
+  const size_t need = (size_t)c->N * c->D;
+  if (need > c->yhat_n) {
+    ALLOC(c->yhat, need);
+    c->yhat_n = need;
+  }
+  const double *Wt = c->Wt;
+  const double *E = c->Es;
+  int lde = c->H;
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    if (!c->tmpWt) ALLOC(c->tmpWt, (size_t)c->H * c->D);
+    transpose_kernel<<<cdiv((i64)c->H * c->D, 256), 256, 0, c->stream>>>(c->W, c->D, c->H, c->tmpWt);  // (D,H) -> (H,D)
+    Wt = c->tmpWt;
+    E = c->Y + c->D + c->H;  // Ez block of [Y | Es | Ez | Ed]
+    lde = c->ldY;
+  }
+  SpanGuard g(c, KID_GEMM);
+  launch_gemm_nn_raw(c, E, lde, Wt, c->D, c->yhat, c->D, c->N, c->D, c->H);
+  HIP_TRY(hipGetLastError());
+  c->yhat_valid = true;
+  return 0;
+}
+
+extern "C" int evoamd_reconstruct(evoamd_ctx *c, double *y_hat) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params && y_hat, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->yhat_valid) {
+    REQUIRE(c->stats_rows_valid, "evoamd_reconstruct: call evoamd_stats first (and before setting new parameters)");
+    int r = compute_reconstruction(c);
+    if (r) return r;
+  }
+  HIP_TRY(hipMemcpyAsync(y_hat, c->yhat, (size_t)c->N * c->D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // Everything an EM iteration returns to the host goes through the mailbox kernel; the host polls
 // the sequence number (falls back to a blocking synchronise after 20 ms of spinning).
 static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta) {
@@ -1644,9 +1692,16 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   int r = stats_compute(c);
   if (r) return r;
   c->h_theta_fresh = false;
+  const bool want_rec = (learn_mask & 32) != 0;
+  learn_mask &= 31;
+  if (want_rec) {  // under the Theta the E-step used, i.e. before the update
+    r = compute_reconstruction(c);
+    if (r) return r;
+  }
   if (learn_mask) {
     r = update_params_device(c, learn_mask);
     if (r) return r;
+    c->stats_rows_valid = false;  // the rows belong to the previous Theta now
   }
   // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
   // the reference's step() hands Theta^new back, so it rides along

@@ -174,9 +174,10 @@ class Engine:
     DPAR = {"pre1": 0, "pil_bar": 1, "sigma2_inv": 2, "ljc": 3, "pi": 4, "sigma": 5, "sigma2": 6, "status": 7,
             "ljc_prev": 8, "n_gt2": 12, "n_gt4": 13, "n_gt8": 14}
 
-    def mstep_device(self, to_learn):
-        """Statistics + Theta update on the device.  Returns (tail dict, scalar-parameter dict)."""
-        mask = 0
+    def mstep_device(self, to_learn, reconstruct=False):
+        """Statistics + Theta update on the device.  Returns (tail dict, scalar-parameter dict).
+        reconstruct: also form the data estimate under the OLD Theta (fetch it with reconstruct())."""
+        mask = 32 if reconstruct else 0
         for name in to_learn:
             mask |= self.LEARN_BITS[name]
         tail = np.zeros(8)
@@ -195,6 +196,12 @@ class Engine:
         ms = ctypes.c_double()
         check(self.lib.evoamd_inverse(self._h, dptr(A), None if Bc is None else dptr(Bc), self.H, ctypes.byref(ms)))
         return A, Bc, ms.value
+
+    def reconstruct(self):
+        """(N, D) posterior-predictive estimate under the Theta / K^n of the last statistics pass."""
+        out = np.empty((self.N, self.D))
+        check(self.lib.evoamd_reconstruct(self._h, dptr(out)))
+        return out
 
     def gemm_tn(self, A, B, sym_row0=-1):
         """C = A^T B through the statistics pass's f64 MFMA dispatch (A: K x M, B: K x Nc)."""

@@ -214,7 +214,17 @@ class Model:
             model_params[name] = v
         return model_params
 
-    def _step_device(self, model_params, my_suff_stat, my_data):
+    def _write_reconstruction(self, my_data):
+        """my_data["y_reconstructed"] (_models.py:643-665, sssc.py:507,613-627; complete data): a copy of
+        y whose entries with my_data["x"] False are the posterior-predictive estimate W E_q[s] (EBSC) /
+        W E_q[s o z] (ES3C) under the Theta and K^n of the statistics pass that just ran."""
+        y_hat = self.engine.reconstruct()
+        y_rec = my_data["y"].copy()
+        miss = np.logical_not(my_data["x"])
+        y_rec[miss] = y_hat[miss]
+        my_data["y_reconstructed"] = y_rec
+
+    def _step_device(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """EM iteration with the M-step on the device (device_mstep=True)."""
         if self.comm.size > 1 and not getattr(self.comm, "device_reduces", False):
             raise ValueError("device_mstep with several ranks needs an RcclComm (device-side all-reduce)")
@@ -229,7 +239,9 @@ class Model:
             self._candidates_device(eng, my_suff_stat)
         eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
         self._n_steps += 1
-        tail, dpar = eng.mstep_device(self.to_learn)
+        tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction)
+        if do_reconstruction:
+            self._write_reconstruction(my_data)
         if self.sync_host:
             self.sync_to_host(my_suff_stat)
         my_suff_stat["reset_lpj_isnan"] = int(tail["reset_isnan"])
@@ -242,12 +254,12 @@ class Model:
 
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """One EM iteration (_models.py:161-203): check_params -> E_step -> M_step."""
-        if do_reconstruction:
-            raise NotImplementedError("reconstruct() is outside the accelerated path (SURVEY 8f rank 3)")
         if self.device_mstep:
-            return self._step_device(model_params, my_suff_stat, my_data)
+            return self._step_device(model_params, my_suff_stat, my_data, do_reconstruction)
         model_params = self.check_params(model_params)
         F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
+        if do_reconstruction:  # _models.py:193-194: after the E-step, with the Theta it used
+            self._write_reconstruction(my_data)
         new_params = (self.M_step(model_params, my_suff_stat, my_data, _from_step=True)
                       if len(self.to_learn) > 0 else model_params)
         self._acc = None

@@ -117,10 +117,8 @@ class SSSC(Model):
 
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """check_params -> fused EM_step (sssc.py:407-417)."""
-        if do_reconstruction:
-            raise NotImplementedError("reconstruction is outside the accelerated path (SURVEY 8f rank 3)")
         if self.device_mstep:
-            return self._step_device(model_params, my_suff_stat, my_data)
+            return self._step_device(model_params, my_suff_stat, my_data, do_reconstruction)
         model_params = self.check_params(model_params)
         return self.EM_step(model_params, my_suff_stat, my_data, do_reconstruction)
 
@@ -169,9 +167,9 @@ class SSSC(Model):
     def EM_step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """Fused E- and M-step (sssc.py:419-813).  Returns (F, S_nunique, S_sub, Theta_new); F uses
         the ljc of the Theta the E-step ran with (sssc.py:472,780)."""
-        if do_reconstruction:
-            raise NotImplementedError("reconstruction is outside the accelerated path (SURVEY 8f rank 3)")
         F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
+        if do_reconstruction:  # sssc.py:500-507,613-627: estimates under the Theta of this E-step
+            self._write_reconstruction(my_data)
         v = self.engine.acc_views(self._acc)
         self._acc = None
         for label, key in (("reset_lpj_isnan", "reset_isnan"), ("reset_lpj_smaller_eps_lpj", "reset_smaller_eps"),

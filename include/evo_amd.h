@@ -163,6 +163,14 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
  * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
+/* Posterior-predictive data estimate (complete data): y_hat (N x D, host) with
+ *   y_hat[n] = sum_s q_ns W s / sum_s q_ns = W . E_q[s]           EBSC  (_models.py:614-665, bsc.py:279-287)
+ *   y_hat[n] = sum_s q_ns W (s o kappa_ns) / sum_s q_ns = W . E_q[s o z]   ES3C  (sssc.py:368-405,613-627)
+ * under the Theta and K^n of the last statistics pass -- what Model.reconstruct / EM_step(do_reconstruction)
+ * write into my_data["y_reconstructed"] where my_data["x"] is False (the host applies that mask).
+ * Call after evoamd_stats and before new parameters are set, or pass learn_mask | 32 to
+ * evoamd_mstep_device, which then forms y_hat before it updates Theta. */
+int evoamd_reconstruct(evoamd_ctx *ctx, double *y_hat);
 /* The M-step's H x H solver on its own: A (and B if not NULL) are replaced by their inverses
  * (row-major n x n, n == H of the configured context).  This is the Gauss-Jordan code path that
  * evoamd_mstep_device uses in place of np.linalg.inv (sssc.py:693,738) / lstsq (bsc.py:237);

@@ -479,15 +479,37 @@ def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma")):
     return theta
 
 
-def bsc_step(theta, suff, Y, to_learn=("W", "pi", "sigma"), trace=None):
-    """_models.py:161-203 for BSC on one rank: check_params -> E_step -> M_step.
-    Returns (F, S_nunique, S_sub, theta) like the reference, plus the raw sums dict."""
+def bsc_reconstruct(theta, suff, Y, x):
+    """Model.reconstruct (_models.py:614-665) with BSC.modelmean (bsc.py:279-287), complete data:
+    entries with x False become sum_s q_s (W s)_d / sum_s q_s under the current Theta and K^n."""
+    lpj, ss, S_perm = suff["lpj"], suff["ss"], suff["S_perm"]
+    B = np.minimum(B_MAX - lpj.max(axis=1), B_MAX_SHFT)
+    pjc = np.exp(lpj + B[:, None])
+    y_rec = Y.copy()
+    Wt = theta["W"].T
+    for n in range(Y.shape[0]):
+        this_x = x[n]
+        this_W = Wt[:, np.logical_not(this_x)]
+        this_mu = np.dot(ss[n], this_W).T                       # (D_miss, S)
+        this_pjc = pjc[n]
+        est = (this_mu * this_pjc[None, S_perm:]).sum(axis=1) / this_pjc.sum()
+        y_rec[n][np.logical_not(this_x)] = est
+    return y_rec
+
+
+def bsc_step(theta, suff, Y, to_learn=("W", "pi", "sigma"), trace=None, reconstruct_x=None):
+    """_models.py:161-203 for BSC on one rank: check_params -> E_step [-> reconstruct] -> M_step.
+    Returns (F, S_nunique, S_sub, theta) like the reference, plus the raw sums dict
+    (sums["y_reconstructed"] when reconstruct_x, the my_data["x"] mask, is given)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     theta = check_params(theta, BSC_POLICY)
     Fs, nu, nsub, _ = bsc_E_step(theta, suff, Y, trace)
     F = theta["ljc"] + Fs / N
+    y_rec = bsc_reconstruct(theta, suff, Y, reconstruct_x) if reconstruct_x is not None else None
     sums = bsc_accumulate(theta, suff, Y)
+    if y_rec is not None:
+        sums["y_reconstructed"] = y_rec
     sums["Fs"] = Fs
     if len(to_learn) > 0:
         theta = bsc_update(theta, sums, N, D, H, to_learn)
@@ -595,7 +617,7 @@ def sssc_lpj_allzero(theta, y, counters):
 
 
 def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
-                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True):
+                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True, reconstruct_x=None):
     """sssc.py:419-656: the fused per-datapoint loop (E-step + sufficient statistics) on one
     rank.  Returns the dict of per-rank sums the reference all-reduces (sssc.py:671-691,763,
     773-780).  With evolve=False the EA / selection is skipped (statistics of the resident K^n)."""
@@ -613,6 +635,7 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
         "s_sz_outer": np.zeros((H, H)), "sz_sz_outer": np.zeros((H, H)),
     }
     n_uniq = n_sub = 0.0
+    y_rec = Y.copy() if reconstruct_x is not None else None   # sssc.py:500-507
     for n in range(N):
         y = Y[n]
         cur = ss[n]
@@ -654,6 +677,19 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
         e_ss /= qs
         e_sz /= qs
         e_szsz /= qs
+        if y_rec is not None:
+            # sssc.py:613-627 with SSSC.modelmean (sssc.py:368-405), complete data
+            this_x = reconstruct_x[n]
+            this_sz = np.zeros((H, S))
+            for s in range(S):
+                st = cur[s]
+                t = cache[st.tobytes()]
+                kappa_s = np.dot(t["lam_Wt"], y - t["Wmu"])
+                kappa_s += mus[st]
+                this_sz[st, s] = kappa_s
+            this_mus = np.dot(theta["W"][np.logical_not(this_x), :], this_sz)   # (D_miss, S)
+            est = (this_mus * q[None, S_perm:]).sum(axis=1) / q.sum()
+            y_rec[n][np.logical_not(this_x)] = est
         acc["xpt_s"] += e_s
         acc["xpt_ss"] += e_ss
         acc["xpt_sz"] += e_sz
@@ -668,6 +704,8 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
     acc["n_uniq"] = n_uniq
     acc["n_sub"] = n_sub
     acc["counters"] = counters
+    if y_rec is not None:
+        acc["y_reconstructed"] = y_rec
     return acc
 
 
@@ -700,13 +738,13 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
 
 
 def sssc_step(theta, suff, Y, use_storage=True, to_learn=("W", "pies", "mus", "sigma2", "Psi"),
-              trace=None):
+              trace=None, reconstruct_x=None):
     """sssc.py:407-417 + EM_step on one rank.  Returns (F, S_nunique, S_sub, theta, acc).
     F uses the *old* Theta's ljc (sssc.py:472,780)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     theta = check_params(theta, SSSC_POLICY)
-    acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn)
+    acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn, reconstruct_x=reconstruct_x)
     ljc = theta["ljc"]
     theta = sssc_update(theta, acc, N, D, H, to_learn)
     F = ljc + acc["Fs"] / N

@@ -310,7 +310,45 @@ def make_full_F():
     np.savez_compressed(os.path.join(HERE, "full_F.npz"), **out)
 
 
+def make_recon_fixture(name, algo, D, H, S, N, seed, n_steps=2):
+    """model.step(..., do_reconstruction=True) on complete data (the image-denoising use,
+    examples/image-denoising/main.py:100-110,162-169): my_data["x"] marks the entries that keep their
+    value; every other entry of y_reconstructed is the posterior-predictive estimate."""
+    np.random.seed(seed)
+    model = BSC(D, H, S) if algo == "ebsc" else SSSC(D, H, S)
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
+    Y = BSC(D, H, S).generate_data(gen, N)["y"]
+    x = np.random.random_sample(Y.shape) < 0.4
+    x[0] = False  # one datapoint reconstructed completely
+    x[1] = True   # one not at all
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool), "x": x}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, "fit", "randflip", 5, 1, 1)
+    out = {"algo": np.array(algo), "D": np.int64(D), "H": np.int64(H), "S": np.int64(S), "N": np.int64(N),
+           "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y": Y, "x": x,
+           "ea_parent_selection": np.array("fit"), "ea_mutation": np.array("randflip"),
+           "ea_n_parents": np.int64(5), "ea_n_children": np.int64(1), "ea_n_generations": np.int64(1),
+           "ea_bitflip_prob": np.float64(np.nan), "ea_Mprime": np.int64(suff["Mprime"])}
+    out["t0_ss_in"] = pack(suff["ss"])
+    out.update(theta_arrays("t0_in_", theta, keys))
+    for t in range(n_steps):
+        np.random.seed(1000 + seed + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data, do_reconstruction=True)
+        out["t%d_F" % t] = np.float64(F)
+        out["t%d_y_reconstructed" % t] = my_data["y_reconstructed"].copy()
+        out["t%d_ss_out" % t] = pack(suff["ss"])
+        out.update(theta_arrays("t%d_out_" % t, theta, keys))
+    path = os.path.join(HERE, "recon_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "recon":  # only the reconstruction fixtures (added later)
+        make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
+        make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)
+        sys.exit(0)
     make_kat_bars()
     make_lpj_fixtures()
     make_vary_kn()
@@ -324,3 +362,5 @@ if __name__ == "__main__":
     make_step_fixture("ebsc_sparseflip", "ebsc", 20, 24, 12, 30, seed=7, n_steps=2, ea=("rand", "sparseflip", 4, 2, 1), bitflip_prob=0.1)
     make_step_fixture("es3c_cross", "es3c", 20, 24, 12, 30, seed=8, n_steps=2, ea=("fit", "cross_randflip", 4, 1, 1))
     make_step_fixture("ebsc_gen2", "ebsc", 20, 24, 12, 30, seed=9, n_steps=2, ea=("fit", "randflip", 4, 2, 2), Mprime=5)
+    make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
+    make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)

@@ -299,3 +299,32 @@ def test_es3c_tile_aligned_shapes_against_oracle(engine, D, H, S, N, device_mste
             ref = np.asarray(th_o[k])
             np.testing.assert_allclose(th_a[k], ref, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(ref).max())),
                                        err_msg="%s step %d" % (k, t))
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_reconstruction_against_reference(engine, algo, device_mstep):
+    """model.step(..., do_reconstruction=True) on complete data -- the image-denoising use
+    (examples/image-denoising/main.py:100-110,162-169) -- against my_data["y_reconstructed"] recorded
+    from the reference (tests/golden/recon_*.npz), two chained steps, host and device M-step."""
+    from evo_amd.models import BSC, SSSC
+    g = load_golden("recon_%s.npz" % algo)
+    D, H, S = int(g["D"]), int(g["H"]), int(g["S"])
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    Y, x = g["Y"], g["x"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool), "x": x}
+    model = (BSC if algo == "ebsc" else SSSC)(D, H, S, engine=engine, device_mstep=device_mstep)
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in keys}
+    for k in ("pi", "sigma", "sigma2"):
+        if k in theta:
+            theta[k] = np.float64(theta[k])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data, do_reconstruction=True)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-9)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t])
+        want = g["t%d_y_reconstructed" % t]
+        got = my_data["y_reconstructed"]
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())))
+        assert np.array_equal(got[x], Y[x])

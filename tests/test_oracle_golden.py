@@ -163,3 +163,27 @@ def test_full_free_energy():
     th = {k: g["es3c_" + k] for k in SSSC_KEYS}
     th["sigma2"] = np.float64(th["sigma2"])
     np.testing.assert_allclose(orc.sssc_free_energy_full(th, suff, g["es3c_Y"]), float(g["es3c_L"]), rtol=1e-13)
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_reconstruction_replay(algo):
+    """step(..., do_reconstruction=True) on complete data (_models.py:193-194,614-665; sssc.py:500-507,
+    613-627): the oracle's y_reconstructed against the reference's, two chained steps."""
+    g = load_golden("recon_%s.npz" % algo)
+    H = int(g["H"])
+    Y, x = g["Y"], g["x"]
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    theta = theta_in(g, 0, keys)
+    suff = suff_from_fixture(g, unpack_bits(g["t0_ss_in"], H))
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        if algo == "ebsc":
+            F, nu, nsub, theta, sums = orc.bsc_step(theta, suff, Y, reconstruct_x=x)
+        else:
+            F, nu, nsub, theta, sums = orc.sssc_step(theta, suff, Y, reconstruct_x=x)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-13)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t])
+        want = g["t%d_y_reconstructed" % t]
+        np.testing.assert_allclose(sums["y_reconstructed"], want, rtol=1e-11, atol=1e-12)
+        assert np.array_equal(sums["y_reconstructed"][x], Y[x])          # kept entries untouched
+        assert np.array_equal(sums["y_reconstructed"][1], Y[1])          # x[1] all True
