@@ -52,6 +52,59 @@ def shard(array, rank, size):
     return array[b[rank]:b[rank + 1]]
 
 
+_DTYPES = (np.float64, np.float32, np.int64, np.int32, np.int16, np.uint8, np.bool_, np.uint16, np.uint32, np.uint64)
+
+
+def _sum_array(comm, a):
+    """Element-wise sum over ranks of a float64 array through whatever the communicator offers."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if hasattr(comm, "allreduce_array"):
+        return np.asarray(comm.allreduce_array(a)).reshape(a.shape)
+    return np.asarray(comm.allreduce(a)).reshape(a.shape)  # mpi4py: pickle path, op = SUM
+
+
+def scatter_to_processes(to_scatter, comm=None):
+    """Split an array that lives on rank 0 into np.array_split blocks along axis 0 and hand rank r
+    block r (parallel.py:117-151: get_chunk_dimensions + Scatterv).  Non-root ranks may pass None.
+    The communicators here expose sums only, so shape, dtype and payload travel as zero-padded
+    contributions of rank 0 (one-off data ingest, not a hot path).  Values must be exactly
+    representable in float64 (every dtype the reference's typemap lists except 64-bit integers
+    beyond 2^53)."""
+    comm = comm or SerialComm()
+    if comm.size == 1:
+        return np.array(to_scatter)
+    root = comm.rank == 0
+    meta = np.zeros(10)
+    if root:
+        a = np.asarray(to_scatter)
+        assert a.ndim <= 8
+        meta[0] = [np.dtype(d) for d in _DTYPES].index(a.dtype)
+        meta[1] = a.ndim
+        meta[2:2 + a.ndim] = a.shape
+    meta = _sum_array(comm, meta)
+    dtype = np.dtype(_DTYPES[int(meta[0])])
+    shape = tuple(int(v) for v in meta[2:2 + int(meta[1])])
+    payload = np.asarray(to_scatter, dtype=np.float64) if root else np.zeros(shape)
+    full = _sum_array(comm, payload)
+    return np.ascontiguousarray(shard(full, comm.rank, comm.size)).astype(dtype)
+
+
+def gather_from_processes(chunk, comm=None):
+    """Concatenate the per-rank blocks along axis 0 in rank order (parallel.py:154-173: Gatherv).
+    Every rank receives the gathered array (the reference fills it on rank 0 only)."""
+    comm = comm or SerialComm()
+    chunk = np.asarray(chunk)
+    if comm.size == 1:
+        return chunk.copy()
+    counts = np.zeros(comm.size)
+    counts[comm.rank] = chunk.shape[0]
+    counts = _sum_array(comm, counts).astype(np.int64)
+    starts = np.concatenate(([0], np.cumsum(counts)))
+    full = np.zeros((int(starts[-1]),) + chunk.shape[1:])
+    full[starts[comm.rank]:starts[comm.rank + 1]] = chunk
+    return _sum_array(comm, full).astype(chunk.dtype)
+
+
 class SerialComm:
     rank = 0
     size = 1

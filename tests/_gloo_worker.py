@@ -80,6 +80,15 @@ def main():
     # scalar / object paths of the communicator
     assert comm.allreduce(3) == 3 * world and abs(comm.allreduce(0.5) - 0.5 * world) < 1e-15
     assert comm.bcast({"a": rank}, root=0) == {"a": 0}
+    # data ingest / egress helpers (parallel.py:88-173): np.array_split blocks out, same array back
+    full = g["Y"] if rank == 0 else None
+    mine = parallel.scatter_to_processes(full, comm)
+    np.testing.assert_array_equal(mine, np.array_split(g["Y"], world)[rank])
+    bits = unpack_bits(g["t0_ss_in"], H)
+    mine_b = parallel.scatter_to_processes(bits if rank == 0 else None, comm)
+    assert mine_b.dtype == np.bool_ and np.array_equal(mine_b, np.array_split(bits, world)[rank])
+    back = parallel.gather_from_processes(mine, comm)
+    np.testing.assert_array_equal(back, g["Y"])
     comm.Barrier()
     dist.destroy_process_group()
     print("rank %d ok (F-part %s)" % (rank, F))

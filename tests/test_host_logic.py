@@ -245,3 +245,12 @@ def test_rendezvous_file_roundtrip(tmp_path, monkeypatch):
     assert parallel.rendezvous_unique_id(0, 1, lambda: uid) == uid  # single rank: no file
     with pytest.raises(TimeoutError):
         parallel.rendezvous_unique_id(1, 2, lambda: b"", tag="never", timeout_s=0.2)
+
+
+def test_scatter_gather_single_rank():
+    """parallel.py:117-173 on one rank: identity."""
+    from evo_amd.utils import parallel
+    a = np.arange(12.0).reshape(6, 2)
+    b = parallel.scatter_to_processes(a)
+    assert np.array_equal(a, b) and b is not a
+    assert np.array_equal(parallel.gather_from_processes(b), a)
