@@ -46,7 +46,7 @@ EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector peak
 # dominant kernel per model (the pass over all N x S resident states) as rocprofv3 names it
-ROOFLINE_KERNEL = {"es3c": "void sssc_main_lpj_kernel<0, 512, 2>", "ebsc": "void bsc_lpj_gram2_kernel<0, HW>"}
+ROOFLINE_KERNEL = {"es3c": "void sssc_main_lpj_kernel<0, 512, 2, 2>", "ebsc": "void bsc_lpj_gram2_kernel<0, HW>"}
 
 
 def pmc_traffic(config, kernel):

@@ -936,7 +936,7 @@ static int zero_lists(evoamd_ctx *c) {
   return 0;
 }
 
-#define MAIN_LPJ_LDS_MAX (40 * 1024)  // four 512-thread workgroups per CU
+#define MAIN_LPJ_LDS_MAX (48 * 1024)  // three 512-thread workgroups (3072 pairs) per CU at the limit
 
 template <int TAG>
 static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const bool need[3]) {
@@ -953,18 +953,19 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     // 512-thread workgroups: measured 13.8-17.5 us without overflow and 20.0 us at 8 % overflow on
     // the c2 shape (256: 13.0 / 24.3 us, 1024: 16.3 / 20.5 us).  The B rows of the workgroup's
     // datapoints (and the per-latent table while it is small) are staged in LDS when they fit.
-    const int rows_cap = 512 / a.C + 2;
+    // two pairs per thread: 1024 pairs per workgroup
+    const int rows_cap = 1024 / a.C + 2;
     const int stage_dg = a.H <= 512;
     const size_t lds = ((size_t)rows_cap * a.H + (stage_dg ? (size_t)4 * a.H : 0)) * sizeof(double);
-    const int grid = (int)cdiv(total, 512);
+    const int grid = (int)cdiv(total, 1024);
     if (!a.shared && (a.H % 2) == 0 && lds <= MAIN_LPJ_LDS_MAX) {
       switch (a.HW) {
-        case 1: sssc_main_lpj_kernel<TAG, 512, 1><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
-        case 2: sssc_main_lpj_kernel<TAG, 512, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
-        case 4: sssc_main_lpj_kernel<TAG, 512, 4><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
-        case 8: sssc_main_lpj_kernel<TAG, 512, 8><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
-        case 16: sssc_main_lpj_kernel<TAG, 512, 16><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
-        default: sssc_main_lpj_kernel<TAG, 512, 0><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 1: sssc_main_lpj_kernel<TAG, 512, 1, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 2: sssc_main_lpj_kernel<TAG, 512, 2, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 4: sssc_main_lpj_kernel<TAG, 512, 4, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 8: sssc_main_lpj_kernel<TAG, 512, 8, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        case 16: sssc_main_lpj_kernel<TAG, 512, 16, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+        default: sssc_main_lpj_kernel<TAG, 512, 0, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
       }
     } else
       sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1);

@@ -400,181 +400,6 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
   }
 }
 
-// block_append in two halves so that the global reservation (one returning atomic per workgroup,
-// 2-3 us under load) overlaps with the evaluation instead of stalling every wave at a barrier.
-// append_begin: LDS compaction, then thread 0 issues the atomic and parks the result in ctl[1].
-// append_end (every thread, after the evaluation): barrier, copy the compacted entries out.
-template <int BS>
-__device__ __forceinline__ void append_begin(const ListOut &lo, int shard, int value, bool over, int *buf, int *ctl) {
-  if (threadIdx.x == 0) ctl[0] = 0;
-  __syncthreads();
-  const u64 mask = __ballot(over);
-  if (mask != 0ull) {
-    const int lane = lane_id();
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&ctl[0], __popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (over) buf[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int n = ctl[0];
-    ctl[1] = n ? atomicAdd(&lo.counts[shard], n) : 0;
-  }
-}
-template <int BS>
-__device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl) {
-  __syncthreads();
-  const int n = ctl[0], start = ctl[1];
-  if (n == 0 || start < 0 || start + n > lo.cap) return;  // never write past the shard
-  const i64 dst = (i64)shard * lo.cap + start;
-  for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
-}
-
-// Main lpj pass in natural order.  A workgroup owns BS consecutive (n, state) pairs, i.e. at most
-// BS / C + 2 consecutive datapoints.  What bounds this pass is neither HBM nor arithmetic but the
-// dependent-latency chain of a workgroup times the number of workgroups a CU can hold (measured at
-// H = 512: ~10 us per workgroup generation, 2 workgroups per CU), so the kernel is built to keep
-// that chain short and the LDS footprint small:
-//   * the state words go straight to registers with 16-byte loads (HWT = words per state, a
-//     template parameter so the registers are indexed statically); per-lane 8-byte loads cost a
-//     full pass of the address coalescer per word;
-//   * the rows of B = Y W of the workgroup's datapoints (one contiguous chunk) and the singleton
-//     table D1 are staged in LDS by coalesced loads issued together with the state loads;
-//   * everything that depends on the active set only (log-determinant, Lam = T^-1 Psi) comes from
-//     the tables of sssc_tables_kernel: the per-pair work is two gathers and ~25 flops;
-//   * states with k > 2 are compacted into the overflow list; the workgroup's global reservation
-//     overlaps with the evaluation (append_begin / append_end).
-// Dynamic LDS: rows_cap x H doubles, then H double4 if `stage_dg`.  HWT == 0: any HW, word loop.
-template <int TAG, int BS, int HWT>
-__global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut lo, int rows_cap, int stage_dg) {
-  a.s2inv = a.dpar[DP_S2INV];
-  extern __shared__ double smem[];
-  __shared__ int ovf_buf[BS];
-  __shared__ int ovf_ctl[2];
-  double *Bs = smem;
-  double4 *DGs = (double4 *)(smem + (size_t)rows_cap * a.H);
-  const i64 total = a.N * (i64)a.C;
-  const i64 t0 = (i64)blockIdx.x * BS;
-  const i64 t = t0 + threadIdx.x;
-  const i64 n_first = t0 / a.C;
-  i64 n_last = (t0 + BS - 1) / a.C;
-  if (n_last > a.N - 1) n_last = a.N - 1;
-  const int rows = (int)(n_last - n_first + 1);  // <= rows_cap by construction (host)
-  bool live = t < total;
-  i64 n = 0;
-  int c = 0, ktot = 0, idx0 = 0, idx1 = 0;  // idx0 < idx1: the active latents when ktot <= 2
-  constexpr int NW = HWT > 0 ? HWT : 1;
-  u64 w[NW];
-#pragma unroll
-  for (int i = 0; i < NW; i++) w[i] = 0;
-  const u64 *sp = nullptr;
-  if (live) {
-    // t = n C + c with n_first <= n <= n_first + rows: short search instead of a 32-bit division
-    const int off = (int)(t - n_first * a.C);  // < C + BS
-    int r = (int)(((float)off + 0.5f) * (1.0f / (float)a.C));
-    if (r * a.C > off) r--;
-    if ((r + 1) * a.C <= off) r++;
-    n = n_first + r;
-    c = off - r * a.C;
-    live = !(a.counts && c >= a.counts[n]);
-  }
-  if (live) {
-    sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
-    if (HWT == 1) {
-      w[0] = sp[0];
-    } else if (HWT > 1) {
-      const ulonglong2 *sp2 = (const ulonglong2 *)sp;  // HWT is even: 16-byte aligned
-#pragma unroll
-      for (int i = 0; i < NW / 2; i++) {
-        const ulonglong2 v = sp2[i];
-        w[2 * i] = v.x;
-        w[2 * i + 1] = v.y;
-      }
-    }
-    // popcount and the (at most two) active latents, MSB-first, without divergent bit loops; done
-    // here so that the state words are dead before the barriers
-    if (HWT > 0) {
-#pragma unroll
-      for (int i = 0; i < NW; i++) {
-        const u64 bits = w[i];
-        const int cw = __popcll(bits);
-        const int h0 = __clzll((long long)bits);
-        const u64 rest = bits & ~(0x8000000000000000ull >> (h0 & 63));
-        const int h1 = __clzll((long long)rest);
-        if (cw >= 1) {
-          if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
-        }
-        if (cw >= 2 && ktot == 0) idx1 = i * 64 + h1;
-        ktot += cw;
-      }
-    } else {
-      for (int i = 0; i < a.HW; i++) {
-        const u64 bits = sp[i];
-        const int cw = __popcll(bits);
-        if (cw) {
-          const int h0 = __clzll((long long)bits);
-          if (ktot == 0) idx0 = i * 64 + h0; else idx1 = i * 64 + h0;
-          if (cw >= 2 && ktot == 0) idx1 = i * 64 + __clzll((long long)(bits & ~(0x8000000000000000ull >> h0)));
-          ktot += cw;
-        }
-      }
-    }
-  }
-  {  // stage B rows n_first .. n_last (contiguous) and the singleton table
-    const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
-    double2 *dst = (double2 *)Bs;
-    const int n2 = rows * a.H / 2;
-    for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
-    if (stage_dg)
-      for (int i = threadIdx.x; i < a.H; i += BS) DGs[i] = a.D1[i];
-  }
-  const double yyn = live ? a.yy[n] : 0.0;
-  const bool over = live && ktot > 2;
-  const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
-  append_begin<BS>(lo, shard, (int)t, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
-  if (live && !over) {
-    const int k = ktot;
-    const double *Bn = Bs + (size_t)(n - n_first) * a.H;
-    const double4 *D1t = stage_dg ? DGs : a.D1;
-    // identity padding makes the k = 2 expressions exact for k < 2
-    double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
-    double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
-    if (k >= 1) {
-      d0 = D1t[idx0];
-      b0 = Bn[idx0];
-      L = d0.y;
-      l00 = d0.w;
-    }
-    if (k == 2) {
-      d1 = D1t[idx1];
-      b1 = Bn[idx1];
-      const PairEntry pe = a.PT[(i64)idx0 * a.H + idx1];  // idx0 < idx1
-      g01 = pe.g01;
-      L = pe.L;
-      l00 = pe.l00;
-      l01 = pe.l01;
-      l10 = pe.l10;
-      l11 = pe.l11;
-      if (pe.singular != 0.0) atomicOr(a.err, 2);
-    }
-    const double s = a.s2inv;
-    const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
-    const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
-    const double rr = yyn - d0.x * (b0 + v0) - d1.x * (b1 + v1);
-    const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
-    const double val = L - 0.5 * s * (rr - s * quad);
-    unsigned fl = 0;
-    a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
-    if (fl) {
-      atomicOr(&a.flags[n], fl);
-      atomicOr(&a.err[1], 1);
-    }
-  }
-  append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
-}
-
 // Loads the HWT state words of one state with 16-byte loads and returns popcount and the first two
 // active latents (MSB-first); HWT == 0: runtime word loop.  Shared by the main lpj and statistics
 // kernels.
@@ -620,6 +445,169 @@ __device__ __forceinline__ void load_state_k2(const u64 *sp, int HW, int &ktot, 
       }
     }
   }
+}
+
+// block_append in two halves so that the global reservation (one returning atomic per workgroup,
+// 2-3 us under load) overlaps with the evaluation instead of stalling every wave at a barrier.
+// append_begin: LDS compaction, then thread 0 issues the atomic and parks the result in ctl[1].
+// append_end (every thread, after the evaluation): barrier, copy the compacted entries out.
+template <int BS, int PPT = 1>
+__device__ __forceinline__ void append_begin(const ListOut &lo, int shard, const int (&value)[PPT],
+                                             const bool (&over)[PPT], int *buf /* LDS BS * PPT */, int *ctl) {
+  if (threadIdx.x == 0) ctl[0] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const u64 mask = __ballot(over[p]);
+    if (mask != 0ull) {
+      const int lane = lane_id();
+      const int leader = __ffsll((long long)mask) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&ctl[0], __popcll(mask));
+      base = __shfl(base, leader, 64);
+      if (over[p]) buf[base + __popcll(mask & ((1ull << lane) - 1ull))] = value[p];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = ctl[0];
+    ctl[1] = n ? atomicAdd(&lo.counts[shard], n) : 0;
+  }
+}
+template <int BS>
+__device__ __forceinline__ void append_begin(const ListOut &lo, int shard, int value, bool over, int *buf, int *ctl) {
+  const int v[1] = {value};
+  const bool o[1] = {over};
+  append_begin<BS, 1>(lo, shard, v, o, buf, ctl);
+}
+template <int BS>
+__device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl) {
+  __syncthreads();
+  const int n = ctl[0], start = ctl[1];
+  if (n == 0 || start < 0 || start + n > lo.cap) return;  // never write past the shard
+  const i64 dst = (i64)shard * lo.cap + start;
+  for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
+}
+
+// Main lpj pass in natural order.  A workgroup owns BS consecutive (n, state) pairs, i.e. at most
+// BS / C + 2 consecutive datapoints.  What bounds this pass is neither HBM nor arithmetic but the
+// dependent-latency chain of a workgroup times the number of workgroups a CU can hold (measured at
+// H = 512: ~10 us per workgroup generation, 2 workgroups per CU), so the kernel is built to keep
+// that chain short and the LDS footprint small:
+//   * the state words go straight to registers with 16-byte loads (HWT = words per state, a
+//     template parameter so the registers are indexed statically); per-lane 8-byte loads cost a
+//     full pass of the address coalescer per word;
+//   * the rows of B = Y W of the workgroup's datapoints (one contiguous chunk) and the singleton
+//     table D1 are staged in LDS by coalesced loads issued together with the state loads;
+//   * everything that depends on the active set only (log-determinant, Lam = T^-1 Psi) comes from
+//     the tables of sssc_tables_kernel: the per-pair work is two gathers and ~25 flops;
+//   * states with k > 2 are compacted into the overflow list; the workgroup's global reservation
+//     overlaps with the evaluation (append_begin / append_end).
+// Dynamic LDS: rows_cap x H doubles, then H double4 if `stage_dg`.  HWT == 0: any HW, word loop.
+// PPT = (n, state) pairs per thread (pair p of a thread is t0 + threadIdx.x + p BS: coalesced per
+// p).  With one pair per thread the c2 launch is 1.22 "rounds" of resident threads (640k pairs on
+// 256 x 2048 slots) and its tail round costs as much as the full one; two pairs per thread make it a
+// single round with twice the loads in flight per wave.
+template <int TAG, int BS, int HWT, int PPT>
+__global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut lo, int rows_cap, int stage_dg) {
+  a.s2inv = a.dpar[DP_S2INV];
+  extern __shared__ double smem[];
+  __shared__ int ovf_buf[BS * PPT];
+  __shared__ int ovf_ctl[2];
+  double *Bs = smem;
+  double4 *DGs = (double4 *)(smem + (size_t)rows_cap * a.H);
+  const i64 total = a.N * (i64)a.C;
+  const i64 t0 = (i64)blockIdx.x * (BS * PPT);
+  const i64 n_first = t0 / a.C;
+  i64 n_last = (t0 + BS * PPT - 1) / a.C;
+  if (n_last > a.N - 1) n_last = a.N - 1;
+  const int rows = (int)(n_last - n_first + 1);  // <= rows_cap by construction (host)
+  bool live[PPT], over[PPT];
+  int nloc[PPT], c[PPT], ktot[PPT], idx0[PPT], idx1[PPT], tv[PPT];
+  double yyn[PPT];
+  const float rC = 1.0f / (float)a.C;
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    const i64 t = t0 + threadIdx.x + (i64)p * BS;
+    tv[p] = (int)t;
+    live[p] = t < total;
+    nloc[p] = c[p] = ktot[p] = idx0[p] = idx1[p] = 0;
+    yyn[p] = 0.0;
+    if (live[p]) {
+      // t = n C + c with n_first <= n <= n_first + rows: float quotient, then exact
+      const int off = (int)(t - n_first * a.C);  // < C + BS PPT
+      int r = (int)(((float)off + 0.5f) * rC);
+      if (r * a.C > off) r--;
+      if ((r + 1) * a.C <= off) r++;
+      nloc[p] = r;
+      c[p] = off - r * a.C;
+      live[p] = !(a.counts && c[p] >= a.counts[n_first + r]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (live[p]) {
+      const i64 n = n_first + nloc[p];
+      // popcount and the (at most two) active latents right after the loads, so that the state
+      // words are dead before the barriers
+      load_state_k2<HWT>(a.states + ((a.shared ? 0 : n * (i64)a.C) + c[p]) * a.HW, a.HW, ktot[p], idx0[p], idx1[p]);
+      yyn[p] = a.yy[n];
+    }
+    over[p] = live[p] && ktot[p] > 2;
+  }
+  {  // stage B rows n_first .. n_last (contiguous) and the singleton table
+    const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
+    double2 *dst = (double2 *)Bs;
+    const int n2 = rows * a.H / 2;
+    for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
+    if (stage_dg)
+      for (int i = threadIdx.x; i < a.H; i += BS) DGs[i] = a.D1[i];
+  }
+  const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
+  append_begin<BS, PPT>(lo, shard, tv, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
+  const double4 *D1t = stage_dg ? DGs : a.D1;
+  const double s = a.s2inv;
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (live[p] && !over[p]) {
+      const int k = ktot[p];
+      const double *Bn = Bs + (size_t)nloc[p] * a.H;
+      // identity padding makes the k = 2 expressions exact for k < 2
+      double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
+      double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
+      if (k >= 1) {
+        d0 = D1t[idx0[p]];
+        b0 = Bn[idx0[p]];
+        L = d0.y;
+        l00 = d0.w;
+      }
+      if (k == 2) {
+        d1 = D1t[idx1[p]];
+        b1 = Bn[idx1[p]];
+        const PairEntry pe = a.PT[(i64)idx0[p] * a.H + idx1[p]];  // idx0 < idx1
+        g01 = pe.g01;
+        L = pe.L;
+        l00 = pe.l00;
+        l01 = pe.l01;
+        l10 = pe.l10;
+        l11 = pe.l11;
+        if (pe.singular != 0.0) atomicOr(a.err, 2);
+      }
+      const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
+      const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
+      const double rr = yyn[p] - d0.x * (b0 + v0) - d1.x * (b1 + v1);
+      const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
+      const double val = L - 0.5 * s * (rr - s * quad);
+      unsigned fl = 0;
+      const i64 n = n_first + nloc[p];
+      a.lpj_out[n * a.ldo + a.col0 + c[p]] = clamp_lpj(val, fl);
+      if (fl) {
+        atomicOr(&a.flags[n], fl);
+        atomicOr(&a.err[1], 1);
+      }
+    }
+  }
+  append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
 }
 
 // Main statistics pass over the resident K^n (sssc.py:553-611): workgroups own whole datapoints
