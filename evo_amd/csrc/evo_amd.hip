@@ -615,7 +615,8 @@ static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const do
 
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
-                          int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1) {
+                          int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1,
+                          bool c_is_zero = false) {
   // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of the
   // tile size): only its upper tiles are computed, the rest is mirrored
   const bool vec = gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (M % 2) == 0 && (Nc % 2) == 0 && M >= 2 && Nc >= 2;
@@ -648,7 +649,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
   if (split) {
     kps = (K + splits - 1) / splits;
     kps = ((kps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-    HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
+    if (!c_is_zero) HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
   }
   const unsigned grid = (unsigned)(tiles * (split ? splits : 1));
   SpanGuard g(c, KID_GEMM);
@@ -761,10 +762,8 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   }
   int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
   if (r) return r;
-  interleave_gp_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, (i64)H * H, c->GP, H, c->mus,
-                                                                      c->pilbar_v, c->DG);
   sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
-                                                                     c->PT);
+                                                                     c->PT, c->GP, c->DG);
   HIP_TRY(hipGetLastError());
   c->B_valid = false;
   if (c->have_data) {
@@ -1330,7 +1329,8 @@ static int stats_compute(evoamd_ctx *c) {
                                                                        c->partial2, cdiv(N, 4), c->acc + a.sigma);
       HIP_TRY(hipGetLastError());
     }
-    r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N);  // Wp = Es^T Y  (H,D)
+    r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N, false, -1,
+                       /*c_is_zero=*/true);  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
     if (r) return r;
   } else {
     double *Es = c->Y + D, *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed]
@@ -1412,7 +1412,8 @@ static int stats_compute(evoamd_ctx *c) {
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
     // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
     r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
-                       ((D + H) % GEMM_BM) == 0 ? D + H : -1);  // launch_gemm_tn drops the hint if its tile does not divide it
+                       ((D + H) % GEMM_BM) == 0 ? D + H : -1,  // launch_gemm_tn drops the hint if its tile does not divide it
+                       /*c_is_zero=*/true);                    // acc was cleared at the top of stats_compute
     if (r) return r;
   }
   {
@@ -1543,13 +1544,9 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
   if (c->model == EVOAMD_MODEL_SSSC) {
     // mus / pies first (Psi needs the NEW mus, sssc.py:733), then both H x H inverses in one launch:
     // tmpA <- xpt_szsz (for W, sssc.py:693), tmpB <- xpt_ss + eps I (for Psi, sssc.py:738)
-    sssc_update_vectors_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, Nptr, H, learn,
-                                                                    c->pies, c->mus);
-    if (learn & L_W)
-      HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.xszsz, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    if (learn & L_PSI)
-      sssc_psi_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->mus, c->acc + a.xss, c->acc + a.xszsz,
-                                                                    c->acc + a.s_sz, H, c->tmpC, c->tmpB);
+    sssc_mstep_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, c->acc + a.xss,
+                                                                    c->acc + a.xszsz, c->acc + a.s_sz, Nptr, H, learn,
+                                                                    c->pies, c->mus, c->tmpA, c->tmpC, c->tmpB);
     if ((learn & L_W) && (learn & L_PSI))
       r = launch_inverse(c, c->tmpA, c->tmpB, H, force_pivot);
     else if (learn & L_W)
@@ -1573,8 +1570,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, n_part, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar);
-    interleave_gp_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, HH, c->GP, H, c->mus, c->pilbar_v, c->DG);
-    sssc_tables_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1, c->PT);
+    sssc_tables_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1, c->PT,
+                                                             c->GP, c->DG);
     HIP_TRY(hipGetLastError());
     r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
     if (r) return r;

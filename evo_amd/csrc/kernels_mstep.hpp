@@ -843,42 +843,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict
 #define L_PI 2     // BSC
 #define L_SIGMA 8  // BSC
 
-// pies, mus (sssc.py:712-727) + check_params clamp of pies (tol = 1e-5).  One thread per h.
-__global__ __launch_bounds__(256) void sssc_update_vectors_kernel(const double *__restrict__ xs,
-                                                                  const double *__restrict__ xsz,
-                                                                  const double *__restrict__ Nptr, int H, int learn,
-                                                                  double *__restrict__ pies, double *__restrict__ mus) {
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= H) return;
-  const double N = *Nptr;
-  if (learn & L_PIES) {
-    double p = xs[h] / N;
-    if (p <= 5e-5) p = 5e-5;                // eps_pies
-    if (p >= 1.0 - 5e-5) p = 1.0 - 5e-5;
-    pies[h] = p;
-  }
-  if (learn & L_MUS) mus[h] = xsz[h] * 1.0 / (xs[h] + 2.220446049250313e-16);  // eps_mus
-  double p = pies[h];                        // check_params: pies in [tol, 1 - tol]
-  p = fmax(1e-5, p);
-  p = fmin(1.0 - 1e-5, p);
-  pies[h] = p;
-}
-
-// Psi_raw = mus mus^T * xss + xszsz - 2 mus[:,None] * s_sz  and  T2 = xss + eps I (sssc.py:732-738)
-__global__ __launch_bounds__(256) void sssc_psi_prepare_kernel(const double *__restrict__ mus,
-                                                               const double *__restrict__ xss,
-                                                               const double *__restrict__ xszsz,
-                                                               const double *__restrict__ s_sz, int H,
-                                                               double *__restrict__ psi_raw, double *__restrict__ T2) {
+// Start of the ES3C Theta update in one launch (sssc.py:711-738): pies (clipped, sssc.py:716-720), mus =
+// xpt_sz / (xpt_s + eps) (sssc.py:726), a copy of xpt_szsz for the in-place inverse, and
+//   Psi_raw = mus mus^T * xss + xszsz - 2 mus[:,None] * s_sz,   T2 = xss + eps I   (sssc.py:732-738).
+// Thread (i, j) recomputes the two mus it needs from the accumulator (was three ~5 us launches).
+__global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
+    const double *__restrict__ xs, const double *__restrict__ xsz, const double *__restrict__ xss,
+    const double *__restrict__ xszsz, const double *__restrict__ s_sz, const double *__restrict__ Nptr, int H, int learn,
+    double *__restrict__ pies, double *__restrict__ mus, double *__restrict__ xszsz_copy,
+    double *__restrict__ psi_raw, double *__restrict__ T2) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
-  double v = 0.0;
-  v += (mus[i] * mus[j]) * xss[t];
-  v += xszsz[t];
-  v -= 2 * mus[i] * s_sz[t];
-  psi_raw[t] = v;
-  T2[t] = xss[t] + ((i == j) ? 1e-5 : 0.0);
+  const bool lm = (learn & L_MUS) != 0;
+  const double mi = lm ? xsz[i] * 1.0 / (xs[i] + 2.220446049250313e-16) : mus[i];  // eps_mus
+  const double mj = lm ? xsz[j] * 1.0 / (xs[j] + 2.220446049250313e-16) : mus[j];
+  if (learn & L_W) xszsz_copy[t] = xszsz[t];
+  if (learn & L_PSI) {
+    double v = 0.0;
+    v += (mi * mj) * xss[t];
+    v += xszsz[t];
+    v -= 2 * mi * s_sz[t];
+    psi_raw[t] = v;
+    T2[t] = xss[t] + ((i == j) ? 1e-5 : 0.0);
+  }
+  if (j == 0) {  // the vectors, one thread per latent (after every read of mus[] in this thread)
+    const double N = *Nptr;
+    double p = pies[i];
+    if (learn & L_PIES) {
+      p = xs[i] / N;
+      if (p <= 5e-5) p = 5e-5;  // eps_pies
+      if (p >= 1.0 - 5e-5) p = 1.0 - 5e-5;
+    }
+    p = fmax(1e-5, p);  // check_params: pies in [tol, 1 - tol]
+    p = fmin(1.0 - 1e-5, p);
+    pies[i] = p;
+    if (lm) mus[i] = mi;
+  }
 }
 
 // Psi = Psi_raw * inv(T2) element-wise (the reference's quirk Q2), then check_params' diagonal floor

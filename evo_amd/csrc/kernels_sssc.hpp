@@ -937,21 +937,24 @@ __global__ __launch_bounds__(256) void set_diag_kernel(double *__restrict__ M, c
   if (h < H) M[(i64)h * H + h] = d[h];
 }
 
-// GP[i][j] = {G[i][j], Psi[i][j]}
 // Tables of the state terms for |A| <= 2 (one thread per ordered pair h0 <= h1); with T = I + Psi_A
 // G_A / sigma2 (file header): L = sum pil_bar - log|det T| / 2 and Lam = T^-1 Psi_A.  Runs once per
-// Theta (H^2 / 2 tiny systems) instead of once per (datapoint, state) pair.
+// Theta (H^2 / 2 tiny systems) instead of once per (datapoint, state) pair.  Also writes the
+// interleaved GP[i][j] = {G_ij, Psi_ij} and DG[h] = {mu_h, pil_bar_h, G_hh, Psi_hh} of the k > 2 levels.
 __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restrict__ G, const double *__restrict__ Psi,
                                                           const double *__restrict__ mus,
                                                           const double *__restrict__ pil_bar,
                                                           const double *__restrict__ dpar, int H,
-                                                          double4 *__restrict__ D1, PairEntry *__restrict__ PT) {
+                                                          double4 *__restrict__ D1, PairEntry *__restrict__ PT,
+                                                          double2 *__restrict__ GP, double4 *__restrict__ DG) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int h0 = (int)(t / H), h1 = (int)(t - (i64)h0 * H);
   const double s = dpar[DP_S2INV];
+  GP[t] = make_double2(G[t], Psi[t]);  // {G_ij, Psi_ij} as one 16-byte element for the k > 2 levels
   if (h0 == h1) {
     const double g = G[t], p = Psi[t];
+    DG[h0] = make_double4(mus[h0], pil_bar[h0], g, p);
     const double T = 1.0 + s * p * g;
     D1[h0] = make_double4(mus[h0], pil_bar[h0] - 0.5 * log(fabs(T)), g, p / T);
     return;
@@ -977,13 +980,3 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
   PT[t] = e;
 }
 
-__global__ __launch_bounds__(256) void interleave_gp_kernel(const double *__restrict__ G,
-                                                            const double *__restrict__ Psi, i64 n,
-                                                            double2 *__restrict__ GP, int H,
-                                                            const double *__restrict__ mus,
-                                                            const double *__restrict__ pil_bar,
-                                                            double4 *__restrict__ DG) {
-  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) GP[i] = make_double2(G[i], Psi[i]);
-  if (i < H) DG[i] = make_double4(mus[i], pil_bar[i], G[i * H + i], Psi[i * H + i]);
-}
