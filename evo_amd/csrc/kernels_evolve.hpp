@@ -56,8 +56,7 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     key[q] = (s < S) ? row[s] : INFINITY;
     lmin = fmin(lmin, key[q]);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lmin = fmin(lmin, __shfl_xor(lmin, o, 64));
+  lmin = wave_min(lmin);
   const double shift = 2.0 * fmin(lmin, 0.0);
 #pragma unroll
   for (int q = 0; q < SPL; q++) {
@@ -79,15 +78,10 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
         bv = key[q];
         bi = lane + 64 * q;
       }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const double v2 = __shfl_xor(bv, o, 64);
-      const int i2 = __shfl_xor(bi, o, 64);
-      if (v2 < bv || (v2 == bv && i2 < bi)) {
-        bv = v2;
-        bi = i2;
-      }
-    }
+    // lexicographic (key, index) minimum over the wave: DPP min of the key, then of the index among
+    // the lanes that hold it (a __shfl_xor butterfly on the pair is 18 LDS-latency permutes per round)
+    const double gv = wave_min(bv);
+    bi = (int)wave_min_u32((bv == gv) ? (unsigned)bi : 0xFFFFFFFFu);
     if (lane == 0) sel[j] = bi;
     if ((bi & 63) == lane) {
 #pragma unroll
