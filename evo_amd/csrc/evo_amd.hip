@@ -634,8 +634,22 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
   i64 splits = 1;
   if (K >= 128 && !deterministic) {
     if (big) {
+      // tiles that really run (the strictly lower tiles of a symmetric block exit at once)
+      i64 real = tiles;
+      if (sym_row0 >= 0) {
+        const i64 ts = cdiv(Nc, T);
+        real -= ts * (ts - 1) / 2;
+      }
+      // chunks per XCD: the fullest last round of the 64 resident workgroups of an XCD
       i64 per_xcd = 1;
-      while (per_xcd < 16 && (double)(tiles * per_xcd) / (64.0 * (double)cdiv(tiles * per_xcd, 64)) < 0.9) per_xcd++;
+      double best = 0.0;
+      for (i64 pc = 1; pc <= 16; pc++) {
+        const double eff = (double)(real * pc) / (64.0 * (double)cdiv(real * pc, 64));
+        if (eff > best + 0.01) {
+          best = eff;
+          per_xcd = pc;
+        }
+      }
       splits = 8 * per_xcd;
     } else {
       splits = (512 + tiles - 1) / tiles;
