@@ -55,6 +55,9 @@ SIGNATURES = {
     "evoamd_stats": (_I, [_vp, _c_dp]),
     "evoamd_mstep_device": (_I, [_vp, _I, _c_dp, _c_dp]),
     "evoamd_reconstruct": (_I, [_vp, _c_dp]),
+    "evoamd_upload_masks": (_I, [_vp, _c_u8p, _c_u8p]),
+    "evoamd_upload_yrec": (_I, [_vp, _c_dp]),
+    "evoamd_lpj_single_masked": (_I, [_vp, _c_dp, _c_u8p, _c_u8p, _I, _c_dp, _c_i32p]),
     "evoamd_inverse": (_I, [_vp, _c_dp, _c_dp, _I, _c_dp]),
     "evoamd_gemm_tn": (_I, [_vp, _c_dp, _c_dp, _c_dp, _I64, _I, _I, _I]),
     "evoamd_get_params_bsc": (_I, [_vp, _c_dp, _c_dp, _c_dp]),

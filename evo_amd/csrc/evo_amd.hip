@@ -128,6 +128,9 @@ struct evoamd_ctx {
   int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
                      // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
+  uint8_t *mask_infr = nullptr, *mask_x = nullptr;  // EBSC incomplete data: reliable entries / entries that keep their value
+  double *Yrec = nullptr;       // y_reconstructed (N x D): what the M-step's Wp contraction reads then
+  bool yrec_valid = false, rec_in_stats = false;
   double *yhat = nullptr, *tmpWt = nullptr;  // reconstruction (N x D) and W^T scratch (ES3C)
   size_t yhat_n = 0;
   bool yhat_valid = false;
@@ -332,7 +335,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 static void free_all(evoamd_ctx *c) {
   void *ptrs[] = {c->Y,      c->yy,     c->y2sum,   c->states,  c->cand,     c->lpj,       c->cand_lpj,
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
-                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,
+                  c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states};
@@ -370,6 +373,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "bsc_direct") == 0) {
     c->bsc_direct = value != 0;
     c->have_params = false;  // G / B are (not) needed: set_params again
+    return 0;
+  }
+  if (strcmp(name, "reconstruct_in_stats") == 0) {  // one-shot: the next statistics pass forms y_reconstructed first
+    c->rec_in_stats = value != 0;
     return 0;
   }
   if (strcmp(name, "inverse_spd") == 0) {
@@ -544,6 +551,44 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_data = true;
   c->B_valid = false;
+  return 0;
+}
+
+extern "C" int evoamd_upload_masks(evoamd_ctx *c, const uint8_t *x_infr, const uint8_t *x) {
+  REQUIRE(c && c->configured && c->have_data, "configure and upload_data first");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!x_infr) {  // back to complete data (upload_data again restores entries that were zeroed)
+    if (c->mask_infr) (void)hipFree(c->mask_infr);
+    if (c->mask_x) (void)hipFree(c->mask_x);
+    c->mask_infr = c->mask_x = nullptr;
+    c->yrec_valid = false;
+    return 0;
+  }
+  REQUIRE(c->model == EVOAMD_MODEL_BSC, "incomplete data (x_infr) is implemented for EBSC only");
+  const size_t nd = (size_t)c->N * c->D;
+  ALLOC(c->mask_infr, nd);
+  ALLOC(c->mask_x, nd);
+  ALLOC(c->Yrec, nd);
+  HIP_TRY(hipMemcpyAsync(c->mask_infr, x_infr, nd, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->mask_x, x ? x : x_infr, nd, hipMemcpyHostToDevice, c->stream));
+  // missing entries (NaN in the reference's data) become zeros: they then drop out of ||y_obs||^2
+  mask_apply_kernel<<<cdiv((i64)nd, 256), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_infr, c->N, c->D);
+  row_sqnorm_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->yy);
+  HIP_TRY(hipMemsetAsync(c->y2sum, 0, (size_t)c->D * sizeof(double), c->stream));
+  launch_colsum<true>(c, c->Y, c->ldY, c->N, c->D, c->y2sum);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->yrec_valid = false;
+  c->B_valid = false;
+  return 0;
+}
+
+extern "C" int evoamd_upload_yrec(evoamd_ctx *c, const double *y_rec) {
+  REQUIRE(c && c->configured && c->mask_infr && y_rec, "upload_masks first");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->Yrec, y_rec, (size_t)c->N * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->yrec_valid = true;
   return 0;
 }
 
@@ -816,10 +861,11 @@ struct Batch {
   unsigned *flags;
   int kid;
   int tag;  // 0 resident K^n, 1 candidate batch, 2 anything else (names the kernel instantiation)
+  const uint8_t *mask = nullptr;  // EBSC incomplete data: x_infr rows of this batch's datapoints
 };
 
 static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
-  if (!c->bsc_direct && b.tag != 2) {
+  if (!c->bsc_direct && b.tag != 2 && !b.mask) {  // masked data: per-datapoint Gram matrices -> direct form
     const i64 total = b.N * (i64)b.C;
     unsigned grid = cdiv(total, 256);
     SpanGuard g(c, b.kid);
@@ -866,7 +912,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
   SpanGuard g(c, b.kid);
 #define BSC_LAUNCH(R)                                                                                     \
   bsc_lpj_kernel<R><<<grid, 256, 0, c->stream>>>(b.Y, c->Wt, b.states, b.counts, b.N, b.C, b.C, b.shared, \
-                                                  c->D, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
+                                                  c->D, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, b.mask)
   if (c->D <= 64)
     BSC_LAUNCH(1);
   else if (c->D <= 128)
@@ -1059,6 +1105,7 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
     HIP_TRY(hipGetLastError());
   }
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
+  b.mask = c->mask_infr;
   return launch_lpj(c, b);  // stream-ordered; device-side errors surface at the next host-returning call
 }
 
@@ -1069,6 +1116,7 @@ static int eval_candidates(evoamd_ctx *c) {
   }
   Batch b = {c->cand, c->cand_counts, c->Y, c->Bm, c->yy, c->N, c->Cmax, 0, c->cand_lpj, c->Cmax, 0,
              c->flags + c->N, KID_LPJ_CAND, 1};
+  b.mask = c->mask_infr;
   return launch_lpj(c, b);
 }
 
@@ -1152,6 +1200,7 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
     }
   }
   Batch b = {c->tmp_states, nullptr, c->Y, c->Bm, c->yy, c->N, C, 1, c->tmp_lpj, C, 0, c->flags + c->N, KID_MISC, 2};
+  b.mask = c->mask_infr;
   r = launch_lpj(c, b);
   if (!r) {
     hipError_t e = hipMemcpyAsync(lpj_out, c->tmp_lpj, (size_t)c->N * C * sizeof(double), hipMemcpyDeviceToHost,
@@ -1165,9 +1214,10 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
   return 0;
 }
 
-extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *states_bool, int C,
-                                 double *lpj_out, int32_t *flags_out) {
+static int lpj_single_impl(evoamd_ctx *c, const double *y, const uint8_t *x_infr, const uint8_t *states_bool, int C,
+                           double *lpj_out, int32_t *flags_out) {
   REQUIRE(c && c->configured && c->have_params, "configure and set_params first");
+  REQUIRE(!x_infr || c->model == EVOAMD_MODEL_BSC, "incomplete data: EBSC only");
   REQUIRE(y && states_bool && lpj_out && C > 0, "bad arguments");
   HIP_TRY(hipSetDevice(c->device));
   int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)C + 2);
@@ -1182,6 +1232,14 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
   double *dy = c->tmp_y, *db = c->tmp_y + c->D, *dyy = c->tmp_y + c->D + c->H;
   unsigned *dfl = (unsigned *)(c->tmp_lpj + C);
   HIP_TRY(hipMemcpyAsync(dy, y, (size_t)c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  uint8_t *dmask = nullptr;
+  if (x_infr) {  // one row of x_infr behind the packed states' staging area
+    r = ensure_stage(c, (size_t)C * c->H + c->D);
+    if (r) return r;
+    dmask = c->stage + (size_t)C * c->H;
+    HIP_TRY(hipMemcpyAsync(dmask, x_infr, (size_t)c->D, hipMemcpyHostToDevice, c->stream));
+    mask_apply_kernel<<<cdiv(c->D, 256), 256, 0, c->stream>>>(dy, c->D, dmask, 1, c->D);
+  }
   HIP_TRY(hipMemcpyAsync(c->stage, states_bool, (size_t)C * c->H, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(dfl, 0, sizeof(unsigned), c->stream));
   pack_states_kernel<<<cdiv((i64)C * c->HW, 256), 256, 0, c->stream>>>(c->stage, c->tmp_states, C, c->H, c->HW);
@@ -1191,6 +1249,7 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
     if (r) return r;
   }
   Batch b = {c->tmp_states, nullptr, dy, db, dyy, 1, C, 1, c->tmp_lpj, C, 0, dfl, KID_MISC, 2};
+  b.mask = dmask;
   r = launch_lpj(c, b);
   if (r) return r;
   unsigned fl = 0;
@@ -1204,6 +1263,17 @@ extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *
   }
   if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
   return 0;
+}
+
+extern "C" int evoamd_lpj_single(evoamd_ctx *c, const double *y, const uint8_t *states_bool, int C,
+                                 double *lpj_out, int32_t *flags_out) {
+  return lpj_single_impl(c, y, nullptr, states_bool, C, lpj_out, flags_out);
+}
+
+extern "C" int evoamd_lpj_single_masked(evoamd_ctx *c, const double *y, const uint8_t *x_infr,
+                                        const uint8_t *states_bool, int C, double *lpj_out, int32_t *flags_out) {
+  REQUIRE(x_infr, "x_infr is NULL");
+  return lpj_single_impl(c, y, x_infr, states_bool, C, lpj_out, flags_out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1299,6 +1369,8 @@ static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowma
 
 // Everything of evoamd_stats up to (and including) the all-reduce; the packed accumulator stays on
 // the device.  tail[7] receives ljc of the Theta the E-step ran with.
+static int compute_reconstruction(evoamd_ctx *c);
+
 static int stats_compute(evoamd_ctx *c) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
   HIP_TRY(hipSetDevice(c->device));
@@ -1343,7 +1415,22 @@ static int stats_compute(evoamd_ctx *c) {
                                                                        c->partial2, cdiv(N, 4), c->acc + a.sigma);
       HIP_TRY(hipGetLastError());
     }
-    r = launch_gemm_tn(c, c->Es, H, c->Y, c->ldY, c->acc + a.Wp, D, H, D, N, false, -1,
+    const double *Ywp = c->Y;
+    int ldwp = c->ldY;
+    if (c->mask_infr) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211)
+      if (c->rec_in_stats) {
+        r = compute_reconstruction(c);  // y_hat = Es W^T under the Theta of this E-step (_models.py:193-194)
+        if (r) return r;
+        select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
+        HIP_TRY(hipGetLastError());
+        c->yrec_valid = true;
+        c->rec_in_stats = false;
+      }
+      REQUIRE(c->yrec_valid, "incomplete data: the M-step needs y_reconstructed (bsc.py:186); reconstruct or upload it");
+      Ywp = c->Yrec;
+      ldwp = D;
+    }
+    r = launch_gemm_tn(c, c->Es, H, Ywp, ldwp, c->acc + a.Wp, D, H, D, N, false, -1,
                        /*c_is_zero=*/true);  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
     if (r) return r;
   } else {
@@ -1701,6 +1788,7 @@ static int mailbox_errors(evoamd_ctx *c) {
 
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
+  REQUIRE(!(c && c->mask_infr), "incomplete data: the Theta update runs on the host (bsc.py:113-118,266-272)");
   int r = stats_compute(c);
   if (r) return r;
   c->h_theta_fresh = false;

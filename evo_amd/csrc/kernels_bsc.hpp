@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
     const double *__restrict__ Y, const double *__restrict__ Wt, const u64 *__restrict__ states,
     const int *__restrict__ counts, i64 N, int C, int Cstride, int shared, int D, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err) {
+    int *__restrict__ err, const uint8_t *__restrict__ mask /* (N, D) x_infr or nullptr */) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const int lane = lane_id(), wave = wave_id_uniform();
   const int nchunk = (C + BSC_CHUNK - 1) / BSC_CHUNK;
@@ -48,10 +48,12 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
   // observables are processed in slabs of 64*R so any D works with R registers per lane
   for (int d0 = 0; d0 < D; d0 += 64 * R) {
     double yv[R];
+    bool mv[R];  // incomplete data: only reliable entries enter the residual (bsc.py:91-93)
 #pragma unroll
     for (int r = 0; r < R; r++) {
       int d = d0 + lane + 64 * r;
       yv[r] = (d < D) ? y[d] : 0.0;
+      mv[r] = (d < D) && (!mask || mask[n * D + d] != 0);
     }
 #pragma unroll
     for (int i = 0; i < BSC_CHUNK; i++) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
         double p = 0.0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          double t = acc[r] - yv[r];
+          double t = mv[r] ? acc[r] - yv[r] : 0.0;  // select, not multiply: missing entries may hold NaN
           p += t * t;
         }
         part[i] += p;
@@ -267,6 +269,35 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
   if (fl) {
     atomicOr(&flags[n], fl);
     atomicOr(&err[1], 1);
+  }
+}
+
+// Incomplete data: Y <- reliable ? Y : 0 (the reference's missing entries are NaN,
+// examples/image-inpainting/main.py:105-110); zeros drop out of ||y_obs||^2 and y_outer sums.
+__global__ __launch_bounds__(256) void mask_apply_kernel(double *__restrict__ Y, int ld, const uint8_t *__restrict__ mask,
+                                                         i64 N, int D) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * D) return;
+  const i64 n = t / D;
+  const int d = (int)(t - n * D);
+  if (!mask[t]) Y[n * ld + d] = 0.0;
+}
+
+// y_reconstructed on the device (_models.py:643-665): keep y where x is set, the posterior-predictive
+// estimate elsewhere; datapoints without a single reliable entry are skipped (:648-649).
+__global__ __launch_bounds__(256) void select_rec_kernel(const double *__restrict__ Y, int ld,
+                                                         const uint8_t *__restrict__ x, const uint8_t *__restrict__ infr,
+                                                         const double *__restrict__ yhat, i64 N, int D,
+                                                         double *__restrict__ Yrec) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const i64 n = (i64)blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  bool any = false;
+  for (int d = lane; d < D; d += 64) any = any || infr[n * D + d] != 0;
+  any = __any(any);
+  for (int d = lane; d < D; d += 64) {
+    const i64 e = n * D + d;
+    Yrec[e] = (x[e] || !any) ? Y[n * ld + d] : yhat[e];
   }
 }
 

@@ -139,14 +139,35 @@ class Engine:
         check(self.lib.evoamd_lpj_shared(self._h, u8ptr(b), b.shape[0], dptr(out)))
         return out
 
-    def lpj_single(self, y, states):
+    def lpj_single(self, y, states, x_infr=None):
         y = as_f64(y)
         b = as_bool_bytes(states)
         assert y.shape == (self.D,) and b.ndim == 2 and b.shape[1] == self.H
         out = np.empty(b.shape[0], dtype=np.float64)
         flags = np.zeros(3, dtype=np.int32)
-        check(self.lib.evoamd_lpj_single(self._h, dptr(y), u8ptr(b), b.shape[0], dptr(out), i32ptr(flags)))
+        if x_infr is None:
+            check(self.lib.evoamd_lpj_single(self._h, dptr(y), u8ptr(b), b.shape[0], dptr(out), i32ptr(flags)))
+        else:
+            m = as_bool_bytes(x_infr)
+            assert m.shape == (self.D,)
+            check(self.lib.evoamd_lpj_single_masked(self._h, dptr(y), u8ptr(m), u8ptr(b), b.shape[0], dptr(out),
+                                                    i32ptr(flags)))
         return out, flags
+
+    def upload_masks(self, x_infr, x=None):
+        """EBSC incomplete data: reliable entries x_infr (N, D) and keep-mask x (default x_infr); None clears."""
+        if x_infr is None:
+            check(self.lib.evoamd_upload_masks(self._h, None, None))
+            return
+        mi = as_bool_bytes(x_infr)
+        mx = as_bool_bytes(x_infr if x is None else x)
+        assert mi.shape == (self.N, self.D) and mx.shape == (self.N, self.D)
+        check(self.lib.evoamd_upload_masks(self._h, u8ptr(mi), u8ptr(mx)))
+
+    def upload_yrec(self, y_rec):
+        y_rec = as_f64(y_rec)
+        assert y_rec.shape == (self.N, self.D)
+        check(self.lib.evoamd_upload_yrec(self._h, dptr(y_rec)))
 
     def vary_kn(self, Mprime, want_sums=True):
         sums = np.zeros(2, dtype=np.float64)

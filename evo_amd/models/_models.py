@@ -104,6 +104,9 @@ class Model:
         self._device = device
         self._y_token = None
         self._x_infr_token = None
+        self._incomplete = False
+        self._had_masks = False
+        self._yrec_token = None
         self._resident = False   # K^n on the device is authoritative (sync_host=False only)
         self._acc = None         # statistics computed by E_step for the M_step of the same step()
         self._n_steps = 0
@@ -126,11 +129,16 @@ class Model:
         """Configure the engine for this rank's shard and make Y / K^n resident."""
         Y = my_data["y"]
         xi = my_data["x_infr"]
-        xi_token = (id(xi), xi.shape)
-        if self._x_infr_token != xi_token:  # checked once per array object, like the Y upload below
-            if not xi.all():
-                raise NotImplementedError("missing data (x_infr) is outside the accelerated path (SURVEY 8f rank 3)")
-            self._x_infr_token = xi_token
+        xi_token = (id(xi), xi.shape, id(my_data.get("x")))
+        new_masks = self._x_infr_token != xi_token
+        if new_masks:  # checked once per array object, like the Y upload below
+            self._incomplete = not xi.all()
+            if self._incomplete:
+                if self.model_name != "bsc":
+                    raise NotImplementedError("missing data (x_infr) is implemented for EBSC only (SURVEY 8f rank 3)")
+                if self.device_mstep:
+                    raise NotImplementedError("missing data: use device_mstep=False (the Theta update of bsc.py:113-118,"
+                                              "266-272 runs on the host)")
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])
@@ -146,6 +154,21 @@ class Model:
         if self._y_token != token:
             eng.upload_data(Y)
             self._y_token = token
+            new_masks = True
+        if new_masks:
+            if self._incomplete:
+                eng.upload_masks(xi, my_data.get("x"))
+                self._yrec_token = None
+            elif self._had_masks:
+                eng.upload_masks(None)
+                eng.upload_data(Y)
+            self._had_masks = self._incomplete
+            self._x_infr_token = xi_token
+        if self._incomplete and "y_reconstructed" in my_data:
+            yr = my_data["y_reconstructed"]
+            if self._yrec_token != id(yr):  # an older reconstruction the M-step should read (bsc.py:186)
+                eng.upload_yrec(np.where(np.isnan(yr), 0.0, yr))
+                self._yrec_token = id(yr)
         if upload_states and (self.sync_host or not self._resident):
             eng.upload_states(my_suff_stat["ss"])
             self._resident = True
@@ -221,6 +244,8 @@ class Model:
         y_hat = self.engine.reconstruct()
         y_rec = my_data["y"].copy()
         miss = np.logical_not(my_data["x"])
+        if self._incomplete:  # datapoints without a single reliable entry are skipped (_models.py:648-649)
+            miss &= my_data["x_infr"].any(axis=1)[:, None]
         y_rec[miss] = y_hat[miss]
         my_data["y_reconstructed"] = y_rec
 
@@ -257,8 +282,9 @@ class Model:
         if self.device_mstep:
             return self._step_device(model_params, my_suff_stat, my_data, do_reconstruction)
         model_params = self.check_params(model_params)
-        F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
-        if do_reconstruction:  # _models.py:193-194: after the E-step, with the Theta it used
+        F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True,
+                                          _reconstruct=do_reconstruction)
+        if do_reconstruction and not self._incomplete:  # _models.py:193-194: after the E-step, with the Theta it used
             self._write_reconstruction(my_data)
         new_params = (self.M_step(model_params, my_suff_stat, my_data, _from_step=True)
                       if len(self.to_learn) > 0 else model_params)
@@ -276,13 +302,20 @@ class Model:
     def standard_init(self, my_data, W_init=None, pi_init=None, sigma_init=None):
         """Theta^init for BSC (_models.py:205-283): W = data mean + N(0,(sigma/4)^2) unless given,
         pi = 1/H, sigma = sqrt(mean data variance).  RNG calls as in the reference."""
-        if not my_data["x_infr"].all():
-            raise NotImplementedError("missing data is outside the accelerated path")
         D, H = self.D, self.H
-        y_mean, var, _ = self._data_moments(my_data)
-        if sigma_init is None:
-            sigma_init = np.sqrt(var.sum() / D)
-            assert sigma_init > 0.0
+        xi = my_data["x_infr"]
+        if xi.all():
+            y_mean, var, _ = self._data_moments(my_data)
+            if sigma_init is None:
+                sigma_init = np.sqrt(var.sum() / D)
+        else:
+            # _models.py:246-267: sums over the reliable entries; the mean divides by my_N (per rank)
+            Y = np.where(xi, my_data["y"], 0.0)
+            y_mean = self.comm.allreduce(Y.sum(axis=0) / Y.shape[0])
+            if sigma_init is None:
+                tmp = (np.where(xi, Y - y_mean, 0.0) ** 2).sum(axis=0)
+                sigma_init = np.sqrt(self.comm.allreduce(tmp.sum() / xi.sum()))
+        assert sigma_init > 0.0
         if type(W_init) is not np.ndarray:
             if W_init == "random_uniform":
                 W_init = self.comm.bcast(np.random.random((D, H)))
@@ -327,7 +360,12 @@ class Model:
             self._resident = False
             self._push_params(model_params)
         states = np.ascontiguousarray(my_suff_stat["this_states"], dtype=bool)
-        out, flags = eng.lpj_single(my_data["this_y"], states)
+        xi = my_data.get("this_x_infr")
+        masked = xi is not None and not np.all(xi)
+        if masked and self.model_name != "bsc":
+            raise NotImplementedError("missing data (x_infr) is implemented for EBSC only (SURVEY 8f rank 3)")
+        this_y = my_data["this_y"]
+        out, flags = eng.lpj_single(np.where(xi, this_y, 0.0) if masked else this_y, states, xi if masked else None)
         for key, f in zip(("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"), flags):
             if f:
                 my_suff_stat[key] = my_suff_stat.get(key, 0) + 1
@@ -338,7 +376,9 @@ class Model:
         """All-zero permanent state (bsc.py:59-76, sssc.py:224-239)."""
         lpj = np.empty((my_suff_stat["S_perm"],))
         if my_suff_stat["permanent"]["allzero"]:
-            lpj[0] = self._allzero_lpj(model_params, (my_data["this_y"] ** 2).sum())
+            xi = my_data.get("this_x_infr")
+            y_obs = my_data["this_y"] if xi is None else my_data["this_y"][xi]
+            lpj[0] = self._allzero_lpj(model_params, (y_obs ** 2).sum())
         return self.lpj_reset_check(lpj, my_suff_stat)
 
     # ---- E-step --------------------------------------------------------------------------------
@@ -385,7 +425,7 @@ class Model:
         seed = (self.seed * 1000003 + self._n_steps) * max(1, self.comm.size) + self.comm.rank
         eng.evolve_randflip(min(my_suff_stat["n_parents"], self.S), my_suff_stat["n_children"], seed, fit)
 
-    def E_step(self, model_params, my_suff_stat, my_data, _keep_acc=False):
+    def E_step(self, model_params, my_suff_stat, my_data, _keep_acc=False, _reconstruct=False):
         """New variational states, their lpj, K^n update and the free energy (_models.py:453-565).
         Returns (F, S_nunique, S_sub).  my_suff_stat["ss"] / ["lpj"] are updated in place when
         ``sync_host`` (always in rng="reference" mode)."""
@@ -398,7 +438,14 @@ class Model:
             self._candidates_device(eng, my_suff_stat)
         eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
         self._n_steps += 1
+        if self._incomplete and _reconstruct:
+            # incomplete data: y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211), so the
+            # statistics pass forms it between the Es rows and the contraction
+            eng.set_option("reconstruct_in_stats", 1)
         acc = eng.stats()
+        if self._incomplete and _reconstruct:
+            self._write_reconstruction(my_data)
+            self._yrec_token = id(my_data["y_reconstructed"])  # the device already holds it
         if not getattr(self.comm, "device_reduces", False):
             acc = _reduce_array(self.comm, acc)
         v = eng.acc_views(acc)

@@ -40,7 +40,15 @@ class BSC(Model):
         model_params["piH"] = pi * self.H
         model_params["pre1"] = -1.0 / 2.0 / sigma / sigma
         model_params["pil_bar"] = np.log(pi / (1.0 - pi))
-        model_params["ljc"] = self.H * np.log(1.0 - pi) - self.D / 2 * np.log(2 * np.pi * sigma * sigma)
+        xi = my_data["x_infr"]
+        if xi.all():
+            model_params["ljc"] = self.H * np.log(1.0 - pi) - self.D / 2 * np.log(2 * np.pi * sigma * sigma)
+            self._n_reliable = None
+        else:  # bsc.py:113-118: the Gaussian normaliser counts the reliable entries
+            N = self.comm.allreduce(xi.shape[0])
+            self._n_reliable = self.comm.allreduce(int(xi.sum()))
+            model_params["ljc"] = (self.H * np.log(1.0 - pi)
+                                   - np.log(2 * np.pi * sigma * sigma) * self._n_reliable / N / 2)
         for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"):
             my_suff_stat[key] = 0
         if self._engine_matches():
@@ -76,7 +84,11 @@ class BSC(Model):
             model_params["pi"] = pies_new.sum() / H
             model_params["pies"] = pies_new
         if "sigma" in self.to_learn:
-            model_params["sigma"] = np.sqrt(float(sums["sigma"]) / N / D)
+            n_rel = getattr(self, "_n_reliable", None)
+            if n_rel is not None:  # bsc.py:266-272 as written: OLD sigma x count of reliable entries
+                model_params["sigma"] = np.sqrt((float(sums["sigma"]) + n_rel * model_params["sigma"] ** 2) / N / D)
+            else:
+                model_params["sigma"] = np.sqrt(float(sums["sigma"]) / N / D)
         return model_params
 
     def M_step(self, model_params, my_suff_stat, my_data, _from_step=False):

@@ -163,6 +163,22 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
  * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
+/* Incomplete data, EBSC (examples/image-inpainting/main.py:105-111).  x_infr (N x D bool
+ * bytes): reliable entries -- only they enter lpj (bsc.py:59-97), the allzero term and the sigma sum
+ * (bsc.py:206-219); x (N x D, NULL = x_infr): entries that keep their value in y_reconstructed.  Call after
+ * evoamd_upload_data (missing entries of Y may hold NaN; the device copy zeroes them).  All lpj entry
+ * points then use the direct residual kernel with the mask (a Gram form would need W_obs^T W_obs per
+ * datapoint).  The M-step's Wp contraction reads y_reconstructed (bsc.py:184-189): either
+ * evoamd_set_option(ctx, "reconstruct_in_stats", 1) before evoamd_stats (it then forms
+ * y_hat = Es W^T and y_rec = x ? y : y_hat first; fetch y_hat with evoamd_reconstruct), or hand over an
+ * older one with evoamd_upload_yrec.  x_infr == NULL returns to complete data (upload Y again).  The
+ * Theta update for incomplete data stays on the host (evoamd_mstep_device refuses). */
+int evoamd_upload_masks(evoamd_ctx *ctx, const uint8_t *x_infr, const uint8_t *x);
+int evoamd_upload_yrec(evoamd_ctx *ctx, const double *y_reconstructed);
+/* evoamd_lpj_single with this datapoint's x_infr row (D bool bytes): log_pseudo_joint reading
+ * my_data["this_x_infr"] (bsc.py:80-95). */
+int evoamd_lpj_single_masked(evoamd_ctx *ctx, const double *y, const uint8_t *x_infr, const uint8_t *states, int C,
+                             double *lpj_out, int32_t *flags_out);
 /* Posterior-predictive data estimate (complete data): y_hat (N x D, host) with
  *   y_hat[n] = sum_s q_ns W s / sum_s q_ns = W . E_q[s]           EBSC  (_models.py:614-665, bsc.py:279-287)
  *   y_hat[n] = sum_s q_ns W (s o kappa_ns) / sum_s q_ns = W . E_q[s o z]   ES3C  (sssc.py:368-405,613-627)

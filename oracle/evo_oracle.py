@@ -364,22 +364,40 @@ BSC_POLICY = {  # _models.py:47-52
 }
 
 
-def bsc_standard_init(Y, H):
-    """_models.py:205-283 default branch: W = y_mean + N(0, (sigma/4)^2), pi=1/H."""
+def bsc_standard_init(Y, H, x_infr=None):
+    """_models.py:205-283 default branch: W = y_mean + N(0, (sigma/4)^2), pi=1/H.  With missing
+    entries (x_infr not all True) mean and variance run over the reliable entries only
+    (_models.py:246-267; note the mean divides by my_N, not by the per-dimension count)."""
     D = Y.shape[1]
-    y_mean, var = standard_init_common(Y)
-    sigma = np.sqrt(var.sum() / D)
+    if x_infr is None or x_infr.all():
+        y_mean, var = standard_init_common(Y)
+        sigma = np.sqrt(var.sum() / D)
+    else:
+        N = Y.shape[0]
+        y_mean = np.zeros(D)
+        for n in range(N):
+            y_mean[x_infr[n]] += Y[n][x_infr[n]]
+        y_mean = y_mean / N
+        tmp = np.zeros(D)
+        for n in range(N):
+            tmp[x_infr[n]] += (Y[n][x_infr[n]] - y_mean[x_infr[n]]) ** 2
+        sigma = np.sqrt(tmp.sum() / x_infr.flatten().sum())
     noise = np.random.normal(scale=sigma / 4.0, size=[D, H])
     return {"W": y_mean[:, None] + noise, "pi": 1.0 / H, "sigma": sigma}
 
 
-def bsc_precompute(theta, D, H):
-    """bsc.py:99-125 (complete data).  Adds pre1, pil_bar, piH, ljc to ``theta``."""
+def bsc_precompute(theta, D, H, x_infr=None):
+    """bsc.py:99-125.  Adds pre1, pil_bar, piH, ljc to ``theta`` (incomplete data: the Gaussian
+    normaliser counts the reliable entries, bsc.py:113-118)."""
     pi, sigma = theta["pi"], theta["sigma"]
     theta["piH"] = pi * H
     theta["pre1"] = -1.0 / 2.0 / sigma / sigma
     theta["pil_bar"] = np.log(pi / (1.0 - pi))
-    theta["ljc"] = H * np.log(1.0 - pi) - D / 2 * np.log(2 * np.pi * sigma * sigma)
+    if x_infr is not None and not x_infr.all():
+        sum_n_d = x_infr.sum()
+        theta["ljc"] = H * np.log(1.0 - pi) - np.log(2 * np.pi * sigma * sigma) * sum_n_d / x_infr.shape[0] / 2
+    else:
+        theta["ljc"] = H * np.log(1.0 - pi) - D / 2 * np.log(2 * np.pi * sigma * sigma)
     return new_counters()
 
 
@@ -394,14 +412,16 @@ def bsc_lpj(theta, states, y, counters, x_infr=None):
     return lpj_clamp(lpj, counters)
 
 
-def bsc_lpj_allzero(theta, y, counters):
-    """bsc.py:59-76 with permanent['allzero']: lpj = pre1*||y||^2."""
+def bsc_lpj_allzero(theta, y, counters, x_infr=None):
+    """bsc.py:59-76 with permanent['allzero']: lpj = pre1*||y_obs||^2."""
     lpj = np.empty((1,))
-    lpj[0] = theta["pre1"] * (y ** 2).sum()
+    if x_infr is None:
+        x_infr = np.ones(y.shape[0], dtype=bool)
+    lpj[0] = theta["pre1"] * (y[x_infr] ** 2).sum()
     return lpj_clamp(lpj, counters)
 
 
-def bsc_E_step(theta, suff, Y, trace=None):
+def bsc_E_step(theta, suff, Y, trace=None, x_infr=None):
     """_models.py:453-565 on one rank.  Mutates suff['ss'], suff['lpj'] in place; returns
     (Fs, sum_nunique, sum_sub, counters) -- the *un-normalised* per-rank quantities that the
     reference all-reduces (_models.py:540-547).  ``trace`` (list) optionally receives
@@ -409,17 +429,18 @@ def bsc_E_step(theta, suff, Y, trace=None):
     N, D = Y.shape
     H = theta["W"].shape[1]
     S = suff["ss"].shape[1]
-    counters = bsc_precompute(theta, D, H)
+    counters = bsc_precompute(theta, D, H, x_infr)
     S_perm, incl, Mprime = suff["S_perm"], suff["incl"], suff["Mprime"]
     n_uniq = n_sub = 0.0
     for n in range(N):
         y = Y[n]
+        xi = None if x_infr is None else x_infr[n]
         cur = suff["ss"][n]
         if S_perm > 0:
-            suff["lpj"][n, 0:S_perm] = bsc_lpj_allzero(theta, y, counters)
-        cur_lpj = bsc_lpj(theta, cur, y, counters)
+            suff["lpj"][n, 0:S_perm] = bsc_lpj_allzero(theta, y, counters, xi)
+        cur_lpj = bsc_lpj(theta, cur, y, counters, xi)
         new_s, new_l = evolve_states(cur, cur_lpj, suff, theta["piH"],
-                                     lambda st: bsc_lpj(theta, st, y, counters))
+                                     lambda st: bsc_lpj(theta, st, y, counters, xi))
         if trace is not None:
             trace.append((n, new_s.copy(), new_l.copy()))
         a, b = vary_Kn(cur_lpj, new_l, suff["lpj"][n, S_perm:], cur, new_s, H, S, S_perm, incl, Mprime)
@@ -429,9 +450,14 @@ def bsc_E_step(theta, suff, Y, trace=None):
     return Fs, n_uniq, n_sub, counters
 
 
-def bsc_accumulate(theta, suff, Y):
-    """bsc.py:176-223: per-rank M-step sums (my_Wp (H,D), my_Wq (H,H), my_pies (H,), my_sigma)."""
+def bsc_accumulate(theta, suff, Y, x_infr=None, y_rec=None):
+    """bsc.py:176-223: per-rank M-step sums (my_Wp (H,D), my_Wq (H,H), my_pies (H,), my_sigma).
+    Incomplete data (bsc.py:184-189): Wp uses y_reconstructed, the residual the reliable entries."""
     N, D = Y.shape
+    incmpl = x_infr is not None and not x_infr.all()
+    if incmpl:
+        assert y_rec is not None  # bsc.py:186
+        Y = y_rec
     Wt = theta["W"].T
     H = Wt.shape[0]
     lpj, ss, S_perm = suff["lpj"], suff["ss"], suff["S_perm"]
@@ -441,9 +467,9 @@ def bsc_accumulate(theta, suff, Y):
     Wq = np.zeros((H, H))
     pies = np.zeros(H)
     sig = 0.0
-    obs = np.ones(D, dtype=bool)  # complete data: the reference still indexes with the mask
     for n in range(N):
         y = Y[n]
+        obs = x_infr[n] if x_infr is not None else np.ones(D, dtype=bool)  # the reference always indexes with the mask
         q = pjc[n]
         st = ss[n]
         t_Wp = np.zeros_like(Wp)
@@ -451,7 +477,7 @@ def bsc_accumulate(theta, suff, Y):
         t_pies = np.zeros(H)
         t_sig = 0.0
         if suff["permanent"]["allzero"]:
-            t_sig += q[0] * (y ** 2).sum()
+            t_sig += q[0] * (y[obs] ** 2).sum()
         t_pies += (q[S_perm:].T * st.T).sum(axis=1)
         t_Wp += np.outer((q[S_perm:].T * st.T).sum(axis=1), y)
         t_Wq += np.dot(q[S_perm:].T * st.T, st)
@@ -464,9 +490,11 @@ def bsc_accumulate(theta, suff, Y):
     return {"Wp": Wp, "Wq": Wq, "pies": pies, "sigma": sig}
 
 
-def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma")):
+def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma"), n_reliable=None):
     """bsc.py:226-277: Theta update from the all-reduced sums.  Mutates and returns theta.
-    rcond follows the reference's version test, which yields -1 on NumPy 2.x."""
+    rcond follows the reference's version test, which yields -1 on NumPy 2.x.
+    n_reliable = x_infr.sum() selects the incomplete-data sigma (bsc.py:266-272: the OLD sigma
+    enters with the count of RELIABLE entries, as the reference writes it)."""
     if "W" in to_learn:
         rcond = None if float(np.__version__[2:]) >= 14.0 else -1
         theta["W"] = np.linalg.lstsq(sums["Wq"], sums["Wp"], rcond=rcond)[0].T
@@ -475,19 +503,25 @@ def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma")):
         theta["pi"] = pies_new.sum() / H
         theta["pies"] = pies_new
     if "sigma" in to_learn:
-        theta["sigma"] = np.sqrt(sums["sigma"] / N / D)
+        if n_reliable is not None:
+            theta["sigma"] = np.sqrt((sums["sigma"] + n_reliable * theta["sigma"] ** 2) / N / D)
+        else:
+            theta["sigma"] = np.sqrt(sums["sigma"] / N / D)
     return theta
 
 
-def bsc_reconstruct(theta, suff, Y, x):
-    """Model.reconstruct (_models.py:614-665) with BSC.modelmean (bsc.py:279-287), complete data:
-    entries with x False become sum_s q_s (W s)_d / sum_s q_s under the current Theta and K^n."""
+def bsc_reconstruct(theta, suff, Y, x, x_infr=None):
+    """Model.reconstruct (_models.py:614-665) with BSC.modelmean (bsc.py:279-287): entries with x
+    False become sum_s q_s (W s)_d / sum_s q_s under the current Theta and K^n; datapoints without a
+    single reliable entry are skipped (_models.py:648-649)."""
     lpj, ss, S_perm = suff["lpj"], suff["ss"], suff["S_perm"]
     B = np.minimum(B_MAX - lpj.max(axis=1), B_MAX_SHFT)
     pjc = np.exp(lpj + B[:, None])
     y_rec = Y.copy()
     Wt = theta["W"].T
     for n in range(Y.shape[0]):
+        if x_infr is not None and np.logical_not(x_infr[n]).all():
+            continue
         this_x = x[n]
         this_W = Wt[:, np.logical_not(this_x)]
         this_mu = np.dot(ss[n], this_W).T                       # (D_miss, S)
@@ -497,22 +531,25 @@ def bsc_reconstruct(theta, suff, Y, x):
     return y_rec
 
 
-def bsc_step(theta, suff, Y, to_learn=("W", "pi", "sigma"), trace=None, reconstruct_x=None):
+def bsc_step(theta, suff, Y, to_learn=("W", "pi", "sigma"), trace=None, reconstruct_x=None, x_infr=None,
+             y_rec_prev=None):
     """_models.py:161-203 for BSC on one rank: check_params -> E_step [-> reconstruct] -> M_step.
     Returns (F, S_nunique, S_sub, theta) like the reference, plus the raw sums dict
     (sums["y_reconstructed"] when reconstruct_x, the my_data["x"] mask, is given)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     theta = check_params(theta, BSC_POLICY)
-    Fs, nu, nsub, _ = bsc_E_step(theta, suff, Y, trace)
+    Fs, nu, nsub, _ = bsc_E_step(theta, suff, Y, trace, x_infr)
     F = theta["ljc"] + Fs / N
-    y_rec = bsc_reconstruct(theta, suff, Y, reconstruct_x) if reconstruct_x is not None else None
-    sums = bsc_accumulate(theta, suff, Y)
+    y_rec = bsc_reconstruct(theta, suff, Y, reconstruct_x, x_infr) if reconstruct_x is not None else None
+    # incomplete data: the M-step reads my_data["y_reconstructed"], i.e. this step's or an older one
+    sums = bsc_accumulate(theta, suff, Y, x_infr, y_rec if y_rec is not None else y_rec_prev)
     if y_rec is not None:
         sums["y_reconstructed"] = y_rec
     sums["Fs"] = Fs
     if len(to_learn) > 0:
-        theta = bsc_update(theta, sums, N, D, H, to_learn)
+        incmpl = x_infr is not None and not x_infr.all()
+        theta = bsc_update(theta, sums, N, D, H, to_learn, n_reliable=x_infr.sum() if incmpl else None)
     return F, nu / N, nsub / N, theta, sums
 
 

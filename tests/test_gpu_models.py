@@ -328,3 +328,51 @@ def test_reconstruction_against_reference(engine, algo, device_mstep):
         got = my_data["y_reconstructed"]
         np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())))
         assert np.array_equal(got[x], Y[x])
+
+
+def test_missing_data_ebsc_against_reference(engine):
+    """EBSC on incomplete data (image-inpainting set-up: NaN at the missing entries, x_infr = x = ~isnan):
+    standard_init, masked lpj / selection, reconstruction feeding the same step's M-step, the step that
+    reuses an older y_reconstructed -- against tests/golden/missing_ebsc.npz recorded from the reference."""
+    from evo_amd.models import BSC
+    g = load_golden("missing_ebsc.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    Y, x_infr = g["Y"], g["x_infr"]
+    my_data = {"y": Y, "x_infr": x_infr, "x": x_infr.copy()}
+    model = BSC(D, H, S, engine=engine)
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in BSC_KEYS}
+    for k in ("pi", "sigma"):
+        theta[k] = np.float64(theta[k])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data, do_reconstruction=bool(g["t%d_do_rec" % t]))
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-9, err_msg="F step %d" % t)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t]), "K^n step %d" % t
+        np.testing.assert_allclose(suff["lpj"], g["t%d_lpj_out" % t], rtol=1e-9)
+        want = g["t%d_y_reconstructed" % t]
+        np.testing.assert_allclose(my_data["y_reconstructed"], want, rtol=1e-8, atol=1e-9)
+        for k in BSC_KEYS:
+            ref = g["t%d_out_%s" % (t, k)]
+            np.testing.assert_allclose(theta[k], ref, rtol=1e-7, atol=1e-9 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    # per-datapoint operator with this_x_infr (bsc.py:80-95) against the E-step's own numbers
+    model.E_step_precompute(theta, suff, my_data)
+    n = 3
+    my_data["this_y"], my_data["this_x_infr"] = Y[n], x_infr[n]
+    suff["this_states"] = suff["ss"][n]
+    one = model.log_pseudo_joint(theta, suff, my_data)
+    from oracle import evo_oracle as orc
+    th = dict(theta)
+    orc.bsc_precompute(th, D, H, x_infr)
+    np.testing.assert_allclose(one, orc.bsc_lpj(th, suff["ss"][n], Y[n], orc.new_counters(), x_infr[n]), rtol=1e-10)
+
+
+def test_missing_data_es3c_is_refused(engine):
+    from evo_amd.models import SSSC
+    Y = np.random.RandomState(0).normal(size=(6, 8))
+    xi = np.ones_like(Y, dtype=bool)
+    xi[0, 0] = False
+    model = SSSC(8, 4, 3, engine=engine)
+    with pytest.raises(NotImplementedError):
+        model._prepare({"ss": np.zeros((6, 3, 4), bool), "S_perm": 0, "permanent": {"background": False}},
+                       {"y": Y, "x_infr": xi})

@@ -254,3 +254,20 @@ def test_scatter_gather_single_rank():
     b = parallel.scatter_to_processes(a)
     assert np.array_equal(a, b) and b is not a
     assert np.array_equal(parallel.gather_from_processes(b), a)
+
+
+def test_standard_init_incomplete_data_matches_reference():
+    """BSC.standard_init on data with missing entries (_models.py:246-267) reproduces the Theta^init the
+    reference produced for tests/golden/missing_ebsc.npz (same RNG consumption before the call)."""
+    from conftest import load_golden
+    from oracle import evo_oracle as orc
+    from evo_amd.models import BSC
+    g = load_golden("missing_ebsc.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    np.random.seed(int(g["seed"]))
+    orc.bsc_generate({"W": 10.0 * orc.bars_dictionary(H), "pi": 2.0 / H, "sigma": 1.0}, N)
+    np.random.random_sample((N, D))
+    model = BSC(D, H, S, engine=object())
+    th = model.check_params(model.standard_init({"y": g["Y"], "x_infr": g["x_infr"]}))
+    for k in ("W", "pi", "sigma"):
+        np.testing.assert_allclose(th[k], g["t0_in_%s" % k], rtol=1e-12, atol=1e-13, err_msg=k)

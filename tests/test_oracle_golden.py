@@ -187,3 +187,44 @@ def test_reconstruction_replay(algo):
         np.testing.assert_allclose(sums["y_reconstructed"], want, rtol=1e-11, atol=1e-12)
         assert np.array_equal(sums["y_reconstructed"][x], Y[x])          # kept entries untouched
         assert np.array_equal(sums["y_reconstructed"][1], Y[1])          # x[1] all True
+
+
+def test_missing_data_replay_ebsc():
+    """EBSC on incomplete data (x_infr not all True, NaN at the missing entries): masked lpj
+    (bsc.py:59-97), ljc over the reliable entries (bsc.py:113-118), M-step on y_reconstructed with the
+    masked residual and the incomplete-data sigma (bsc.py:184-223,266-272), reconstruction
+    (_models.py:614-665) -- three chained steps, the last one without a fresh reconstruction."""
+    g = load_golden("missing_ebsc.npz")
+    H = int(g["H"])
+    Y, x_infr = g["Y"], g["x_infr"]
+    assert np.isnan(Y[~x_infr]).all() and not np.isnan(Y[x_infr]).any()
+    theta = theta_in(g, 0, BSC_KEYS)
+    suff = suff_from_fixture(g, unpack_bits(g["t0_ss_in"], H))
+    y_rec = None
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        do_rec = bool(g["t%d_do_rec" % t])
+        F, nu, nsub, theta, sums = orc.bsc_step(theta, suff, Y, x_infr=x_infr,
+                                                reconstruct_x=x_infr if do_rec else None, y_rec_prev=y_rec)
+        if do_rec:
+            y_rec = sums["y_reconstructed"]
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-13)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t])
+        np.testing.assert_allclose(suff["lpj"], g["t%d_lpj_out" % t], rtol=1e-12)
+        np.testing.assert_allclose(y_rec, g["t%d_y_reconstructed" % t], rtol=1e-11, atol=1e-12)
+        for k in BSC_KEYS:
+            np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+def test_standard_init_incomplete_data():
+    """_models.py:246-267 on the fixture's data: same RNG draw, same Theta^init as the reference."""
+    g = load_golden("missing_ebsc.npz")
+    np.random.seed(int(g["seed"]))
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    # replay the RNG consumption that precedes standard_init in the generator (data + mask draws)
+    W = 10.0 * orc.bars_dictionary(H)
+    orc.bsc_generate({"W": W, "pi": 2.0 / H, "sigma": 1.0}, N)
+    np.random.random_sample((N, D))
+    th = orc.check_params(orc.bsc_standard_init(g["Y"], H, g["x_infr"]), orc.BSC_POLICY)
+    for k in BSC_KEYS:
+        np.testing.assert_allclose(th[k], g["t0_in_%s" % k], rtol=1e-12, atol=1e-13, err_msg=k)
