@@ -591,39 +591,73 @@ __global__ __launch_bounds__(256) void gjp_update_kernel(GjMats m, int n, int p0
 // ---------------------------------------------------------------------------------------
 #define GJS_B 16
 
-// In-place inverse of the SPD 16 x 16 block M (LDS, row stride 17) by ONE wave: lane l owns row
-// l & 15, columns 4 (l >> 4) .. +3.  No pivoting, no barriers (one wave's LDS operations execute in
-// order).  d0[q] = original diagonal entries for the singularity test.  Returns false on a bad pivot.
+// In-place inverse of the SPD 16 x 16 block M (LDS, row stride 17) by ONE wave, the block in
+// registers: lane l owns row l & 15, columns 4 (l >> 4) .. +3.  No pivoting.  Per pivot q:
+//   pivot row for my columns   lane q of my own 16-lane DPP row        -> row_newbcast:q (8 DPP moves)
+//   pivot element              one lane, statically known             -> v_readlane
+//   my row's multiplier M[i][q] same position in DPP row q >> 2       -> ds_bpermute (2)
+// then 4 FMAs.  The first version kept the block in LDS and paid two LDS round trips plus the
+// reciprocal chain per pivot (4.8 us per block, half of every block step of the SPD path).
+// d0[q] = original diagonal entries for the singularity test.  Returns false on a bad pivot.
+template <int Q>
+__device__ __forceinline__ double row_bcast_f64(double v) {  // lane Q of each 16-lane row to the whole row
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + Q, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + Q, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bpermute_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane * 4, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane * 4, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int Q>
+__device__ __forceinline__ void inv16_step(double (&a)[4], int i, int c0, double dreg, bool &ok) {
+  constexpr int QG = Q >> 2, QJ = Q & 3;
+  double pr[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) pr[j] = row_bcast_f64<Q>(a[j]);
+  const double piv = readlane_f64_dyn(a[QJ], Q + 16 * QG);
+  const double f = bpermute_f64(a[QJ], i + 16 * QG);
+  if (!(piv > 1e-13 * readlane_f64_dyn(dreg, Q))) ok = false;
+  const double rinv = fast_rcp(piv);
+  const double g = f * rinv;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = c0 + j;
+    double v;
+    if (i == Q) v = (c == Q) ? rinv : pr[j] * rinv;
+    else v = (c == Q) ? -g : fma(-g, pr[j], a[j]);
+    a[j] = v;
+  }
+}
 __device__ __forceinline__ bool inv16_spd_wave(double (*M)[GJS_B + 1], const double *d0) {
   const int l = lane_id(), i = l & 15, c0 = (l >> 4) * 4;
   bool ok = true;
   double a[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) a[j] = M[i][c0 + j];
-#pragma unroll 1
-  for (int q = 0; q < GJS_B; q++) {
-    const double piv = M[q][q];
-    const double f = M[i][q];
-    double pr[4];
+  const double dreg = d0[i];
+  inv16_step<0>(a, i, c0, dreg, ok);
+  inv16_step<1>(a, i, c0, dreg, ok);
+  inv16_step<2>(a, i, c0, dreg, ok);
+  inv16_step<3>(a, i, c0, dreg, ok);
+  inv16_step<4>(a, i, c0, dreg, ok);
+  inv16_step<5>(a, i, c0, dreg, ok);
+  inv16_step<6>(a, i, c0, dreg, ok);
+  inv16_step<7>(a, i, c0, dreg, ok);
+  inv16_step<8>(a, i, c0, dreg, ok);
+  inv16_step<9>(a, i, c0, dreg, ok);
+  inv16_step<10>(a, i, c0, dreg, ok);
+  inv16_step<11>(a, i, c0, dreg, ok);
+  inv16_step<12>(a, i, c0, dreg, ok);
+  inv16_step<13>(a, i, c0, dreg, ok);
+  inv16_step<14>(a, i, c0, dreg, ok);
+  inv16_step<15>(a, i, c0, dreg, ok);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < 4; j++) pr[j] = M[q][c0 + j];
-    if (!(piv > 1e-13 * d0[q])) ok = false;
-    const double rinv = fast_rcp(piv);
-    const double g = f * rinv;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int c = c0 + j;
-      double v;
-      if (i == q) v = (c == q) ? rinv : pr[j] * rinv;
-      else v = (c == q) ? -g : fma(-g, pr[j], a[j]);
-      a[j] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; j++) M[i][c0 + j] = a[j];
-    __builtin_amdgcn_wave_barrier();
-  }
-  return __all(ok);
+  for (int j = 0; j < 4; j++) M[i][c0 + j] = a[j];
+  __builtin_amdgcn_wave_barrier();
+  return ok;  // every comparison used wave-uniform values
 }
 
 // Stashes diag(A) (the singularity scale) and inverts the first diagonal block: <<<nmat, 64>>>.
