@@ -585,21 +585,35 @@ EPS_PSI = TOL
 EPS_SIGMA2 = TOL
 
 
-def sssc_standard_init(Y, H, to_learn=("W", "pies", "mus", "sigma2", "Psi")):
-    """sssc.py:104-197, default branch, complete data: pies~U(0.1,0.5), mus~N(0,1),
-    Psi=I, sigma2 = mean diag cov + 1e-3, W = y_mean + N(0, sigma2/16).  RNG order kept."""
+def sssc_standard_init(Y, H, to_learn=("W", "pies", "mus", "sigma2", "Psi"), x_infr=None):
+    """sssc.py:104-197, default branch: pies~U(0.1,0.5), mus~N(0,1), Psi=I, sigma2 = mean diag
+    cov + 1e-3, W = y_mean + N(0, sigma2/16).  RNG order kept.  Incomplete data (sssc.py:144-176): mean
+    over the reliable entries divided by N, sigma2 = sum of squared deviations / number of reliable
+    entries + 1e-3."""
     D = Y.shape[1]
     theta = {"pies": np.random.uniform(low=0.1, high=0.5, size=[H])}
     theta["mus"] = np.random.normal(0, 1, [H]) if "mus" in to_learn else np.ones(H)
     theta["Psi"] = np.diag(np.ones(H))
-    y_mean, _ = standard_init_common(Y)
-    theta["sigma2"] = np.mean(np.diag(np.cov(Y.T))) + 0.001
+    if x_infr is None or x_infr.all():
+        y_mean, _ = standard_init_common(Y)
+        theta["sigma2"] = np.mean(np.diag(np.cov(Y.T))) + 0.001
+    else:
+        N = Y.shape[0]
+        y_mean = np.zeros(D)
+        for n in range(N):
+            y_mean[x_infr[n]] += Y[n][x_infr[n]]
+        y_mean = y_mean / N
+        tmp = np.zeros(D)
+        for n in range(N):
+            tmp[x_infr[n]] += (Y[n][x_infr[n]] - y_mean[x_infr[n]]) ** 2
+        theta["sigma2"] = tmp.sum() / x_infr.flatten().sum() + 0.001
     theta["W"] = y_mean[:, None] + np.random.normal(scale=np.sqrt(theta["sigma2"]) / 4.0, size=[D, H])
     return theta
 
 
-def sssc_precompute(theta, D):
-    """sssc.py:328-366 (complete data).  sigma2 goes through longdouble like the reference."""
+def sssc_precompute(theta, D, x_infr=None):
+    """sssc.py:328-366.  sigma2 goes through longdouble like the reference; incomplete data
+    (sssc.py:352-357): the Gaussian normaliser counts the reliable entries."""
     pies = theta["pies"]
     s2 = np.asarray(theta["sigma2"]).astype("longdouble")
     theta["ljc"] = np.log(1.0 - pies).sum() - D / 2 * np.log(2 * np.pi)
@@ -607,13 +621,19 @@ def sssc_precompute(theta, D):
     theta["pil_bar"] = np.log(pies / (1.0 - pies))
     theta["sigma2_inv"] = (1.0 / s2).astype(np.float64)
     theta["ljc"] -= 0.5 * (D * np.log(s2).astype(np.float64))
+    if x_infr is not None and not x_infr.all():
+        sum_n_d = x_infr.sum()
+        theta["ljc"] = (np.log(1.0 - pies).sum()
+                        + (-np.log(2 * np.pi) - np.log(theta["sigma2"])) * sum_n_d / x_infr.shape[0] / 2)
     return new_counters()
 
 
-def sssc_state_terms(theta, state):
-    """sssc.py:276-318: everything the reference caches per state id."""
+def sssc_state_terms(theta, state, obs=None):
+    """sssc.py:276-318: everything the reference caches per state id (obs = this datapoint's x_infr:
+    with incomplete data the terms belong to the datapoint, i.e. use_storage must be False)."""
     W, Psi, mus, s2i = theta["W"], theta["Psi"], theta["mus"], theta["sigma2_inv"]
-    obs = np.ones(W.shape[0], dtype=bool)  # complete data; same indexing expression as the reference
+    if obs is None:
+        obs = np.ones(W.shape[0], dtype=bool)  # complete data; same indexing expression as the reference
     W_s = W[obs, :][:, state]
     Psi_s = Psi[state, :][:, state]
     Psi_s_inv = np.linalg.inv(Psi_s)
@@ -624,13 +644,15 @@ def sssc_state_terms(theta, state):
     logdet_M = np.linalg.slogdet(M)[1]
     lam = np.linalg.inv(M)
     lam_Wt = np.dot(lam, W_s.T) * s2i
-    C_inv = -np.dot(sW, lam_Wt) + s2i * np.eye(W.shape[0])
+    C_inv = -np.dot(sW, lam_Wt) + s2i * np.eye(int(obs.sum()))
     return {"Wmu": Wmu, "C_det": logdet_M + logdet_Psi, "C_inv": C_inv, "lam": lam, "lam_Wt": lam_Wt}
 
 
-def sssc_lpj(theta, states, y, counters, cache):
+def sssc_lpj(theta, states, y, counters, cache, obs=None):
     """sssc.py:241-326.  ``cache`` maps state bytes -> sssc_state_terms (the reference's
-    ``storage``; numerically a pure memo)."""
+    ``storage``; numerically a pure memo for complete data)."""
+    if obs is not None:
+        y = y[obs]
     C = states.shape[0]
     quad = np.zeros(C)
     prior = np.zeros(C)
@@ -639,33 +661,39 @@ def sssc_lpj(theta, states, y, counters, cache):
         key = st.tobytes()
         prior[c] = theta["pil_bar"][st].sum()
         if key not in cache:
-            cache[key] = sssc_state_terms(theta, st)
+            cache[key] = sssc_state_terms(theta, st, obs)
         t = cache[key]
         r = y - t["Wmu"]
         quad[c] = -0.5 * (t["C_det"] + (r * np.dot(t["C_inv"], r)).sum())
     return lpj_clamp(quad + prior, counters)
 
 
-def sssc_lpj_allzero(theta, y, counters):
+def sssc_lpj_allzero(theta, y, counters, obs=None):
     """sssc.py:224-239."""
     lpj = np.empty((1,))
+    if obs is not None:
+        y = y[obs]
     lpj[0] = -0.5 * (y ** 2).sum() * theta["sigma2_inv"]
     return lpj_clamp(lpj, counters)
 
 
 def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
-                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True, reconstruct_x=None):
+                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True, reconstruct_x=None, x_infr=None):
     """sssc.py:419-656: the fused per-datapoint loop (E-step + sufficient statistics) on one
     rank.  Returns the dict of per-rank sums the reference all-reduces (sssc.py:671-691,763,
     773-780).  With evolve=False the EA / selection is skipped (statistics of the resident K^n)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     S = suff["ss"].shape[1]
-    counters = sssc_precompute(theta, D)
+    incmpl = x_infr is not None and not x_infr.all()
+    if incmpl:
+        assert not use_storage and reconstruct_x is not None  # the reference needs both (sssc.py:630-633)
+    counters = sssc_precompute(theta, D, x_infr)
     S_perm, incl, Mprime = suff["S_perm"], suff["incl"], suff["Mprime"]
     lpj_all, ss = suff["lpj"], suff["ss"]
     mus = theta["mus"]
     cache = {}
+    trace_WW = 0.0   # trace of sum_n outer(W_obs xpt_sz) (sssc.py:640-645,751)
     acc = {
         "xpt_s": np.zeros(H), "xpt_ss": np.zeros((H, H)), "xpt_sz": np.zeros(H),
         "xpt_szsz": np.zeros((H, H)), "Wp": np.zeros((D, H)),
@@ -675,13 +703,14 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
     y_rec = Y.copy() if reconstruct_x is not None else None   # sssc.py:500-507
     for n in range(N):
         y = Y[n]
+        obs = x_infr[n] if incmpl else None
         cur = ss[n]
         if S_perm > 0:
-            lpj_all[n, 0:S_perm] = sssc_lpj_allzero(theta, y, counters)
-        cur_lpj = sssc_lpj(theta, cur, y, counters, cache)
+            lpj_all[n, 0:S_perm] = sssc_lpj_allzero(theta, y, counters, obs)
+        cur_lpj = sssc_lpj(theta, cur, y, counters, cache, obs)
         if evolve:
             new_s, new_l = evolve_states(cur, cur_lpj, suff, theta["piH"],
-                                         lambda st: sssc_lpj(theta, st, y, counters, cache))
+                                         lambda st: sssc_lpj(theta, st, y, counters, cache, obs))
             if trace is not None:
                 trace.append((n, new_s.copy(), new_l.copy()))
             a, b = vary_Kn(cur_lpj, new_l, lpj_all[n, S_perm:], cur, new_s, H, S, S_perm, incl, Mprime)
@@ -700,7 +729,7 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
             st = cur[s]
             w = q[s + S_perm]
             t = cache[st.tobytes()]
-            kappa = np.dot(t["lam_Wt"], y - t["Wmu"])
+            kappa = np.dot(t["lam_Wt"], (y[obs] if incmpl else y) - t["Wmu"])
             kappa += mus[st]
             second = t["lam"] + np.outer(kappa, kappa)
             e_sz[st] += kappa * w
@@ -721,7 +750,7 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
             for s in range(S):
                 st = cur[s]
                 t = cache[st.tobytes()]
-                kappa_s = np.dot(t["lam_Wt"], y - t["Wmu"])
+                kappa_s = np.dot(t["lam_Wt"], (y[obs] if incmpl else y) - t["Wmu"])
                 kappa_s += mus[st]
                 this_sz[st, s] = kappa_s
             this_mus = np.dot(theta["W"][np.logical_not(this_x), :], this_sz)   # (D_miss, S)
@@ -731,12 +760,23 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
         acc["xpt_ss"] += e_ss
         acc["xpt_sz"] += e_sz
         acc["xpt_szsz"] += e_szsz
-        acc["Wp"] += e_sz[None, :] * y[:, None]          # sssc.py:634
+        if incmpl:
+            acc["Wp"] += e_sz[None, :] * y_rec[n][:, None]   # sssc.py:631: the reconstructed row
+            Wx = np.dot(theta["W"][obs, :], e_sz)            # sssc.py:640-645
+            trace_WW += (Wx ** 2).sum()
+        else:
+            acc["Wp"] += e_sz[None, :] * y[:, None]      # sssc.py:634
         acc["s_sz_outer"] += np.outer(e_s, e_sz)         # sssc.py:637
         acc["sz_sz_outer"] += np.outer(e_sz, e_sz)       # sssc.py:646
         if not use_storage:
             cache = {}
-    acc["y_outer_diag"] = (Y ** 2).sum(axis=0)           # sssc.py:761
+    if incmpl:
+        acc["y_inner"] = (Y[x_infr] ** 2).sum()          # sssc.py:748
+        acc["trace_WW"] = trace_WW
+        acc["n_reliable"] = x_infr.sum()
+        acc["y_outer_diag"] = np.where(x_infr, Y, 0.0).__pow__(2).sum(axis=0)
+    else:
+        acc["y_outer_diag"] = (Y ** 2).sum(axis=0)       # sssc.py:761
     acc["Fs"] = free_energy_sum(lpj_all)                 # sssc.py:777-779
     acc["n_uniq"] = n_uniq
     acc["n_sub"] = n_sub
@@ -750,6 +790,7 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
     """sssc.py:687-770: Theta update from the all-reduced sums, including the reference's
     element-wise Psi product and dead '+eps' statement and the sigma2 formula
     built from first moments and the *new* W (Q4).  Mutates and returns theta."""
+    sigma2_old = theta["sigma2"]
     if "W" in to_learn:
         theta["W"] = np.dot(acc["Wp"], np.linalg.inv(acc["xpt_szsz"]))
     if "pies" in to_learn:
@@ -766,22 +807,27 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
         Psi -= 2 * theta["mus"][:, None] * acc["s_sz_outer"]
         theta["Psi"] = Psi * np.linalg.inv(acc["xpt_ss"] + EPS_PSI * np.eye(H))
     if "sigma2" in to_learn:
-        WtW = np.dot(theta["W"].T, theta["W"])
-        s2 = 0.0
-        s2 += acc["y_outer_diag"].sum()
-        s2 -= np.trace(np.dot(acc["sz_sz_outer"], WtW))
-        theta["sigma2"] = (s2 / N / D) + EPS_SIGMA2
+        if "trace_WW" in acc:  # incomplete data, sssc.py:747-755 (OLD sigma2 x count of reliable entries)
+            s2 = acc["y_inner"] - acc["trace_WW"]
+            theta["sigma2"] = ((s2 + acc["n_reliable"] * sigma2_old) / N / D) + EPS_SIGMA2
+        else:
+            WtW = np.dot(theta["W"].T, theta["W"])
+            s2 = 0.0
+            s2 += acc["y_outer_diag"].sum()
+            s2 -= np.trace(np.dot(acc["sz_sz_outer"], WtW))
+            theta["sigma2"] = (s2 / N / D) + EPS_SIGMA2
     return theta
 
 
 def sssc_step(theta, suff, Y, use_storage=True, to_learn=("W", "pies", "mus", "sigma2", "Psi"),
-              trace=None, reconstruct_x=None):
+              trace=None, reconstruct_x=None, x_infr=None):
     """sssc.py:407-417 + EM_step on one rank.  Returns (F, S_nunique, S_sub, theta, acc).
     F uses the *old* Theta's ljc (sssc.py:472,780)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     theta = check_params(theta, SSSC_POLICY)
-    acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn, reconstruct_x=reconstruct_x)
+    acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn, reconstruct_x=reconstruct_x,
+                             x_infr=x_infr)
     ljc = theta["ljc"]
     theta = sssc_update(theta, acc, N, D, H, to_learn)
     F = ljc + acc["Fs"] / N

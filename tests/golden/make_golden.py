@@ -344,6 +344,42 @@ def make_recon_fixture(name, algo, D, H, S, N, seed, n_steps=2):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_missing_fixture_es3c(D=25, H=10, S=8, N=36, seed=41, n_steps=2):
+    """ES3C on incomplete data (NaN holes, x_infr = x = ~isnan(y)); the reference needs
+    use_storage=False (the cached state terms depend on the datapoint's reliable entries) and
+    do_reconstruction=True in every step (sssc.py:630-633 reads this_y_rec)."""
+    np.random.seed(seed)
+    model = SSSC(D, H, S, use_storage=False)
+    gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
+    Y = BSC(D, H, S).generate_data(gen, N)["y"]
+    miss = np.random.random_sample(Y.shape) < 0.25
+    miss[0] = False
+    Y = Y.copy()
+    Y[miss] = np.nan
+    x_infr = np.logical_not(np.isnan(Y))
+    my_data = {"y": Y, "x_infr": x_infr, "x": x_infr.copy()}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, "fit", "randflip", 5, 1, 1)
+    out = {"algo": np.array("es3c"), "D": np.int64(D), "H": np.int64(H), "S": np.int64(S), "N": np.int64(N),
+           "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y": Y, "x_infr": x_infr,
+           "ea_parent_selection": np.array("fit"), "ea_mutation": np.array("randflip"),
+           "ea_n_parents": np.int64(5), "ea_n_children": np.int64(1), "ea_n_generations": np.int64(1),
+           "ea_bitflip_prob": np.float64(np.nan), "ea_Mprime": np.int64(suff["Mprime"])}
+    out["t0_ss_in"] = pack(suff["ss"])
+    out.update(theta_arrays("t0_in_", theta, SSSC_KEYS))
+    for t in range(n_steps):
+        np.random.seed(1000 + seed + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data, do_reconstruction=True)
+        out["t%d_F" % t] = np.float64(F)
+        out["t%d_y_reconstructed" % t] = my_data["y_reconstructed"].copy()
+        out["t%d_ss_out" % t] = pack(suff["ss"])
+        out["t%d_lpj_out" % t] = suff["lpj"].copy()
+        out.update(theta_arrays("t%d_out_" % t, theta, SSSC_KEYS))
+    path = os.path.join(HERE, "missing_es3c.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_missing_fixture(name="ebsc", D=25, H=10, S=8, N=40, seed=31, n_steps=3):
     """EBSC on incomplete data, the image-inpainting use (examples/image-inpainting/main.py:105-111):
     y holds NaN where a value is missing, x_infr = x = ~isnan(y); step 0 and 1 reconstruct, step 2
@@ -386,6 +422,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "missing":  # only the incomplete-data fixture (added later)
         make_missing_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "missing_es3c":
+        make_missing_fixture_es3c()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "recon":  # only the reconstruction fixtures (added later)
         make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
         make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)
@@ -406,3 +445,4 @@ if __name__ == "__main__":
     make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
     make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)
     make_missing_fixture()
+    make_missing_fixture_es3c()

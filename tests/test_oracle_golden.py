@@ -228,3 +228,23 @@ def test_standard_init_incomplete_data():
     th = orc.check_params(orc.bsc_standard_init(g["Y"], H, g["x_infr"]), orc.BSC_POLICY)
     for k in BSC_KEYS:
         np.testing.assert_allclose(th[k], g["t0_in_%s" % k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_missing_data_replay_es3c():
+    """ES3C on incomplete data: per-datapoint W_obs in the state terms (sssc.py:276-318), ljc over the
+    reliable entries (:352-357), Wp from the reconstructed rows (:631), the incomplete-data sigma2
+    (:747-755), reconstruction (:613-627) -- two chained steps against the reference."""
+    g = load_golden("missing_es3c.npz")
+    H = int(g["H"])
+    Y, x_infr = g["Y"], g["x_infr"]
+    theta = theta_in(g, 0, SSSC_KEYS)
+    suff = suff_from_fixture(g, unpack_bits(g["t0_ss_in"], H))
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        F, nu, nsub, theta, acc = orc.sssc_step(theta, suff, Y, use_storage=False, reconstruct_x=x_infr, x_infr=x_infr)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-12)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t])
+        np.testing.assert_allclose(suff["lpj"], g["t%d_lpj_out" % t], rtol=1e-11)
+        np.testing.assert_allclose(acc["y_reconstructed"], g["t%d_y_reconstructed" % t], rtol=1e-10, atol=1e-11)
+        for k in SSSC_KEYS:
+            np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-8, atol=1e-10, err_msg=k)
