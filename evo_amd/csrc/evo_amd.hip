@@ -564,7 +564,6 @@ extern "C" int evoamd_upload_masks(evoamd_ctx *c, const uint8_t *x_infr, const u
     c->yrec_valid = false;
     return 0;
   }
-  REQUIRE(c->model == EVOAMD_MODEL_BSC, "incomplete data (x_infr) is implemented for EBSC only");
   const size_t nd = (size_t)c->N * c->D;
   ALLOC(c->mask_infr, nd);
   ALLOC(c->mask_x, nd);
@@ -576,6 +575,11 @@ extern "C" int evoamd_upload_masks(evoamd_ctx *c, const uint8_t *x_infr, const u
   row_sqnorm_kernel<<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->yy);
   HIP_TRY(hipMemsetAsync(c->y2sum, 0, (size_t)c->D * sizeof(double), c->stream));
   launch_colsum<true>(c, c->Y, c->ldY, c->N, c->D, c->y2sum);
+  if (c->model == EVOAMD_MODEL_SSSC) {  // W^T (H, D) for the per-datapoint Gram blocks
+    if (!c->Wt) ALLOC(c->Wt, (size_t)c->H * c->D);
+    if (c->have_params)
+      transpose_kernel<<<cdiv((i64)c->H * c->D, 256), 256, 0, c->stream>>>(c->W, c->D, c->H, c->Wt);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->yrec_valid = false;
@@ -823,6 +827,10 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   if (r) return r;
   sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
                                                                      c->PT, c->GP, c->DG);
+  if (c->mask_infr) {  // incomplete data: the per-datapoint Gram blocks read W^T
+    if (!c->Wt) ALLOC(c->Wt, (size_t)H * D);
+    transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->W, D, H, c->Wt);
+  }
   HIP_TRY(hipGetLastError());
   c->B_valid = false;
   if (c->have_data) {
@@ -948,6 +956,9 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.col0 = b.col0;
   a.flags = b.flags;
   a.err = c->err;
+  a.mask = b.mask;
+  a.Wt = c->Wt;
+  a.D = c->D;
   return a;
 }
 
@@ -1003,6 +1014,20 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
   const int cap = (int)list_cap(total);
   int r = zero_lists(c);
   if (r) return r;
+  if (a.mask) {
+    // incomplete data: G_A belongs to the datapoint, so no tables and no Gram gathers: the
+    // wavefront-per-state kernel forms W_obs^T W_obs for every pair (k <= 8 first, the rest via list 3)
+    const ListIn nat = {nullptr, nullptr, 0};
+    const ListOut l3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
+    const ListIn i3m = {l3.items, l3.counts, cap};
+    const ListOut none_out = {nullptr, nullptr, 0};
+    SpanGuard g(c, kid_main);
+    const int gridm = (int)std::min<i64>(total, 65536);
+    sssc_big_kernel<0><<<gridm, 64, big_lds(8), c->stream>>>(a, nat, l3, 8);
+    sssc_big_kernel<0><<<1024, 64, big_lds(SSSC_KCAP), c->stream>>>(a, i3m, none_out, SSSC_KCAP);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const ListIn none = {nullptr, nullptr, 0};
   const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                 o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
@@ -1217,7 +1242,6 @@ extern "C" int evoamd_lpj_shared(evoamd_ctx *c, const uint8_t *states_bool, int 
 static int lpj_single_impl(evoamd_ctx *c, const double *y, const uint8_t *x_infr, const uint8_t *states_bool, int C,
                            double *lpj_out, int32_t *flags_out) {
   REQUIRE(c && c->configured && c->have_params, "configure and set_params first");
-  REQUIRE(!x_infr || c->model == EVOAMD_MODEL_BSC, "incomplete data: EBSC only");
   REQUIRE(y && states_bool && lpj_out && C > 0, "bad arguments");
   HIP_TRY(hipSetDevice(c->device));
   int r = ensure_tmp(c, (size_t)C * c->HW, (size_t)C + 2);
@@ -1436,6 +1460,8 @@ static int stats_compute(evoamd_ctx *c) {
   } else {
     double *Es = c->Y + D, *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed]
     Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS, 0};
+    b.mask = c->mask_infr;
+    const bool masked = c->mask_infr != nullptr;
     SsscArgs sa = sssc_args(c, b);
     sa.lpj_in = c->lpj;
     sa.rowmax = c->rowmax;
@@ -1456,49 +1482,62 @@ static int stats_compute(evoamd_ctx *c) {
     const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                   o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
     const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
-    {
-      // workgroups own whole datapoints; rows of Es / Ez / Ed staged in LDS (<= 64 KiB)
-      int npb = 256 / c->S;
-      if (npb < 1) npb = 1;
-      const int lim = (int)(65536 / ((size_t)24 * H));
-      if (npb > lim) npb = lim < 1 ? 1 : lim;
-      const size_t lds = (size_t)npb * 3 * H * sizeof(double);
-      SpanGuard g(c, KID_STATS);
-      const int sgrid = (int)cdiv(N, npb);
-      switch (c->HW) {
-        case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-        case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-        case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-        case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-        case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-        default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-      }
-      HIP_TRY(hipGetLastError());
-    }
-    if (need[0] || need[1] || need[2]) {
-      SpanGuard g(c, KID_STATS_OVF);
-      const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
-      if (need[0])
-        sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sa, i1, o2);
+    if (masked) {
+      // incomplete data (sssc.py:276: W[this_x_infr, :]): the state terms belong to the datapoint, so every
+      // state goes through the wavefront kernel, which forms W_obs^T W_obs itself and ADDS its moments to
+      // the rows (they start from zero here)
+      HIP_TRY(hipMemset2DAsync(Es, (size_t)c->ldY * sizeof(double), 0, (size_t)3 * H * sizeof(double), (size_t)N, c->stream));
+      const ListIn nat = {nullptr, nullptr, 0};
       const ListOut none_out = {nullptr, nullptr, 0};
-      if (use_k8_kernel(c, tg)) {
-        if (need[1])
-          sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sa, i2, o3);
-      } else if (need[1]) {
-        sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sa, i2, o3, 8);
-      }
-      if (need[2])
-        sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-            sa, i3, none_out, SSSC_KCAP);
+      SpanGuard g(c, KID_STATS);
+      sssc_big_kernel<1><<<(int)std::min<i64>(total, 65536), 64, big_lds(8), c->stream>>>(sa, nat, o3, 8);
+      sssc_big_kernel<1><<<1024, 64, big_lds(SSSC_KCAP), c->stream>>>(sa, i3, none_out, SSSC_KCAP);
       HIP_TRY(hipGetLastError());
-    }
-    // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
-    // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
-    for (int j = 0; j < 3; j++)
-      if (!need[j]) {
-        skipped |= 1 << j;
-        break;
+    } else {
+      {
+        // workgroups own whole datapoints; rows of Es / Ez / Ed staged in LDS (<= 64 KiB)
+        int npb = 256 / c->S;
+        if (npb < 1) npb = 1;
+        const int lim = (int)(65536 / ((size_t)24 * H));
+        if (npb > lim) npb = lim < 1 ? 1 : lim;
+        const size_t lds = (size_t)npb * 3 * H * sizeof(double);
+        SpanGuard g(c, KID_STATS);
+        const int sgrid = (int)cdiv(N, npb);
+        switch (c->HW) {
+          case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+        }
+        HIP_TRY(hipGetLastError());
       }
+      if (need[0] || need[1] || need[2]) {
+        SpanGuard g(c, KID_STATS_OVF);
+        const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
+        if (need[0])
+          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sa, i1, o2);
+        const ListOut none_out = {nullptr, nullptr, 0};
+        if (use_k8_kernel(c, tg)) {
+          if (need[1])
+            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sa, i2, o3);
+        } else if (need[1]) {
+          sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sa, i2, o3, 8);
+        }
+        if (need[2])
+          sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+              sa, i3, none_out, SSSC_KCAP);
+        HIP_TRY(hipGetLastError());
+      }
+      // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
+      // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
+      for (int j = 0; j < 3; j++)
+        if (!need[j]) {
+          skipped |= 1 << j;
+          break;
+        }
+    }
     {
       SpanGuard g(c, KID_MISC);
       r = ensure_colpart(c, (size_t)nblk * 3 * H);
@@ -1512,10 +1551,27 @@ static int stats_compute(evoamd_ctx *c) {
     }
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
     // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
-    r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
-                       ((D + H) % GEMM_BM) == 0 ? D + H : -1,  // launch_gemm_tn drops the hint if its tile does not divide it
-                       /*c_is_zero=*/true);                    // acc was cleared at the top of stats_compute
-    if (r) return r;
+    if (masked) {
+      // y_hat = Ez W^T with the Theta of this E-step: the reconstruction (sssc.py:613-627), the rows the Wp
+      // contraction reads (:631) and, squared over the reliable entries, the trace term of sigma2 (:640-645,751)
+      r = compute_reconstruction(c);
+      if (r) return r;
+      REQUIRE(c->rec_in_stats, "ES3C on incomplete data needs do_reconstruction in every step (sssc.py:630-633)");
+      select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
+      HIP_TRY(hipGetLastError());
+      c->yrec_valid = true;
+      c->rec_in_stats = false;
+      r = launch_gemm_tn(c, Es, c->ldY, Ez, c->ldY, c->acc + a.sWp + (size_t)D * H, H, 2 * H, H, N, false,
+                         (H % GEMM_BM) == 0 ? H : -1, /*c_is_zero=*/true);
+      if (r) return r;
+      r = launch_gemm_tn(c, c->Yrec, D, Ez, c->ldY, c->acc + a.sWp, H, D, H, N, false, -1, /*c_is_zero=*/true);
+      if (r) return r;
+    } else {
+      r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
+                         ((D + H) % GEMM_BM) == 0 ? D + H : -1,  // launch_gemm_tn drops the hint if its tile does not divide it
+                         /*c_is_zero=*/true);                    // acc was cleared at the top of stats_compute
+      if (r) return r;
+    }
   }
   {
     SpanGuard g(c, KID_MISC);
@@ -1523,6 +1579,10 @@ static int stats_compute(evoamd_ctx *c) {
                                           c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped);
     HIP_TRY(hipGetLastError());
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
+    if (c->model == EVOAMD_MODEL_SSSC && c->mask_infr) {  // tail[7] = sum over reliable entries of y_hat^2
+      masked_sqsum_kernel<<<256, 256, 0, c->stream>>>(c->yhat, c->mask_infr, N * (i64)D, c->acc + a.tail + 7);
+      HIP_TRY(hipGetLastError());
+    }
   }
   if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));

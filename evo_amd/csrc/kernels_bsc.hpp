@@ -301,6 +301,23 @@ __global__ __launch_bounds__(256) void select_rec_kernel(const double *__restric
   }
 }
 
+// out[0] += sum over reliable entries of v^2 (ES3C incomplete data: trace of sum_n outer(W_obs xpt_sz),
+// sssc.py:640-645,751, from y_hat = W xpt_sz); one atomic per workgroup.
+__global__ __launch_bounds__(256) void masked_sqsum_kernel(const double *__restrict__ v, const uint8_t *__restrict__ mask,
+                                                           i64 n, double *__restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256)
+    if (mask[i]) s = fma(v[i], v[i], s);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0]);
+}
+
 // Permanent all-zero state: lpj = pre * ||y_n||^2 (bsc.py:72 with pre = pre1; sssc.py:237 with
 // pre = -0.5*sigma2_inv).  yy (N) is the precomputed squared norm.  One thread per n.
 __global__ __launch_bounds__(256) void allzero_lpj_kernel(const double *__restrict__ yy, i64 N,

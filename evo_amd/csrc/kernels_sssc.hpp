@@ -62,6 +62,10 @@ struct SsscArgs {
   int ldE;
   double *xss, *xszsz;    // (H,H) zero-initialised
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
+  // incomplete data (sssc.py:276 W[this_x_infr, :]): reliable-entry mask rows of this batch, W^T, D
+  const uint8_t *mask;    // (N, D) or nullptr
+  const double *Wt;       // (H, D)
+  int D;
 };
 
 #define SSSC_KCAP 64
@@ -781,6 +785,26 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
       Gm[q] = gp.x;
       Pm[q] = gp.y;
+    }
+    if (a.mask) {
+      // incomplete data: G_A of THIS datapoint, W_obs^T W_obs restricted to A -- k (k + 1) / 2 masked dot
+      // products over D, lanes over the observables (rows of W^T are contiguous)
+      __syncthreads();
+      const uint8_t *mrow = a.mask + n * a.D;
+      for (int i = 0; i < k; i++) {
+        const double *wi = a.Wt + (i64)idx[i] * a.D;
+        for (int j = i; j < k; j++) {
+          const double *wj = a.Wt + (i64)idx[j] * a.D;
+          double sdot = 0.0;
+          for (int d = lane; d < a.D; d += 64)
+            if (mrow[d]) sdot = fma(wi[d], wj[d], sdot);
+          sdot = wave_sum(sdot);
+          if (lane == 0) {
+            Gm[i * k + j] = sdot;
+            Gm[j * k + i] = sdot;
+          }
+        }
+      }
     }
     __syncthreads();
     double rr_part = 0.0;

@@ -134,11 +134,9 @@ class Model:
         if new_masks:  # checked once per array object, like the Y upload below
             self._incomplete = not xi.all()
             if self._incomplete:
-                if self.model_name != "bsc":
-                    raise NotImplementedError("missing data (x_infr) is implemented for EBSC only (SURVEY 8f rank 3)")
                 if self.device_mstep:
                     raise NotImplementedError("missing data: use device_mstep=False (the Theta update of bsc.py:113-118,"
-                                              "266-272 runs on the host)")
+                                              "266-272 / sssc.py:352-357,747-755 runs on the host)")
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])
@@ -362,8 +360,6 @@ class Model:
         states = np.ascontiguousarray(my_suff_stat["this_states"], dtype=bool)
         xi = my_data.get("this_x_infr")
         masked = xi is not None and not np.all(xi)
-        if masked and self.model_name != "bsc":
-            raise NotImplementedError("missing data (x_infr) is implemented for EBSC only (SURVEY 8f rank 3)")
         this_y = my_data["this_y"]
         out, flags = eng.lpj_single(np.where(xi, this_y, 0.0) if masked else this_y, states, xi if masked else None)
         for key, f in zip(("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"), flags):

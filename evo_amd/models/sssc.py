@@ -57,15 +57,21 @@ class SSSC(Model):
         learned), Psi = I, sigma2 = mean diag cov + 1e-3, W = data mean + N(0, sigma2/16).  RNG call
         order as in the reference; the ``"random_uniform"`` choice is overwritten by the
         following branch there too."""
-        if not my_data["x_infr"].all():
-            raise NotImplementedError("missing data is outside the accelerated path")
         comm, H, D = self.comm, self.H, self.D
         Y = my_data["y"]
+        xi = my_data["x_infr"]
         theta = {"pies": comm.bcast(np.random.uniform(low=0.1, high=0.5, size=[H]))}
         theta["mus"] = comm.bcast(np.random.normal(0, 1, [H])) if "mus" in self.to_learn else comm.bcast(np.ones(H))
         theta["Psi"] = np.diag(comm.bcast(np.ones(H)))
-        y_mean, _, _ = self._data_moments(my_data)
-        theta["sigma2"] = np.mean(np.diag(np.cov(Y.T))) + 0.001 if sigma_init is None else sigma_init
+        if xi.all():
+            y_mean, _, _ = self._data_moments(my_data)
+            theta["sigma2"] = np.mean(np.diag(np.cov(Y.T))) + 0.001 if sigma_init is None else sigma_init
+        else:  # sssc.py:144-176: sums over the reliable entries, mean divided by the global N
+            Yz = np.where(xi, Y, 0.0)
+            N = comm.allreduce(Y.shape[0])
+            y_mean = comm.allreduce(Yz.sum(axis=0)) / N
+            tmp = (np.where(xi, Yz - y_mean, 0.0) ** 2).sum()
+            theta["sigma2"] = (comm.allreduce(tmp / xi.sum()) + 0.001) if sigma_init is None else sigma_init
         if type(W_init) is not np.ndarray:
             if W_init == "random_uniform":
                 theta["W"] = comm.bcast(np.random.random((D, H)))
@@ -107,6 +113,13 @@ class SSSC(Model):
         model_params["pil_bar"] = np.log(pies / (1.0 - pies))
         model_params["sigma2_inv"] = (1.0 / s2).astype(np.float64)
         model_params["ljc"] = ljc - 0.5 * (D * np.log(s2).astype(np.float64))
+        xi = my_data["x_infr"]
+        self._n_reliable = None
+        if not xi.all():  # sssc.py:352-357: the Gaussian normaliser counts the reliable entries
+            N = self.comm.allreduce(xi.shape[0])
+            self._n_reliable = self.comm.allreduce(int(xi.sum()))
+            model_params["ljc"] = (np.log(1.0 - pies).sum()
+                                   + (-np.log(2 * np.pi) - np.log(model_params["sigma2"])) * self._n_reliable / N / 2)
         for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf", "Psi_s_pinv"):
             my_suff_stat[key] = 0
         if self._engine_matches():
@@ -130,6 +143,7 @@ class SSSC(Model):
         Mutates and returns ``model_params``."""
         H, D = self.H, self.D
         learn = self.to_learn
+        sigma2_old = model_params["sigma2"]
         if "W" in learn:
             try:
                 W_new = np.dot(sums["Wp"], np.linalg.inv(sums["xpt_szsz"]))
@@ -157,18 +171,29 @@ class SSSC(Model):
             Psi -= 2 * mus[:, None] * sums["s_sz_outer"]
             model_params["Psi"] = Psi * np.linalg.inv(sums["xpt_ss"] + self.eps_Psi * np.eye(H))
         if "sigma2" in learn:
-            WtW = np.dot(model_params["W"].T, model_params["W"])
-            s2 = 0.0
-            s2 += sums["y_outer_diag"].sum()
-            s2 -= np.trace(np.dot(sums["sz_sz_outer"], WtW))
-            model_params["sigma2"] = (s2 / N / D) + self.eps_sigma2
+            n_rel = getattr(self, "_n_reliable", None)
+            if n_rel is not None:
+                # sssc.py:747-755: sum y_obs^2 - trace(sum_n outer(W_obs xpt_sz)) + (#reliable) * OLD sigma2;
+                # the trace arrives as the masked square sum of y_hat in the accumulator tail
+                s2 = sums["y_outer_diag"].sum() - float(sums["pad"])
+                model_params["sigma2"] = ((s2 + n_rel * sigma2_old) / N / D) + self.eps_sigma2
+            else:
+                WtW = np.dot(model_params["W"].T, model_params["W"])
+                s2 = 0.0
+                s2 += sums["y_outer_diag"].sum()
+                s2 -= np.trace(np.dot(sums["sz_sz_outer"], WtW))
+                model_params["sigma2"] = (s2 / N / D) + self.eps_sigma2
         return model_params
 
     def EM_step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """Fused E- and M-step (sssc.py:419-813).  Returns (F, S_nunique, S_sub, Theta_new); F uses
         the ljc of the Theta the E-step ran with (sssc.py:472,780)."""
-        F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True)
-        if do_reconstruction:  # sssc.py:500-507,613-627: estimates under the Theta of this E-step
+        if not my_data["x_infr"].all() and not do_reconstruction:
+            raise ValueError("ES3C on incomplete data needs do_reconstruction=True in every step: the reference's "
+                             "Wp accumulation reads the reconstructed row (sssc.py:630-633)")
+        F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True,
+                                          _reconstruct=do_reconstruction)
+        if do_reconstruction and not self._incomplete:  # sssc.py:500-507,613-627: estimates under the Theta of this E-step
             self._write_reconstruction(my_data)
         v = self.engine.acc_views(self._acc)
         self._acc = None

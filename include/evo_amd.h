@@ -163,7 +163,10 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
  * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
-/* Incomplete data, EBSC (examples/image-inpainting/main.py:105-111).  x_infr (N x D bool
+/* Incomplete data (examples/image-inpainting/main.py:105-111); EBSC as described, ES3C:
+ * every state goes through the wavefront kernel, which forms G_A = W_obs^T W_obs of its datapoint
+ * (sssc.py:276-318), the statistics pass always forms y_hat (it needs reconstruct_in_stats, sssc.py:630-633)
+ * and leaves sum over reliable entries of y_hat^2 in the accumulator tail[7] (sssc.py:640-645,751).  x_infr (N x D bool
  * bytes): reliable entries -- only they enter lpj (bsc.py:59-97), the allzero term and the sigma sum
  * (bsc.py:206-219); x (N x D, NULL = x_infr): entries that keep their value in y_reconstructed.  Call after
  * evoamd_upload_data (missing entries of Y may hold NaN; the device copy zeroes them).  All lpj entry

@@ -367,12 +367,38 @@ def test_missing_data_ebsc_against_reference(engine):
     np.testing.assert_allclose(one, orc.bsc_lpj(th, suff["ss"][n], Y[n], orc.new_counters(), x_infr[n]), rtol=1e-10)
 
 
-def test_missing_data_es3c_is_refused(engine):
+def test_missing_data_es3c_against_reference(engine):
+    """ES3C on incomplete data (per-datapoint W_obs^T W_obs formed inside the wavefront kernel): F, K^n, lpj,
+    y_reconstructed and Theta of two chained steps against tests/golden/missing_es3c.npz (reference with
+    use_storage=False, do_reconstruction=True)."""
     from evo_amd.models import SSSC
-    Y = np.random.RandomState(0).normal(size=(6, 8))
-    xi = np.ones_like(Y, dtype=bool)
-    xi[0, 0] = False
-    model = SSSC(8, 4, 3, engine=engine)
-    with pytest.raises(NotImplementedError):
-        model._prepare({"ss": np.zeros((6, 3, 4), bool), "S_perm": 0, "permanent": {"background": False}},
-                       {"y": Y, "x_infr": xi})
+    g = load_golden("missing_es3c.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    Y, x_infr = g["Y"], g["x_infr"]
+    my_data = {"y": Y, "x_infr": x_infr, "x": x_infr.copy()}
+    model = SSSC(D, H, S, engine=engine)
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in SSSC_KEYS}
+    theta["sigma2"] = np.float64(theta["sigma2"])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + int(g["seed"]) + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data, do_reconstruction=True)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-9, err_msg="F step %d" % t)
+        assert np.array_equal(np.packbits(suff["ss"], axis=-1), g["t%d_ss_out" % t]), "K^n step %d" % t
+        np.testing.assert_allclose(suff["lpj"], g["t%d_lpj_out" % t], rtol=1e-9)
+        np.testing.assert_allclose(my_data["y_reconstructed"], g["t%d_y_reconstructed" % t], rtol=1e-8, atol=1e-9)
+        for k in SSSC_KEYS:
+            ref = g["t%d_out_%s" % (t, k)]
+            np.testing.assert_allclose(theta[k], ref, rtol=1e-6, atol=1e-8 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    with pytest.raises(ValueError):
+        model.step(theta, suff, my_data, do_reconstruction=False)
+    # per-datapoint operator with this_x_infr (sssc.py:245-322) against the oracle
+    from oracle import evo_oracle as orc
+    model.E_step_precompute(theta, suff, my_data)
+    n = 5
+    my_data["this_y"], my_data["this_x_infr"] = Y[n], x_infr[n]
+    suff["this_states"] = suff["ss"][n]
+    one = model.log_pseudo_joint(theta, suff, my_data)
+    th = dict(theta)
+    orc.sssc_precompute(th, D, x_infr)
+    np.testing.assert_allclose(one, orc.sssc_lpj(th, suff["ss"][n], Y[n], orc.new_counters(), {}, x_infr[n]), rtol=1e-9)
