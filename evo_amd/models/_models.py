@@ -496,7 +496,8 @@ class Model:
             body = my_suff_stat["lpj"][:, my_suff_stat["S_perm"]:]
         if S_perm:
             if full or compute_lpj:
-                zero = self._allzero_lpj(model_params, (Y ** 2).sum(axis=1))
+                xi = my_data["x_infr"]
+                zero = self._allzero_lpj(model_params, (np.where(xi, Y, 0.0) ** 2).sum(axis=1))  # reliable entries
                 zero = np.array([self.lpj_reset_check(np.array([z]), my_suff_stat)[0] for z in zero])
             else:
                 zero = my_suff_stat["lpj"][:, 0]
