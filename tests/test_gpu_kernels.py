@@ -315,3 +315,17 @@ def test_gemm_tn_dispatch(engine, K, M, Nc, sym):
     if sym:
         blk = C[M - Nc:]
         assert np.abs(blk - blk.T).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_inverse_above_blocked_limit(engine):
+    """n > 1024: the SPD block path has no size limit; a general matrix falls back to the unblocked
+    pivoted elimination (2 n launches)."""
+    n = 1040
+    rng = np.random.default_rng(11)
+    engine.configure("bsc", 8, 4, n, 4, 0, 4)
+    A = _moment_matrix(rng, n)
+    G = rng.standard_normal((n, n)) + 3.0 * np.eye(n)
+    G[0, 0] = 0.0
+    Ai, Gi, _ = engine.inverse(A, G)
+    assert np.abs(Ai @ A - np.eye(n)).max() < 1e-8
+    assert np.abs(Gi @ G - np.eye(n)).max() < 1e-7
