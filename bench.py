@@ -46,7 +46,13 @@ EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector peak
 # dominant kernel per model (the pass over all N x S resident states) as rocprofv3 names it
-ROOFLINE_KERNEL = {"es3c": "void sssc_main_lpj_kernel<0, 512, 2, 2>", "ebsc": "void bsc_lpj_gram2_kernel<0, HW>"}
+def roofline_kernel(cfg):
+    """Name of the kernel that evaluates all N x S resident states (its template arguments carry the
+    number of 64-bit words per state), as rocprofv3 prints it."""
+    hw = (cfg["H"] + 63) // 64
+    if cfg["algo"] == "es3c":
+        return "void sssc_main_lpj_kernel<0, 512, %d, 2>" % (hw if hw in (1, 2, 4, 8, 16) else 0)
+    return "void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)
 
 
 def pmc_traffic(config, kernel):
@@ -232,10 +238,10 @@ def main():
                        "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world, "free_energy_last": F,
                        "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms,
                        "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_steps},
-            "roofline": {"bound": "hbm", "kernel": ROOFLINE_KERNEL[cfg["algo"]] + " (lpj of all N x S resident states)",
+            "roofline": {"bound": "hbm", "kernel": roofline_kernel(cfg) + " (lpj of all N x S resident states)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.config, ROOFLINE_KERNEL[cfg["algo"]]),
+                         "traffic": pmc_traffic(args.config, roofline_kernel(cfg)),
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                          "2 x FETCH + WRITE (gfx950 read-side correction); committed under profiles/",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms,
