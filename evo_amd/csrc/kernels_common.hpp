@@ -236,9 +236,32 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const unsigned *__rest
 // Deterministic tie rule (NumPy's introselect/quicksort order is unspecified): equal lpj
 // never swaps; among equal candidates / equal old values the lowest index goes first.
 // ---------------------------------------------------------------------------------------
-// 64-bit hash of the HW words of one state; 16-byte loads when HW is even (rows are then 16-byte
-// aligned): per-lane 8-byte loads cost one pass of the address coalescer per word.
+// 64-bit hash of the HW words of one state.  Common widths are dispatched to a fixed-trip-count body so
+// that ALL 16-byte loads of the state are issued before the multiply chain starts (a runtime-length loop
+// waits for each load in turn: 8 serialized round trips per state at H = 1024); per-lane 8-byte loads would
+// also cost one pass of the address coalescer per word.
+template <int HW2>
+__device__ __forceinline__ u64 hash_state_fixed(const u64 *sw) {
+  const ulonglong2 *s2 = (const ulonglong2 *)sw;
+  ulonglong2 v[HW2];
+#pragma unroll
+  for (int i = 0; i < HW2; i++) v[i] = s2[i];
+  u64 h = 0;
+#pragma unroll
+  for (int i = 0; i < HW2; i++) {
+    h = (h ^ v[i].x) * 0x9E3779B97F4A7C15ull + (u64)(2 * i);
+    h = (h ^ v[i].y) * 0x9E3779B97F4A7C15ull + (u64)(2 * i + 1);
+  }
+  return h;
+}
 __device__ __forceinline__ u64 hash_state(const u64 *sw, int HW) {
+  switch (HW) {  // uniform
+    case 2: return hash_state_fixed<1>(sw);
+    case 4: return hash_state_fixed<2>(sw);
+    case 8: return hash_state_fixed<4>(sw);
+    case 16: return hash_state_fixed<8>(sw);
+    default: break;
+  }
   u64 h = 0;
   if ((HW & 1) == 0) {
     const ulonglong2 *s2 = (const ulonglong2 *)sw;
@@ -298,6 +321,19 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     const double *cl_n = cand_lpj + n * (i64)Cmax;
     int cnt = counts[n];
     if (cnt > Cmax) cnt = Cmax;
+    // the lpj values this lane owns: issued first so that they are in flight together with the state
+    // words (this kernel is one dependent chain of global round trips per wave, not bandwidth)
+    double nv_raw[CPL], ov[SPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) {
+      const int c = lane + 64 * q;
+      nv_raw[q] = (c < cnt) ? cl_n[c] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < SPL; q++) {
+      const int s = lane + 64 * q;
+      ov[q] = (s < S) ? lpj_n[s] : 0.0;
+    }
     // --- de-duplicate: candidate c survives iff no equal row precedes it in [incl; K^n; cand[0:c]].
     // Every lane hashes its own old states and its own candidates ONCE (the word loads are the only
     // long-latency part); the scan over candidates then compares 64-bit hashes held in registers
@@ -366,19 +402,14 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
           if (c == lane + 64 * q) keep[q] = true;
       }
     }
-    // --- values owned by this lane
-    double nv[CPL], ov[SPL];
+    // --- values owned by this lane (loaded at the top, see nv_raw / ov)
+    double nv[CPL];
     int nrank[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
       const int c = lane + 64 * q;
-      nv[q] = (c < cnt && keep[q]) ? cl_n[c] : 0.0;
+      nv[q] = (c < cnt && keep[q]) ? nv_raw[q] : 0.0;
       nrank[q] = 0;
-    }
-#pragma unroll
-    for (int q = 0; q < SPL; q++) {
-      const int s = lane + 64 * q;
-      ov[q] = (s < S) ? lpj_n[s] : 0.0;
     }
     const int M = n_uniq < Mprime ? n_uniq : Mprime;
     if (M > 0) {
