@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     if (s < S) {
       const double p = fit_parents ? (key[q] - shift) : 1.0;
       const double u = rng_u01(seed, (u64)n, 1, (u64)s);
-      key[q] = (p > 0.0) ? -log(u) / p : 1e300;  // zero-fitness states are taken last
+      // exponential race key -log(u) / p: the logarithm in single precision (one v_log_f32 instead of
+      // the ~60-instruction f64 routine, S of them per datapoint); only the ORDER of the keys matters and
+      // this mode is statistically, not bit-wise, tied to the reference's sampler
+      const float uf = fmaxf((float)u, 1.17549435e-38f);
+      key[q] = (p > 0.0) ? (double)(-__logf(uf)) / p : 1e300;  // zero-fitness states are taken last
     } else {
       key[q] = INFINITY;
     }
