@@ -1409,7 +1409,8 @@ static int stats_compute(evoamd_ctx *c) {
     r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->dpar + DP_FS);
     if (r) return r;
   }
-  const i64 rpb = 256;
+  // column-sum partials: at most ~128 of them (the finish kernels add them serially per column)
+  const i64 rpb = std::max<i64>(256, cdiv(N, 128));
   const int nblk = (int)cdiv(N, rpb);
   int skipped = 0;
   if (c->model == EVOAMD_MODEL_BSC) {
