@@ -1,6 +1,6 @@
 #!/bin/bash
 # Hardware counters of one kernel during the bench workload, in separate small --pmc passes
-# (rocprofv3 only; no tracing domains).  usage: bash tools/pmc_kernel.sh <config> <kernel substring> [tag]
+# (rocprofv3 only; no tracing domains).  The TA_* counter group aborts rocprofv3 on this pool: not requested.  usage: bash tools/pmc_kernel.sh <config> <kernel substring> [tag]
 CFG=${1:-c4}
 KSUB=${2:-sssc_main_lpj_kernel<0}
 TAG=${3:-pmc}
@@ -19,7 +19,6 @@ done <<GROUPS
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 GROUPS
 python3 - "$OUT" "$KSUB" <<'PY'
