@@ -73,6 +73,13 @@ def algorithmic_bytes_lpj(cfg, N):
     return N * (cfg["D"] * 8 + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
 
 
+def layout_bytes_lpj(cfg, N):
+    """Compulsory bytes of the same pass in THIS implementation's HBM layout: per datapoint the row of
+    B = Y W (H doubles, replaces y_n in the Gram form) and per state one 8-byte digest (count + first
+    active latents, replaces the ceil(H/8) bit words) plus the 8-byte lpj written."""
+    return N * (cfg["H"] * 8 + cfg["S"] * (8 + 8))
+
+
 def gemm_flops_per_step(cfg):
     """Dense f64 contractions of one EM iteration in steady state (the launches timed under
     kernel class "gemm_f64"): the K = N statistics contraction, G = W^T W and B = Y W."""
@@ -245,7 +252,13 @@ def main():
                          "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                          "2 x FETCH + WRITE (gfx950 read-side correction); committed under profiles/",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms,
-                         "launches_timed": lpj_n},
+                         "launches_timed": lpj_n,
+                         "layout_bytes_per_launch": layout_bytes_lpj(cfg, cfg["N"]),
+                         "frac_of_layout_bytes": (layout_bytes_lpj(cfg, cfg["N"]) / (lpj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpj_ms > 0 else 0.0,
+                         "layout_note": "achieved/frac price SURVEY 8d's algorithmic bytes (bit-packed states, y_n); the kernel "
+                                        "reads an 8-byte digest per state and the B = Y W row instead, so at large H it moves "
+                                        "fewer bytes than that figure and frac can exceed 1; frac_of_layout_bytes prices what "
+                                        "this layout must move"},
         }
         g = kernel_ms.get("gemm_f64")
         if g:

@@ -109,6 +109,33 @@ __device__ __forceinline__ int pop_msb(u64 &bits) {
   return b;
 }
 
+// State digest: one u64 per packed state, kept next to the bit words by every kernel that writes
+// states (pack / evolve / vary_kn).  bits 0..7 = number of active latents (saturated at 255),
+// bits 8+14j .. 8+14j+13 = j-th active latent in ascending order, j < 4.  The lpj and statistics
+// kernels read 8 bytes per state instead of ceil(H/64) words whenever k fits the digest (EVO's
+// states are sparse: pi H ~ 1..2 active latents); denser states still go through the words.
+#define DIG_IDX_BITS 14
+#define DIG_MAX_H (1 << DIG_IDX_BITS)
+#define DIG_SLOTS 4
+__device__ __forceinline__ void digest_add(u64 &d, int &k, int h) {
+  if (k < DIG_SLOTS) d |= (u64)h << (8 + DIG_IDX_BITS * k);
+  k++;
+}
+__device__ __forceinline__ u64 digest_close(u64 d, int k) { return d | (u64)(k < 255 ? k : 255); }
+__device__ __forceinline__ int dig_k(u64 d) { return (int)(d & 0xFFull); }
+__device__ __forceinline__ int dig_idx(u64 d, int j) {
+  return (int)((d >> (8 + DIG_IDX_BITS * j)) & (u64)(DIG_MAX_H - 1));
+}
+__device__ __forceinline__ u64 make_digest(const u64 *sp, int HW) {
+  u64 d = 0;
+  int k = 0;
+  for (int w = 0; w < HW; w++) {
+    u64 bits = sp[w];
+    while (bits) digest_add(d, k, w * 64 + pop_msb(bits));
+  }
+  return digest_close(d, k);
+}
+
 // 1/d for the k x k eliminations: hardware reciprocal seed + two Newton steps (error < 1 ulp of
 // the correctly rounded quotient in practice).  LAPACK's getf2 also scales by the reciprocal.
 __device__ __forceinline__ double fast_rcp(double d) {

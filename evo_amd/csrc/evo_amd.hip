@@ -135,6 +135,7 @@ struct evoamd_ctx {
   size_t yhat_n = 0;
   bool yhat_valid = false;
   bool stats_rows_valid = false;  // Es / Ez rows describe the current K^n and Theta
+  bool use_digest = true;   // lpj / statistics kernels read the state digests (option "state_digest")
   bool spd_inverse = true;  // M-step H x H systems: SPD block Gauss-Jordan first, pivoted path on a bad pivot
   long spd_fallbacks = 0;   // how often the pivoted repeat was needed
   bool rows_fresh = false;  // rowmax / rowsum / Fs partials describe the current lpj (written by vary_kn)
@@ -154,6 +155,7 @@ struct evoamd_ctx {
   int *h_err = nullptr;
   // variational state
   u64 *states = nullptr, *cand = nullptr;
+  u64 *dig = nullptr, *cand_dig = nullptr;  // state digests (common.hpp), nullptr when H > DIG_MAX_H
   double *lpj = nullptr, *cand_lpj = nullptr;
   int *cand_counts = nullptr;
   unsigned *flags = nullptr;  // 3 x N: resident | candidates | permanent
@@ -338,7 +340,7 @@ static void free_all(evoamd_ctx *c) {
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
-                  c->tmp_y,  c->tmp_lpj, c->tmp_states};
+                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -377,6 +379,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "reconstruct_in_stats") == 0) {  // one-shot: the next statistics pass forms y_reconstructed first
     c->rec_in_stats = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "state_digest") == 0) {
+    c->use_digest = value != 0;
     return 0;
   }
   if (strcmp(name, "inverse_spd") == 0) {
@@ -454,6 +460,10 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->y2sum, (size_t)D);
   ALLOC(c->states, (size_t)N * S * HW);
   ALLOC(c->cand, (size_t)N * Cmax * HW);
+  if (H <= DIG_MAX_H) {
+    ALLOC(c->dig, (size_t)N * S);
+    ALLOC(c->cand_dig, (size_t)N * Cmax);
+  }
   ALLOC(c->lpj, (size_t)N * c->L);
   ALLOC(c->cand_lpj, (size_t)N * Cmax);
   ALLOC(c->cand_counts, (size_t)N);
@@ -601,6 +611,8 @@ static int pack_to_device(evoamd_ctx *c, const uint8_t *host_bool, i64 nstates, 
   if (bytes > c->stage_bytes) return fail(EVOAMD_E_INVALID, "state batch larger than staging buffer");
   HIP_TRY(hipMemcpyAsync(c->stage, host_bool, bytes, hipMemcpyHostToDevice, c->stream));
   pack_states_kernel<<<cdiv(nstates * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, nstates, c->H, c->HW);
+  u64 *dg = dst == c->states ? c->dig : dst == c->cand ? c->cand_dig : nullptr;
+  if (dg) digest_kernel<<<cdiv(nstates, 256), 256, 0, c->stream>>>(dst, dg, nstates, c->HW);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -872,6 +884,12 @@ struct Batch {
   const uint8_t *mask = nullptr;  // EBSC incomplete data: x_infr rows of this batch's datapoints
 };
 
+// digests exist for the two resident state arrays only
+static const u64 *dig_for(const evoamd_ctx *c, const u64 *states) {
+  if (!c->use_digest) return nullptr;
+  return states == c->states ? c->dig : states == c->cand ? c->cand_dig : nullptr;
+}
+
 static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
   if (!c->bsc_direct && b.tag != 2 && !b.mask) {  // masked data: per-datapoint Gram matrices -> direct form
     const i64 total = b.N * (i64)b.C;
@@ -881,11 +899,12 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     const int rows_cap = 512 / b.C + 2;
     const size_t lds = (size_t)rows_cap * c->H * sizeof(double);
     const bool hw_ok = c->HW == 1 || c->HW == 2 || c->HW == 4 || c->HW == 8 || c->HW == 16;
-    if (!b.shared && hw_ok && (c->H % 2) == 0 && lds <= 40 * 1024) {
+    const u64 *dg = b.shared ? nullptr : dig_for(c, b.states);  // with digests the word template is unused
+    if (!b.shared && (hw_ok || dg) && (c->H % 2) == 0 && lds <= 40 * 1024) {
       const unsigned g2 = cdiv(total, 512);
 #define GRAM2(TAG, HWT)                                                                                      \
   bsc_lpj_gram2_kernel<TAG, HWT><<<g2, 512, lds, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, c->H, \
-                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
+                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg)
 #define GRAM2_HW(TAG)                    \
   switch (c->HW) {                       \
     case 1: GRAM2(TAG, 1); break;        \
@@ -935,6 +954,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
 static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   SsscArgs a = {};
   a.states = b.states;
+  a.dig = b.shared ? nullptr : dig_for(c, b.states);
   a.counts = b.counts;
   a.Bm = b.Bm;
   a.yy = b.yy;
@@ -1313,7 +1333,8 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
   vary_kn_kernel<SPL, CPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->cand, c->cand_lpj,        \
                                                                  c->cand_counts, c->N, c->S, c->S_perm, c->HW,   \
                                                                  c->Cmax, Mprime, c->rowmax,                      \
-                                                                 c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS)
+                                                                 c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS, \
+                                                                 c->dig, c->cand_dig)
     const bool c1 = c->Cmax <= 64;
     if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
     else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }
@@ -1354,7 +1375,8 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
   evolve_randflip_kernel<SPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H, \
                                                                     c->HW, n_parents, n_children, c->Cmax, seed,  \
                                                                     fit_parents, c->cand, c->cand_counts, c->list_n,   \
-                                                                    c->model == EVOAMD_MODEL_SSSC ? 4 * LIST_SHARDS : 0)
+                                                                    c->model == EVOAMD_MODEL_SSSC ? 4 * LIST_SHARDS : 0, \
+                                                                    c->cand_dig)
     if (c->S <= 64) EV_LAUNCH(1);
     else if (c->S <= 128) EV_LAUNCH(2);
     else if (c->S <= 256) EV_LAUNCH(4);
@@ -1419,7 +1441,7 @@ static int stats_compute(evoamd_ctx *c) {
 #define BSC_STATS(HWT)                                                                                   \
   bsc_stats_kernel<HWT><<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                 \
       c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->dpar, c->Es,      \
-      c->acc + a.Wq, c->partial2)
+      c->acc + a.Wq, c->partial2, dig_for(c, c->states))
       switch (c->HW) {
         case 1: BSC_STATS(1); break;
         case 2: BSC_STATS(2); break;

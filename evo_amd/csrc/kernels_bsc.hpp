@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err) {
+    int *__restrict__ err, const u64 *__restrict__ dig) {
   extern __shared__ double Bs[];
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
@@ -197,7 +197,12 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
 #pragma unroll
   for (int i = 0; i < BSC_KR; i++) idx[i] = 0;
   const u64 *sp = states + (n * (i64)C + c) * HW;
-  if (live) {
+  if (live && dig) {  // 8 coalesced bytes per state: k and the first DIG_SLOTS = BSC_KR active latents
+    const u64 d = dig[t];
+    k = dig_k(d);
+#pragma unroll
+    for (int j = 0; j < BSC_KR; j++) idx[j] = dig_idx(d, j);
+  } else if (live) {
     u64 w[HWT];
     if (HWT == 1) {
       w[0] = sp[0];
@@ -246,8 +251,10 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
       }
     }
   } else {  // dense state: word loop (same order of additions)
+    k = 0;
     for (int w1 = 0; w1 < HW; w1++) {
       u64 bits = sp[w1];
+      k += __popcll(bits);
       while (bits) {
         const int h = w1 * 64 + pop_msb(bits);
         const double *Gh = G + (i64)h * H;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
     const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H,
     int HW, const double *__restrict__ dpar, double *__restrict__ Es, double *__restrict__ Wq,
-    double *__restrict__ sig_partial) {
+    double *__restrict__ sig_partial, const u64 *__restrict__ dig) {
   extern __shared__ double es_lds[];  // 4 waves x H
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   __shared__ double wsig[4];
@@ -389,32 +396,39 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
       const u64 *sp = states + (n * (i64)S + s) * HW;
       const double qn = q * inv;
       int k = 0;
-      if (HWT > 0) {
+      if (HWT > 0 || dig) {
         constexpr int NW = HWT > 0 ? HWT : 1;
-        u64 w[NW];
-        if (HWT == 1) {
-          w[0] = sp[0];
-        } else {
-          const ulonglong2 *sp2 = (const ulonglong2 *)sp;
-#pragma unroll
-          for (int i = 0; i < NW / 2; i++) {
-            const ulonglong2 v = sp2[i];
-            w[2 * i] = v.x;
-            w[2 * i + 1] = v.y;
-          }
-        }
         int idx[BSC_KR];
 #pragma unroll
         for (int i = 0; i < BSC_KR; i++) idx[i] = 0;
+        if (dig) {
+          const u64 d = dig[n * (i64)S + s];
+          k = dig_k(d);
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-          u64 bits = w[i];
-          while (bits) {
-            const int h = i * 64 + pop_msb(bits);
+          for (int j = 0; j < BSC_KR; j++) idx[j] = dig_idx(d, j);
+        } else {
+          u64 w[NW];
+          if (HWT == 1) {
+            w[0] = sp[0];
+          } else {
+            const ulonglong2 *sp2 = (const ulonglong2 *)sp;
 #pragma unroll
-            for (int j = 0; j < BSC_KR; j++)
-              if (j == k) idx[j] = h;
-            k++;
+            for (int i = 0; i < NW / 2; i++) {
+              const ulonglong2 v = sp2[i];
+              w[2 * i] = v.x;
+              w[2 * i + 1] = v.y;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NW; i++) {
+            u64 bits = w[i];
+            while (bits) {
+              const int h = i * 64 + pop_msb(bits);
+#pragma unroll
+              for (int j = 0; j < BSC_KR; j++)
+                if (j == k) idx[j] = h;
+              k++;
+            }
           }
         }
         if (k <= BSC_KR) {

@@ -20,6 +20,14 @@ __global__ __launch_bounds__(256) void pack_states_kernel(const uint8_t *__restr
   out[idx] = v;
 }
 
+// digest of every packed state (upload paths only; the device producers write it themselves)
+__global__ __launch_bounds__(256) void digest_kernel(const u64 *__restrict__ states, u64 *__restrict__ dig,
+                                                     i64 nstates, int HW) {
+  i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nstates) return;
+  dig[idx] = make_digest(states + idx * HW, HW);
+}
+
 // packed (nstates, HW) -> bool (nstates, H); one thread per latent byte.
 __global__ __launch_bounds__(256) void unpack_states_kernel(const u64 *__restrict__ in,
                                                             uint8_t *__restrict__ out, i64 nstates,
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
                                                       int S_perm, int HW, int Cmax, int Mprime,
                                                       double *__restrict__ rowmax,
                                                       double *__restrict__ rowsum, double *__restrict__ fpartial,
-                                                      int *__restrict__ list_n, int n_list) {
+                                                      int *__restrict__ list_n, int n_list,
+                                                      u64 *__restrict__ dig, const u64 *__restrict__ cand_dig) {
   __shared__ int blk_uniq[4], blk_sub[4];
   if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
     for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
@@ -490,6 +499,7 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
           const int bi = new_i[wave][j], wi = old_i[wave][j];
           for (int w = 0; w < HW; w++) st_n[(i64)wi * HW + w] = cd_n[(i64)bi * HW + w];
           lpj_n[wi] = new_v[wave][j];
+          if (dig) dig[n * (i64)S + wi] = cand_dig[n * (i64)Cmax + bi];
         }
       }
       for (int j = 0; j < g; j++) {  // the register copy of the row follows the swaps

@@ -38,7 +38,7 @@ template <int SPL>
 __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, i64 N, int S, int S_perm, int H, int HW,
     int n_parents, int n_children, int Cmax, u64 seed, int fit_parents, u64 *__restrict__ cand,
-    int *__restrict__ counts, int *__restrict__ list_n, int n_list) {
+    int *__restrict__ counts, int *__restrict__ list_n, int n_list, u64 *__restrict__ cand_dig) {
   __shared__ int sel_sh[4][64];
   if (blockIdx.x == 0 && list_n)  // the candidate lpj chain that follows appends to fresh overflow lists
     for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
@@ -118,11 +118,15 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     }
     const u64 *par = states + (n * (i64)S + sel[p]) * HW;
     u64 *dst = cand + (n * (i64)Cmax + kid) * HW;
+    u64 d = 0;
+    int dk = 0;
     for (int w = 0; w < HW; w++) {
       u64 v = par[w];
       if (w == (mine >> 6)) v ^= (0x8000000000000000ull >> (mine & 63));
       dst[w] = v;
+      while (v) digest_add(d, dk, w * 64 + pop_msb(v));
     }
+    if (cand_dig) cand_dig[n * (i64)Cmax + kid] = digest_close(d, dk);
   }
   if (lane == 0) counts[n] = n_kids;
 }

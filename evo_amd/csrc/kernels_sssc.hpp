@@ -36,6 +36,7 @@ struct PairEntry {
 
 struct SsscArgs {
   const u64 *states;     // (shared ? 1 : N) x C x HW
+  const u64 *dig;        // (N x C) state digests or nullptr (common.hpp)
   const int *counts;     // (N) or nullptr
   const double *Bm;      // (N,H)  b_n = W^T y_n
   const double *yy;      // (N)
@@ -554,7 +555,14 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
       const i64 n = n_first + nloc[p];
       // popcount and the (at most two) active latents right after the loads, so that the state
       // words are dead before the barriers
-      load_state_k2<HWT>(a.states + ((a.shared ? 0 : n * (i64)a.C) + c[p]) * a.HW, a.HW, ktot[p], idx0[p], idx1[p]);
+      if (a.dig) {  // 8 coalesced bytes per state instead of HW words (dig is nullptr for shared sets)
+        const u64 d = a.dig[n * (i64)a.C + c[p]];
+        ktot[p] = dig_k(d);
+        idx0[p] = dig_idx(d, 0);
+        idx1[p] = dig_idx(d, 1);
+      } else {
+        load_state_k2<HWT>(a.states + ((a.shared ? 0 : n * (i64)a.C) + c[p]) * a.HW, a.HW, ktot[p], idx0[p], idx1[p]);
+      }
       yyn[p] = a.yy[n];
     }
     over[p] = live[p] && ktot[p] > 2;
@@ -645,7 +653,14 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, Li
       if ((r + 1) * a.C <= t) r++;
       c = t - r * a.C;
       n = n0 + r;
-      load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k, idx0, idx1);
+      if (a.dig) {
+        const u64 d = a.dig[n * (i64)a.C + c];
+        k = dig_k(d);
+        idx0 = dig_idx(d, 0);
+        idx1 = dig_idx(d, 1);
+      } else {
+        load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k, idx0, idx1);
+      }
       l = a.lpj_in[n * a.ldo + a.col0 + c];
       rmax = a.rowmax[n];
       rsum = a.rowsum[n];

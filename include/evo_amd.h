@@ -66,7 +66,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * (the reference's arithmetic, bsc.py:91-93) instead of the Gram-form kernel.  Takes effect at the
  * next evoamd_set_params_bsc.  "sssc_k8" (1 / 0 / -1, default -1): serve ES3C states with 5..8 active
  * latents with the K=8 register kernel / the LDS wavefront kernel / whichever the counts of the last
- * statistics pass favour. */
+ * statistics pass favour.  "state_digest" (0/1, default 1): the lpj and statistics kernels read the
+ * 8-byte per-state digests (count + first four active latents, maintained by every kernel that
+ * writes states) instead of the ceil(H/64) bit words; 0 selects the word path (A/B, tests). */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */

@@ -186,6 +186,57 @@ def test_device_rng_mode(engine, algo):
     np.testing.assert_allclose(engine.download_lpj(), lpj_after, rtol=1e-12)
 
 
+@pytest.mark.parametrize("algo,H,S", [("ebsc", 70, 24), ("es3c", 70, 24), ("ebsc", 200, 40), ("es3c", 136, 30)])
+def test_state_digest_matches_word_path(engine, algo, H, S):
+    """The lpj / statistics kernels read one 8-byte digest per state (k and the first active
+    latents) that pack, evolve and vary_Kn keep next to the bit words.  Same run with
+    state_digest = 0 (kernels extract from the words).  Fixed Theta: K^n and lpj bit-identical over
+    8 device-RNG steps (init_states starts at k = 1..2, the mutations grow states past the digest's
+    four slots).  Learning: the statistics scatter uses atomics, whose order moves Theta by an ulp
+    and with it exact lpj ties in vary_Kn (also between two runs of the SAME setting), so there the
+    first M-step's Theta and every F are compared to 1e-10 / 1e-9."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(17)
+    D, N = 40, 500
+    W0 = rng.normal(size=(D, H))
+    Y = (rng.random_sample((N, H)) < 3.0 / H).astype(float) @ W0.T + 0.3 * rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+
+    def run(use, learn):
+        engine.set_option("state_digest", use)
+        try:
+            np.random.seed(3)
+            kw = {} if learn else {"to_learn": []}
+            model = cls(D, H, S, rng="device", sync_host=True, engine=engine, seed=23, **kw)
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 6, 3, 1)
+            # every third state dense (k up to ~12 > the digest's four slots): word fall-back, and
+            # children of dense parents exercise it for the candidates as well
+            suff["ss"][:, ::3, :] = np.random.RandomState(5).random_sample((N, len(range(0, S, 3)), H)) < 6.0 / H
+            Fs, theta1 = [], None
+            for it in range(8):
+                F, _, _, theta = model.step(theta, suff, my_data)
+                Fs.append(F)
+                if it == 0:
+                    theta1 = {k: np.array(v) for k, v in theta.items()}
+            return np.array(Fs), suff["ss"].copy(), suff["lpj"].copy(), theta1
+        finally:
+            engine.set_option("state_digest", 1)
+
+    F1, ss1, l1, _ = run(1, False)
+    F0, ss0, l0, _ = run(0, False)
+    np.testing.assert_array_equal(ss1, ss0)
+    np.testing.assert_array_equal(l1, l0)
+    np.testing.assert_array_equal(F1, F0)
+    F1, _, _, t1 = run(1, True)
+    F0, _, _, t0 = run(0, True)
+    np.testing.assert_allclose(F1, F0, rtol=1e-9)
+    for k in t1:
+        np.testing.assert_allclose(t1[k], t0[k], rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense"])
 def test_device_mstep_matches_host(engine, name):
     """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
