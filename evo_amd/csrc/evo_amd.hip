@@ -1334,7 +1334,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
                                                                  c->cand_counts, c->N, c->S, c->S_perm, c->HW,   \
                                                                  c->Cmax, Mprime, c->rowmax,                      \
                                                                  c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS, \
-                                                                 c->dig, c->cand_dig)
+                                                                 c->dig, c->cand_dig, (c->use_digest && c->dig) ? 1 : 0)
     const bool c1 = c->Cmax <= 64;
     if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
     else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }

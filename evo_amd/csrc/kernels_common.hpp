@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
                                                       double *__restrict__ rowmax,
                                                       double *__restrict__ rowsum, double *__restrict__ fpartial,
                                                       int *__restrict__ list_n, int n_list,
-                                                      u64 *__restrict__ dig, const u64 *__restrict__ cand_dig) {
+                                                      u64 *__restrict__ dig, const u64 *__restrict__ cand_dig,
+                                                      int dig_dedup) {
   __shared__ int blk_uniq[4], blk_sub[4];
   if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
     for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
@@ -352,18 +353,22 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
     for (int q = 0; q < SPL; q++) {
       const int s = lane + 64 * q;
       u64 h = 0;
-      if (s < S) h = hash_state(st_n + (i64)s * HW, HW);
+      // with digests the "hash" IS the digest: a complete encoding of the state when k <= DIG_SLOTS
+      // (equal digests <=> equal states), a necessary condition otherwise; 8 bytes per state instead
+      // of HW words, the bulk of this kernel's HBM traffic at large H
+      if (s < S) h = dig_dedup ? dig[n * (i64)S + s] : hash_state(st_n + (i64)s * HW, HW);
       oh[q] = h;
     }
 #pragma unroll
     for (int q = 0; q < CPL; q++) {
       const int c = lane + 64 * q;
       u64 h = 0;
-      if (c < cnt) h = hash_state(cd_n + (i64)c * HW, HW);
+      if (c < cnt) h = dig_dedup ? cand_dig[n * (i64)Cmax + c] : hash_state(cd_n + (i64)c * HW, HW);
       ch[q] = h;
     }
     u64 zero_hash = 0;  // hash of the all-zero state (the permanent state when S_perm = 1)
     for (int w = 0; w < HW; w++) zero_hash = (zero_hash ^ 0ull) * 0x9E3779B97F4A7C15ull + (u64)w;
+    if (dig_dedup) zero_hash = 0;  // digest of the all-zero state
     bool keep[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) keep[q] = false;
@@ -384,7 +389,9 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
       for (int q = 0; q < CPL; q++) maybe = maybe || (lane + 64 * q < c && ch[q] == hc);
       if (S_perm && lane == 0 && hc == zero_hash) maybe = true;
       bool dup = false;
-      if (__any(maybe)) {  // rare: confirm with the exact comparison
+      if (dig_dedup && dig_k(hc) <= DIG_SLOTS) {
+        dup = maybe;  // exact
+      } else if (__any(maybe)) {  // rare: confirm with the exact comparison
         const u64 *cw = cd_n + (i64)c * HW;
         for (int s = lane; s < S && !dup; s += 64) {
           const u64 *sw = st_n + (i64)s * HW;
