@@ -89,14 +89,15 @@ def gemm_flops_per_step(cfg):
     return 2.0 * N * H * D + 2.0 * D * H * H + 2.0 * N * D * H
 
 
-def make_problem(cfg, seed, model):
+def make_problem(cfg, seed, model, dense=False):
     from evo_amd.variational import init_states
     np.random.seed(seed)
     Y = np.random.randn(cfg["N"], cfg["D"])
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
     theta = model.check_params(model.standard_init(my_data))
     suff = init_states(cfg["N"], cfg["S"], cfg["H"], EA["parent_selection"], EA["mutation"], EA["n_parents"],
-                       EA["n_children"], EA["n_generations"])
+                       EA["n_children"], EA["n_generations"],
+                       p_init_Kn=(8.0 / cfg["H"]) if dense else None)  # SURVEY 8d dense-state stress variant
     return my_data, theta, suff
 
 
@@ -164,6 +165,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-mstep", action="store_true", help="Theta update with host NumPy (reference formulas)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--dense-states", action="store_true",
+                    help="SURVEY 8d stress variant: K^n initialised with p_init_Kn = 8/H (mean |s| = 8)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="evoamd_set_option before the run (A/B of a kernel path, e.g. overlap_gemm=0)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,11 +189,14 @@ def main():
     from evo_amd.utils import parallel
 
     eng = Engine()  # LOCAL_RANK selects the GPU
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        eng.set_option(name, int(val))
     comm = parallel.init_rccl_from_env(eng)
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
     model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17,
                 device_mstep=not args.host_mstep)
-    my_data, theta, suff = make_problem(cfg, 1234 + 2 + 1000 * rank, model)
+    my_data, theta, suff = make_problem(cfg, 1234 + 2 + 1000 * rank, model, dense=args.dense_states)
     if world > 1:  # every rank must start from the same Theta (the reference broadcasts rank 0's)
         theta = {k: comm.bcast(v) for k, v in theta.items()}
 
@@ -242,6 +250,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_per_gpu": cfg["N"], "N_total": N_tot,
                        "D": cfg["D"], "H": cfg["H"], "S": cfg["S"], "ea": "fit/randflip 10 parents x 1 child x 1 gen",
+                       "states": "p_init_Kn=8/H (dense stress variant)" if args.dense_states else "p_init_Kn=1/H (init_states default)",
                        "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world, "free_energy_last": F,
                        "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms,
                        "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_steps},

@@ -117,6 +117,12 @@ struct TimedSpan {
 struct evoamd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream: the K = N statistics contraction runs beside the H x H elimination chain of the
+  // Theta update (independent inputs; the chain is launch-latency bound, the GEMM MFMA bound)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool gemm_forked = false;
+  int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
   // which ES3C overflow levels (K=4, K=8, LDS) the next pass over K^n needs; exact, from the
   // counters of the last statistics pass (dpar[DP_NGT*]); unknown -> all
@@ -324,6 +330,9 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   evoamd_ctx *c = new evoamd_ctx();
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -363,6 +372,9 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   for (auto e : c->pool) (void)hipEventDestroy(e);
   free_all(c);
   (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -379,6 +391,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "reconstruct_in_stats") == 0) {  // one-shot: the next statistics pass forms y_reconstructed first
     c->rec_in_stats = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "overlap_gemm") == 0) {
+    c->overlap_gemm = value;
     return 0;
   }
   if (strcmp(name, "state_digest") == 0) {
@@ -1417,8 +1433,40 @@ static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowma
 // the device.  tail[7] receives ljc of the Theta the E-step ran with.
 static int compute_reconstruction(evoamd_ctx *c);
 
-static int stats_compute(evoamd_ctx *c) {
+// the forked statistics contraction must have finished before anything reads its part of acc
+static int join_fork(evoamd_ctx *c) {
+  if (c->gemm_forked) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->gemm_forked = false;
+  }
+  return 0;
+}
+
+// fork_gemm: the caller promises to call join_fork before it reads the contraction's block of acc
+// (evoamd_mstep_device: after the H x H inverses).  Not with a communicator (the all-reduce below
+// needs the whole accumulator) and not while kernels are being timed on the main stream.
+static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  const bool gemm_timed = c->timing && (c->timing_mask & ((1u << KID_GEMM) | (1u << KID_MSTEP) | (1u << KID_MISC)));
+  // measured (tools/ab.sh, MI355X): ES3C H = 512 gains 3-4 % of the iteration (N = 12.5k and 100k); ES3C
+  // H = 128 and EBSC (H = 256, 1024) lose ~1 %: their contraction fills every CU with long split-K
+  // workgroups, the chain's small kernels wait for slots, and the fork/join events cost ~10 us
+  const bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
+  fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) && !c->comm && !gemm_timed &&
+              !c->mask_infr;
+  hipStream_t main_stream = c->stream;
+#define FORK_BEGIN()                                              \
+  if (fork_gemm) {                                                \
+    HIP_TRY(hipEventRecord(c->ev_fork, main_stream));             \
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));       \
+    c->stream = c->stream2;                                       \
+  }
+#define FORK_END()                                                \
+  if (fork_gemm) {                                                \
+    c->stream = main_stream;                                      \
+    HIP_TRY(hipEventRecord(c->ev_join, c->stream2));              \
+    c->gemm_forked = true;                                        \
+  }
   HIP_TRY(hipSetDevice(c->device));
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
@@ -1477,8 +1525,10 @@ static int stats_compute(evoamd_ctx *c) {
       Ywp = c->Yrec;
       ldwp = D;
     }
+    FORK_BEGIN();
     r = launch_gemm_tn(c, c->Es, H, Ywp, ldwp, c->acc + a.Wp, D, H, D, N, false, -1,
                        /*c_is_zero=*/true);  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
+    FORK_END();
     if (r) return r;
   } else {
     double *Es = c->Y + D, *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed]
@@ -1590,9 +1640,11 @@ static int stats_compute(evoamd_ctx *c) {
       r = launch_gemm_tn(c, c->Yrec, D, Ez, c->ldY, c->acc + a.sWp, H, D, H, N, false, -1, /*c_is_zero=*/true);
       if (r) return r;
     } else {
+      FORK_BEGIN();
       r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
                          ((D + H) % GEMM_BM) == 0 ? D + H : -1,  // launch_gemm_tn drops the hint if its tile does not divide it
                          /*c_is_zero=*/true);                    // acc was cleared at the top of stats_compute
+      FORK_END();
       if (r) return r;
     }
   }
@@ -1612,6 +1664,8 @@ static int stats_compute(evoamd_ctx *c) {
   }
   c->stats_rows_valid = true;
   return 0;
+#undef FORK_BEGIN
+#undef FORK_END
 }
 
 // After the accumulator + scalar block reached the host: remember which overflow levels K^n needs.
@@ -1729,7 +1783,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     // mus / pies first (Psi needs the NEW mus, sssc.py:733), then both H x H inverses in one launch:
     // tmpA <- xpt_szsz (for W, sssc.py:693), tmpB <- xpt_ss + eps I (for Psi, sssc.py:738)
     sssc_mstep_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, c->acc + a.xss,
-                                                                    c->acc + a.xszsz, c->acc + a.s_sz, Nptr, H, learn,
+                                                                    c->acc + a.xszsz, Nptr, H, learn,
                                                                     c->pies, c->mus, c->tmpA, c->tmpC, c->tmpB);
     if ((learn & L_W) && (learn & L_PSI))
       r = launch_inverse(c, c->tmpA, c->tmpB, H, force_pivot);
@@ -1738,10 +1792,12 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     else if (learn & L_PSI)
       r = launch_inverse(c, c->tmpB, nullptr, H, force_pivot);
     if (r) return r;
+    r = join_fork(c);  // sWp / s_sz / sz_sz come from the contraction
+    if (r) return r;
     if (learn & L_W)
       launch_gemm_nn_raw(c, c->acc + a.sWp, H, c->tmpA, H, c->W, H, D, H, H);
     if (learn & L_PSI)
-      sssc_psi_finish_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->tmpC, c->tmpB, H, c->Psi);
+      sssc_psi_finish_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->tmpC, c->tmpB, c->acc + a.s_sz, c->mus, H, c->Psi);
     else
       psi_floor_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->Psi, H);
     HIP_TRY(hipGetLastError());
@@ -1764,6 +1820,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     if (learn & L_W) {  // W^T = solve(Wq, Wp)  (bsc.py:237; lstsq == solve for a non-singular Wq)
       HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       r = launch_inverse(c, c->tmpA, nullptr, H, force_pivot);
+      if (r) return r;
+      r = join_fork(c);  // Wp comes from the contraction
       if (r) return r;
       launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H);
       transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
@@ -1872,7 +1930,7 @@ static int mailbox_errors(evoamd_ctx *c) {
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
   REQUIRE(!(c && c->mask_infr), "incomplete data: the Theta update runs on the host (bsc.py:113-118,266-272)");
-  int r = stats_compute(c);
+  int r = stats_compute(c, /*fork_gemm=*/true);
   if (r) return r;
   c->h_theta_fresh = false;
   const bool want_rec = (learn_mask & 32) != 0;
@@ -1886,6 +1944,8 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     if (r) return r;
     c->stats_rows_valid = false;  // the rows belong to the previous Theta now
   }
+  r = join_fork(c);
+  if (r) return r;
   // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
   // the reference's step() hands Theta^new back, so it rides along
   r = mailbox_roundtrip(c, learn_mask != 0);

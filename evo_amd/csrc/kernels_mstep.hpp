@@ -879,11 +879,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict
 
 // Start of the ES3C Theta update in one launch (sssc.py:711-738): pies (clipped, sssc.py:716-720), mus =
 // xpt_sz / (xpt_s + eps) (sssc.py:726), a copy of xpt_szsz for the in-place inverse, and
-//   Psi_raw = mus mus^T * xss + xszsz - 2 mus[:,None] * s_sz,   T2 = xss + eps I   (sssc.py:732-738).
+//   Psi_raw = mus mus^T * xss + xszsz [- 2 mus[:,None] * s_sz],   T2 = xss + eps I   (sssc.py:732-738).
+// The s_sz term is subtracted by sssc_psi_finish_kernel (same order of operations): s_sz comes from the
+// K = N contraction, which runs on the second stream beside the inverses this kernel feeds.
 // Thread (i, j) recomputes the two mus it needs from the accumulator (was three ~5 us launches).
 __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
     const double *__restrict__ xs, const double *__restrict__ xsz, const double *__restrict__ xss,
-    const double *__restrict__ xszsz, const double *__restrict__ s_sz, const double *__restrict__ Nptr, int H, int learn,
+    const double *__restrict__ xszsz, const double *__restrict__ Nptr, int H, int learn,
     double *__restrict__ pies, double *__restrict__ mus, double *__restrict__ xszsz_copy,
     double *__restrict__ psi_raw, double *__restrict__ T2) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -897,7 +899,6 @@ __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
     double v = 0.0;
     v += (mi * mj) * xss[t];
     v += xszsz[t];
-    v -= 2 * mi * s_sz[t];
     psi_raw[t] = v;
     T2[t] = xss[t] + ((i == j) ? 1e-5 : 0.0);
   }
@@ -918,12 +919,16 @@ __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
 
 // Psi = Psi_raw * inv(T2) element-wise (the reference's quirk Q2), then check_params' diagonal floor
 __global__ __launch_bounds__(256) void sssc_psi_finish_kernel(const double *__restrict__ psi_raw,
-                                                              const double *__restrict__ T2inv, int H,
+                                                              const double *__restrict__ T2inv,
+                                                              const double *__restrict__ s_sz,
+                                                              const double *__restrict__ mus, int H,
                                                               double *__restrict__ Psi) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
-  double v = psi_raw[t] * T2inv[t];
+  double v = psi_raw[t];
+  v -= 2 * mus[i] * s_sz[t];  // mus[i] is the NEW mean (sssc.py:733), written by the prepare kernel
+  v *= T2inv[t];
   if (i == j && v < 1e-5) v = 1e-5;
   Psi[t] = v;
 }

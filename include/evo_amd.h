@@ -68,7 +68,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * latents with the K=8 register kernel / the LDS wavefront kernel / whichever the counts of the last
  * statistics pass favour.  "state_digest" (0/1, default 1): the lpj and statistics kernels read the
  * 8-byte per-state digests (count + first four active latents, maintained by every kernel that
- * writes states) instead of the ceil(H/64) bit words; 0 selects the word path (A/B, tests). */
+ * writes states) instead of the ceil(H/64) bit words; 0 selects the word path (A/B, tests).
+ * "overlap_gemm" (0 / 1 / 2, default 1): evoamd_mstep_device runs the K = N statistics contraction on a
+ * second stream beside the H x H elimination chain (single rank, no kernel timing; neither reads what
+ * the other writes): never / for the shapes where it was measured to pay (ES3C, large H) / always. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */

@@ -237,6 +237,38 @@ def test_state_digest_matches_word_path(engine, algo, H, S):
         np.testing.assert_allclose(t1[k], t0[k], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_overlap_gemm_option(engine, algo):
+    """evoamd_mstep_device forks the K = N statistics contraction onto a second stream beside the
+    H x H inverses (default).  The serial schedule (overlap_gemm = 0) must give the same Theta and F:
+    a missing join would show up as a stale or half-written sum_n y <s z>^T block."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(2)
+    D, H, S, N = 48, 96, 20, 4000
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+    out = []
+    for ov in (2, 0):  # 2 = always (1 = only for the shapes where it was measured to pay)
+        engine.set_option("overlap_gemm", ov)
+        try:
+            np.random.seed(3)
+            model = cls(D, H, S, rng="device", sync_host=True, engine=engine, seed=5)
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 6, 2, 1)
+            Fs = []
+            for _ in range(3):
+                F, _, _, theta = model.step(theta, suff, my_data)
+                Fs.append(F)
+            out.append((np.array(Fs), {k: np.array(v) for k, v in theta.items()}))
+        finally:
+            engine.set_option("overlap_gemm", 1)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9)
+    for k in out[0][1]:
+        np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-7, atol=1e-10)
+
+
 @pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense"])
 def test_device_mstep_matches_host(engine, name):
     """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
