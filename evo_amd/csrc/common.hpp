@@ -109,6 +109,14 @@ __device__ __forceinline__ int pop_msb(u64 &bits) {
   return b;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, so
+// every wave first waits for ALL its outstanding global stores and atomics (s_waitcnt vmcnt(0); f64
+// atomics are acknowledged from the memory side, microseconds under load) before it reaches the
+// barrier.  Where the threads of a workgroup talk through LDS only, waiting for the LDS queue is enough.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// same idea within one wave (LDS operations of a wave execute in order)
+__device__ __forceinline__ void lds_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // State digest: one u64 per packed state, kept next to the bit words by every kernel that writes
 // states (pack / evolve / vary_kn).  bits 0..7 = number of active latents (saturated at 255),
 // bits 8+14j .. 8+14j+13 = j-th active latent in ascending order, j < 4.  The lpj and statistics

@@ -187,6 +187,11 @@ struct evoamd_ctx {
   // statistics
   double *acc = nullptr;
   i64 acc_n = 0;
+  // ES3C: second-moment contributions of the overflow kernels (states with > 2 active latents), kept
+  // apart from the k = 2 sums so that sssc_finish_kernel can rebuild the lower triangle (2 H^2 doubles
+  // in front of acc in the same allocation: one memset clears both)
+  double *acc_base = nullptr;
+  i64 ovf_n = 0;
   double *Es = nullptr;  // BSC: (N,H); SSSC: columns D..D+H of c->Y (Ez follows)
   int *list1 = nullptr, *list2 = nullptr, *list3 = nullptr, *list_n = nullptr, *err = nullptr;
   size_t list_words = 0;  // capacity of each overflow list (ints)
@@ -348,7 +353,7 @@ static void free_all(evoamd_ctx *c) {
                   c->cand_counts, c->flags, c->rowmax, c->rowsum, c->partial, c->partial2, c->diag, c->stage,    c->W,
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
-                  c->acc,    c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
+                  c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -507,7 +512,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     c->Es = nullptr;  // lives inside c->Y for SSSC
   }
   c->acc_n = acc_len(c);
-  ALLOC(c->acc, (size_t)c->acc_n + DP_COUNT);  // packed accumulator, then the scalar block (one D2H)
+  c->ovf_n = (model == EVOAMD_MODEL_SSSC) ? 2 * (i64)H * H : 0;
+  ALLOC(c->acc_base, (size_t)c->ovf_n + c->acc_n + DP_COUNT);  // [overflow H x H pair |] packed accumulator, then the scalar block (one D2H)
+  c->acc = c->acc_base + c->ovf_n;
   c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 4);
   if (model == EVOAMD_MODEL_BSC) {
@@ -550,7 +557,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->Y, 0, (size_t)N * c->ldY * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
-  HIP_TRY(hipMemsetAsync(c->acc, 0, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc_base, 0, ((size_t)c->ovf_n + c->acc_n + DP_COUNT) * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
@@ -1471,7 +1478,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
   const int H = c->H, D = c->D;
-  HIP_TRY(hipMemsetAsync(c->acc, 0, (size_t)c->acc_n * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->acc_base, 0, (size_t)(c->ovf_n + c->acc_n) * sizeof(double), c->stream));
   c->yhat_valid = c->stats_rows_valid = false;
   int r = ensure_B(c);
   if (r) return r;
@@ -1545,6 +1552,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     sa.ldE = c->ldY;
     sa.xss = c->acc + a.xss;
     sa.xszsz = c->acc + a.xszsz;
+    sa.xss_o = c->acc_base;
+    sa.xszsz_o = c->acc_base + (size_t)H * H;
     const i64 total = N * (i64)c->S;
     const int cap = (int)list_cap(total);
     // the final K^n is made of resident states and accepted candidates: same levels as the candidates
@@ -1619,7 +1628,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
       sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
                                                                  c->acc + a.xsz, c->colpart, nblk, H, c->y2sum,
-                                                                 c->acc + a.y2, D);
+                                                                 c->acc + a.y2, D, sa.xss_o, sa.xszsz_o,
+                                                                 masked ? nullptr : c->PT);
       HIP_TRY(hipGetLastError());
     }
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)

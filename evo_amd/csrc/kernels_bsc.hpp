@@ -470,13 +470,12 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
       }
       sig += q * ((l - pil_bar * (double)k) / pre1);
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
+    lds_wave_fence();  // not __threadfence_block(): that would wait for this wave's global Wq atomics
     for (int h = lane; h < H; h += 64) Es[n * H + h] = es[h] * inv;
     sig = wave_sum(sig) * inv;
   }
   if (lane == 0) wsig[wave] = (n < N) ? sig : 0.0;
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) sig_partial[blockIdx.x] = ((wsig[0] + wsig[1]) + wsig[2]) + wsig[3];
 }
 

@@ -61,7 +61,8 @@ struct SsscArgs {
   const double *rowmax, *rowsum;
   double *Es, *Ez, *Ed;   // (N, ldE) rows per datapoint: xpt_s, xpt_sz and the DIAGONAL of xpt_szsz
   int ldE;
-  double *xss, *xszsz;    // (H,H) zero-initialised
+  double *xss, *xszsz;    // (H,H) zero-initialised: strict UPPER triangle sums of the states with 2 active latents
+  double *xss_o, *xszsz_o;  // (H,H) zero-initialised: what the overflow kernels (> 2 active latents) add, xszsz_o both triangles
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
   // incomplete data (sssc.py:276 W[this_x_infr, :]): reliable-entry mask rows of this batch, W^T, D
   const uint8_t *mask;    // (N, D) or nullptr
@@ -316,10 +317,10 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
   }
 }
 
-// Scatter of the second moments of one state (sssc.py:576-595).  xpt_ss is symmetric with
-// diagonal xpt_ss[h][h] = xpt_s[h], so only the strict upper triangle is accumulated here and
-// finish_sym_kernel mirrors it and fills the diagonal from xpt_s; xpt_szsz needs every entry
-// (Lam is not symmetric once Psi is not).
+// Scatter of the second moments of one overflow state (sssc.py:576-595) into xss_o / xszsz_o.  xpt_ss
+// is symmetric with diagonal xpt_ss[h][h] = xpt_s[h], so only the strict upper triangle is
+// accumulated and sssc_finish_kernel mirrors it and fills the diagonal from xpt_s; xpt_szsz needs
+// every off-diagonal entry (Lam is not symmetric once Psi is not).
 template <int K>
 __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&idx)[K], int k, double qn,
                                                 const double (&kap)[K], const double (&P)[K][K]) {
@@ -330,8 +331,8 @@ __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&i
       for (int j = 0; j < K; j++) {
         if (j < k) {
           const i64 o = (i64)idx[i] * a.H + idx[j];
-          if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
-          if (j != i) unsafeAtomicAdd(&a.xszsz[o], qn * (P[i][j] + kap[i] * kap[j]));
+          if (j > i) unsafeAtomicAdd(&a.xss_o[o], qn);
+          if (j != i) unsafeAtomicAdd(&a.xszsz_o[o], qn * (P[i][j] + kap[i] * kap[j]));
         }
       }
     }
@@ -460,7 +461,7 @@ template <int BS, int PPT = 1>
 __device__ __forceinline__ void append_begin(const ListOut &lo, int shard, const int (&value)[PPT],
                                              const bool (&over)[PPT], int *buf /* LDS BS * PPT */, int *ctl) {
   if (threadIdx.x == 0) ctl[0] = 0;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
     const u64 mask = __ballot(over[p]);
@@ -473,7 +474,7 @@ __device__ __forceinline__ void append_begin(const ListOut &lo, int shard, const
       if (over[p]) buf[base + __popcll(mask & ((1ull << lane) - 1ull))] = value[p];
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) {
     const int n = ctl[0];
     ctl[1] = n ? atomicAdd(&lo.counts[shard], n) : 0;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void append_begin(const ListOut &lo, int shard, int v
 }
 template <int BS>
 __device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl) {
-  __syncthreads();
+  lds_barrier();
   const int n = ctl[0], start = ctl[1];
   if (n == 0 || start < 0 || start + n > lo.cap) return;  // never write past the shard
   const i64 dst = (i64)shard * lo.cap + start;
@@ -698,15 +699,17 @@ __global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, Li
           unsafeAtomicAdd(&es[idx1], qn);
           unsafeAtomicAdd(&ez[idx1], qn * k1);
           unsafeAtomicAdd(&ed[idx1], qn * (l11 + k1 * k1));
-          const i64 o01 = (i64)idx0 * a.H + idx1, o10 = (i64)idx1 * a.H + idx0;
-          unsafeAtomicAdd(&a.xss[o01], qn);  // strict upper triangle only (finish_sym_kernel mirrors)
+          // Global f64 atomics are what bounds this kernel (~16 G/s, executed memory-side), so a pair
+          // state issues two, not three: the (idx1, idx0) element differs from the (idx0, idx1) one by
+          // qn (l10 - l01), a per-PAIR constant times sum(qn) = xss[o01]; sssc_finish_kernel adds it.
+          const i64 o01 = (i64)idx0 * a.H + idx1;
+          unsafeAtomicAdd(&a.xss[o01], qn);
           unsafeAtomicAdd(&a.xszsz[o01], qn * (l01 + k0 * k1));
-          unsafeAtomicAdd(&a.xszsz[o10], qn * (l10 + k1 * k0));
         }
       }
     }
     append_end<256>(lo, shard, ovf_buf, ovf_ctl);
-    __syncthreads();  // ovf_ctl / ovf_buf are reused by the next chunk
+    lds_barrier();  // ovf_ctl / ovf_buf are reused by the next chunk (LDS only: do not wait for the global atomics)
   }
   for (int i = threadIdx.x; i < nrows * a.H; i += 256) {
     const int r = i / a.H, h = i - r * a.H;
@@ -933,8 +936,8 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       for (int q = lane; q < k * k; q += 64) {
         const int i = q / k, j = q - i * k;
         const i64 o = (i64)idx[i] * a.H + idx[j];
-        if (j > i) unsafeAtomicAdd(&a.xss[o], qn);
-        if (j != i) unsafeAtomicAdd(&a.xszsz[o], qn * (Pm[q] + fv[i] * fv[j]));
+        if (j > i) unsafeAtomicAdd(&a.xss_o[o], qn);
+        if (j != i) unsafeAtomicAdd(&a.xszsz_o[o], qn * (Pm[q] + fv[i] * fv[j]));
       }
     }
   }
@@ -948,7 +951,9 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
                                                           double *__restrict__ xs, double *__restrict__ xsz,
                                                           const double *__restrict__ part, int nblk, int H,
                                                           const double *__restrict__ y2sum, double *__restrict__ y2out,
-                                                          int D) {
+                                                          int D, const double *__restrict__ xss_o,
+                                                          const double *__restrict__ xszsz_o,
+                                                          const PairEntry *__restrict__ PT) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t < D) y2out[t] = y2sum[t];
   if (t >= (i64)H * H) return;
@@ -965,8 +970,21 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
     xsz[i] = z;
     xss[t] = s;
     xszsz[t] = d;
-  } else if (i > j) {
-    xss[t] = xss[(i64)j * H + i];
+  } else if (i < j) {
+    // this thread owns both (i,j) and (j,i).  xss / xszsz hold the upper-triangle sums of the pair
+    // states (sssc_stats_kernel), xss_o / xszsz_o what the overflow kernels added (any k).
+    const i64 tl = (i64)j * H + i;
+    const double uss = xss[t], u = xszsz[t];
+    double lower = u;
+    if (PT && uss != 0.0) {  // Lam of a pair is not symmetric once Psi is not (quirk Q2): l10 - l01 per unit of q
+      const PairEntry pe = PT[t];
+      lower = u + (pe.l10 - pe.l01) * uss;
+    }
+    const double ss = uss + xss_o[t];
+    xss[t] = ss;
+    xss[tl] = ss;
+    xszsz[t] = u + xszsz_o[t];
+    xszsz[tl] = lower + xszsz_o[tl];
   }
 }
 
