@@ -109,6 +109,23 @@ __device__ __forceinline__ int pop_msb(u64 &bits) {
   return b;
 }
 
+// p[0] + p[stride] + ... (count terms) added in exactly that order, with the loads of eight terms
+// issued together: a plain `s += p[b * stride]` loop waits one full memory round trip per term (the
+// finish kernels spent 150 us on 128 partial rows that way).
+__device__ __forceinline__ double ordered_strided_sum(const double *__restrict__ p, i64 stride, i64 count) {
+  double s = 0.0;
+  i64 b = 0;
+  for (; b + 8 <= count; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p[(b + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+  }
+  for (; b < count; b++) s += p[b * stride];
+  return s;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, so
 // every wave first waits for ALL its outstanding global stores and atomics (s_waitcnt vmcnt(0); f64
 // atomics are acknowledged from the memory side, microseconds under load) before it reaches the

@@ -948,7 +948,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     }
 #define GRAM_LAUNCH(TAG)                                                                                       \
   bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
-                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err)
+                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg)
     if (b.tag == 0)
       GRAM_LAUNCH(0);
     else

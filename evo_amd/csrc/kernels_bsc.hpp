@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int shared, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err) {
+    int *__restrict__ err, const u64 *__restrict__ dig) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
   for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
@@ -130,7 +130,30 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const double *Bn = Bm + n * H;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
-    for (int w = 0; w < HW; w++) {
+    bool done = false;
+    if (dig) {  // one 8-byte digest instead of HW dependent word loads (dig is nullptr for shared sets)
+      const u64 d = dig[t];
+      const int kd = dig_k(d);
+      if (kd <= DIG_SLOTS) {
+        int idx[DIG_SLOTS];
+#pragma unroll
+        for (int j = 0; j < DIG_SLOTS; j++) idx[j] = dig_idx(d, j);
+#pragma unroll
+        for (int i = 0; i < DIG_SLOTS; i++) {  // same order of additions as the word loop below
+          if (i < kd) {
+            const double *Gh = G + (i64)idx[i] * H;
+            s1 += Bn[idx[i]];
+            s3 += Gh[idx[i]];
+#pragma unroll
+            for (int j = i + 1; j < DIG_SLOTS; j++)
+              if (j < kd) s2 += Gh[idx[j]];
+          }
+        }
+        k = kd;
+        done = true;
+      }
+    }
+    for (int w = 0; w < HW && !done; w++) {
       u64 bits = sp[w];
       while (bits) {
         const int h = w * 64 + pop_msb(bits);
@@ -488,8 +511,7 @@ __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {  // last workgroup: sigma (tree over 256 threads, fixed order)
     __shared__ double sh[256];
-    double s = 0.0;
-    for (i64 i = threadIdx.x; i < nsig; i += 256) s += sig_part[i];
+    const double s = (i64)threadIdx.x < nsig ? ordered_strided_sum(sig_part + threadIdx.x, 256, (nsig - threadIdx.x + 255) / 256) : 0.0;
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -501,8 +523,7 @@ __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
   if (i == j) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; b++) s += part[(i64)b * H + i];
+    const double s = ordered_strided_sum(part + i, H, nblk);
     pies[i] = s;
     Wq[t] = s;
   } else if (i > j) {

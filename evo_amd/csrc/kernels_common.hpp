@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256) void reduce3_partials_kernel(const double *__r
                                                                double *__restrict__ dpar) {
   __shared__ double sh[3][256];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (i64 i = threadIdx.x; i < n; i += 256) {
-    s0 += partial[i];
-    s1 += partial[n + i];
-    s2 += partial[2 * n + i];
+  if ((i64)threadIdx.x < n) {
+    const i64 cnt = (n - threadIdx.x + 255) / 256;
+    s0 = ordered_strided_sum(partial + threadIdx.x, 256, cnt);
+    s1 = ordered_strided_sum(partial + n + threadIdx.x, 256, cnt);
+    s2 = ordered_strided_sum(partial + 2 * n + threadIdx.x, 256, cnt);
   }
   sh[0][threadIdx.x] = s0;
   sh[1][threadIdx.x] = s1;

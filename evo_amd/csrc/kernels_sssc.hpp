@@ -239,11 +239,17 @@ __device__ __forceinline__ int list_fetch(const ListIn &li, const int *prefix, i
 template <int K, int MODE>
 __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u64 *sp, int (&idx)[K], int &k,
                                                double &val, double (&kap)[K], double (&P)[K][K], bool &singular,
-                                               const double *Bn, const double4 *DGt) {
+                                               const double *Bn, const double4 *DGt, u64 dg = 0,
+                                               bool have_dg = false) {
 #pragma unroll
   for (int i = 0; i < K; i++) idx[i] = 0;
   k = 0;
-  for (int w = 0; w < a.HW; w++) {
+  if (have_dg) {  // the digest is a complete encoding (k <= DIG_SLOTS): no second pass over the words
+    k = dig_k(dg);
+#pragma unroll
+    for (int i = 0; i < (K < DIG_SLOTS ? K : DIG_SLOTS); i++) idx[i] = dig_idx(dg, i);
+  }
+  for (int w = 0; w < a.HW && !have_dg; w++) {
     u64 bits = sp[w];
     while (bits) {
       const int h = w * 64 + pop_msb(bits);
@@ -366,9 +372,17 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
       c = (int)(eu - (unsigned)n * (unsigned)a.C);
       live = !(a.counts && c >= a.counts[n]);
     }
+    u64 dg = 0;
+    bool have_dg = false;
     if (live) {
       sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
-      for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+      if (a.dig) {  // nullptr for shared sets and transient batches
+        dg = a.dig[n * (i64)a.C + c];
+        ktot = dig_k(dg);  // saturates at 255 > K
+        have_dg = ktot <= DIG_SLOTS;
+      } else {
+        for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+      }
     }
     const bool over = live && ktot > K;
     block_append<BS>(lo, (int)(round & (LIST_SHARDS - 1)), (int)e, over, ovf_buf, ovf_ctl);
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
     int idx[K], k;
     double val = 0.0, kap[K], P[K][K];
     bool singular = false;
-    sssc_eval_regs<K, MODE>(a, n, sp, idx, k, val, kap, P, singular, a.Bm + n * a.H, a.DG);
+    sssc_eval_regs<K, MODE>(a, n, sp, idx, k, val, kap, P, singular, a.Bm + n * a.H, a.DG, dg, have_dg);
     if (singular) atomicOr(a.err, 2);
     if (MODE == 0) {
       unsigned fl = 0;
@@ -958,19 +972,18 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
   if (t < D) y2out[t] = y2sum[t];
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
+  // the three column sums of latent i are taken by three different threads of row i (the diagonal one
+  // and its two right-hand neighbours, cyclically): each is a chain of nblk dependent additions
+  const bool wide = H >= 3;
   if (i == j) {
-    double s = 0.0, z = 0.0, d = 0.0;
-    for (int b = 0; b < nblk; b++) {
-      const double *p = part + (i64)b * 3 * H;
-      s += p[i];
-      z += p[H + i];
-      d += p[2 * H + i];
-    }
+    const double s = ordered_strided_sum(part + i, 3 * (i64)H, nblk);
     xs[i] = s;
-    xsz[i] = z;
     xss[t] = s;
-    xszsz[t] = d;
-  } else if (i < j) {
+  }
+  if (wide ? (j == (i + 1 == H ? 0 : i + 1)) : (i == j)) xsz[i] = ordered_strided_sum(part + H + i, 3 * (i64)H, nblk);
+  if (wide ? (j == (i + 2 >= H ? i + 2 - H : i + 2)) : (i == j))
+    xszsz[(i64)i * H + i] = ordered_strided_sum(part + 2 * H + i, 3 * (i64)H, nblk);
+  if (i < j) {
     // this thread owns both (i,j) and (j,i).  xss / xszsz hold the upper-triangle sums of the pair
     // states (sssc_stats_kernel), xss_o / xszsz_o what the overflow kernels added (any k).
     const i64 tl = (i64)j * H + i;
