@@ -220,7 +220,7 @@ def _moment_matrix(rng, n, cond_boost=0.05):
     return X @ X.T / (3 * n) + cond_boost * np.eye(n)
 
 
-@pytest.mark.parametrize("n", [7, 16, 40, 100, 128, 130, 200, 500])
+@pytest.mark.parametrize("n", [7, 16, 40, 64, 65, 100, 128, 130, 192, 200, 500])
 def test_inverse_spd_block_path(engine, n):
     """The M-step's H x H solver on Gram-type (SPD) matrices -- the shape np.linalg.inv is given
     at sssc.py:693,738 and lstsq at bsc.py:237 -- against numpy, two matrices per call."""
