@@ -141,6 +141,12 @@ struct evoamd_ctx {
   size_t yhat_n = 0;
   bool yhat_valid = false;
   bool stats_rows_valid = false;  // Es / Ez rows describe the current K^n and Theta
+  // software pipelining across the API boundary: evoamd_mstep_device enqueues the NEXT iteration's pass
+  // over the resident K^n behind the mailbox kernel, so the GPU works through the ~40 us the host needs
+  // between two iterations; evoamd_lpj_resident then finds it done.  `gen` is bumped by everything that
+  // changes what that pass computes (Theta, K^n, data, options).
+  unsigned long long gen = 0, prefetch_gen = ~0ull;
+  bool prefetch_lpj = true;  // option "prefetch_lpj"
   bool use_digest = true;   // lpj / statistics kernels read the state digests (option "state_digest")
   bool spd_inverse = true;  // M-step H x H systems: SPD block Gauss-Jordan first, pivoted path on a bad pivot
   long spd_fallbacks = 0;   // how often the pivoted repeat was needed
@@ -163,6 +169,8 @@ struct evoamd_ctx {
   u64 *states = nullptr, *cand = nullptr;
   u64 *dig = nullptr, *cand_dig = nullptr;  // state digests (common.hpp), nullptr when H > DIG_MAX_H
   double *lpj = nullptr, *cand_lpj = nullptr;
+  double *lpj_alt = nullptr;  // target of the prefetched pass; swapped with lpj when it is consumed (the rows of the
+                              // E-step that just ended stay readable until then: sync_to_host, download_lpj)
   int *cand_counts = nullptr;
   unsigned *flags = nullptr;  // 3 x N: resident | candidates | permanent
   double *rowmax = nullptr, *rowsum = nullptr, *partial = nullptr, *partial2 = nullptr, *diag = nullptr;
@@ -354,7 +362,7 @@ static void free_all(evoamd_ctx *c) {
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
-                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig};
+                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -385,6 +393,7 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
 
 extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   REQUIRE(c && name, "bad arguments");
+  c->gen++;  // an option can change which kernel form evaluates K^n: drop a prefetched pass
   if (strcmp(name, "sssc_k8") == 0) {
     c->k8_mode = value < 0 ? -1 : (value != 0);
     return 0;
@@ -396,6 +405,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "reconstruct_in_stats") == 0) {  // one-shot: the next statistics pass forms y_reconstructed first
     c->rec_in_stats = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "prefetch_lpj") == 0) {
+    c->prefetch_lpj = value != 0;
     return 0;
   }
   if (strcmp(name, "overlap_gemm") == 0) {
@@ -413,8 +426,12 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   return fail(EVOAMD_E_INVALID, "unknown option '%s'", name);
 }
 
+static int join_fork(evoamd_ctx *c);
+
 extern "C" int evoamd_synchronize(evoamd_ctx *c) {
   REQUIRE(c, "ctx is NULL");
+  int rj = join_fork(c);
+  if (rj) return rj;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -484,8 +501,13 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (H <= DIG_MAX_H) {
     ALLOC(c->dig, (size_t)N * S);
     ALLOC(c->cand_dig, (size_t)N * Cmax);
+  } else {  // latent indices do not fit the digest's 14-bit slots: every kernel takes its word path
+    if (c->dig) (void)hipFree(c->dig);
+    if (c->cand_dig) (void)hipFree(c->cand_dig);
+    c->dig = c->cand_dig = nullptr;
   }
   ALLOC(c->lpj, (size_t)N * c->L);
+  ALLOC(c->lpj_alt, (size_t)N * c->L);
   ALLOC(c->cand_lpj, (size_t)N * Cmax);
   ALLOC(c->cand_counts, (size_t)N);
   ALLOC(c->flags, (size_t)3 * N);
@@ -561,6 +583,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
+  c->gen++;
   c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
   if (c->tmpWt) (void)hipFree(c->tmpWt);  // sized by (H, D): rebuilt on demand
   c->tmpWt = nullptr;
@@ -583,6 +606,7 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_data = true;
+  c->gen++;
   c->B_valid = false;
   return 0;
 }
@@ -634,6 +658,7 @@ static int pack_to_device(evoamd_ctx *c, const uint8_t *host_bool, i64 nstates, 
   if (bytes > c->stage_bytes) return fail(EVOAMD_E_INVALID, "state batch larger than staging buffer");
   HIP_TRY(hipMemcpyAsync(c->stage, host_bool, bytes, hipMemcpyHostToDevice, c->stream));
   pack_states_kernel<<<cdiv(nstates * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, nstates, c->H, c->HW);
+  if (dst == c->states) c->gen++;
   u64 *dg = dst == c->states ? c->dig : dst == c->cand ? c->cand_dig : nullptr;
   if (dg) digest_kernel<<<cdiv(nstates, 256), 256, 0, c->stream>>>(dst, dg, nstates, c->HW);
   HIP_TRY(hipGetLastError());
@@ -809,6 +834,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
     }
   }
   c->have_params = true;
+  c->gen++;
   c->h_theta_fresh = false;
   c->yhat_valid = c->stats_rows_valid = false;
   return 0;
@@ -874,6 +900,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
     c->B_valid = true;
   }
   c->have_params = true;
+  c->gen++;
   c->h_theta_fresh = false;
   c->yhat_valid = c->stats_rows_valid = false;
   return 0;
@@ -1159,9 +1186,20 @@ static int check_err(evoamd_ctx *c) {
   return 0;
 }
 
+static int lpj_resident_launch(evoamd_ctx *c, double *out);
+
 extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
   HIP_TRY(hipSetDevice(c->device));
+  if (c->prefetch_gen == c->gen) {  // evoamd_mstep_device already enqueued exactly this pass
+    c->prefetch_gen = ~0ull;
+    std::swap(c->lpj, c->lpj_alt);
+    return 0;
+  }
+  return lpj_resident_launch(c, c->lpj);
+}
+
+static int lpj_resident_launch(evoamd_ctx *c, double *out) {
   {
     int rb = ensure_B(c);
     if (rb) return rb;
@@ -1169,10 +1207,10 @@ extern "C" int evoamd_lpj_resident(evoamd_ctx *c) {
   c->rows_fresh = false;
   if (c->S_perm) {
     allzero_lpj_kernel<<<cdiv(c->N, 256), 256, 0, c->stream>>>(c->yy, c->N, c->dpar, c->model == EVOAMD_MODEL_SSSC,
-                                                               c->lpj, c->L, c->flags + 2 * c->N, c->err);
+                                                               out, c->L, c->flags + 2 * c->N, c->err);
     HIP_TRY(hipGetLastError());
   }
-  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
+  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, out, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
   b.mask = c->mask_infr;
   return launch_lpj(c, b);  // stream-ordered; device-side errors surface at the next host-returning call
 }
@@ -1350,6 +1388,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
   REQUIRE(c && c->configured && c->have_cand, "no resident candidate batch (call lpj_candidates / evolve first)");
   REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
   HIP_TRY(hipSetDevice(c->device));
+  c->gen++;
   {
     SpanGuard g(c, KID_VARY_KN);
 #define VK_LAUNCH(SPL, CPL)                                                                                   \
@@ -1461,6 +1500,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
   fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) && !c->comm && !gemm_timed &&
               !c->mask_infr;
+  {
+    int rj = join_fork(c);  // a previous call that failed between fork and join must not race with the memset below
+    if (rj) return rj;
+  }
   hipStream_t main_stream = c->stream;
 #define FORK_BEGIN()                                              \
   if (fork_gemm) {                                                \
@@ -1788,6 +1831,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
   const i64 HH = (i64)H * H;
   const double *Nptr = c->acc + a.tail + 3;
   int r = 0;
+  c->gen++;
   SpanGuard g(c, KID_MSTEP);
   if (c->model == EVOAMD_MODEL_SSSC) {
     // mus / pies first (Psi needs the NEW mus, sssc.py:733), then both H x H inverses in one launch:
@@ -1889,7 +1933,7 @@ extern "C" int evoamd_reconstruct(evoamd_ctx *c, double *y_hat) {
 
 // Everything an EM iteration returns to the host goes through the mailbox kernel; the host polls
 // the sequence number (falls back to a blocking synchronise after 20 ms of spinning).
-static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta) {
+static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = false) {
   const AccLayout a = acc_layout(c);
   const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
   MailboxSegs segs = {};
@@ -1911,6 +1955,11 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta) {
   mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, c->stream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
                                                               c->mbox_counter, seq);
   HIP_TRY(hipGetLastError());
+  if (prefetch && c->prefetch_lpj && !c->mask_infr) {
+    // behind the mailbox kernel in stream order: the host is released as soon as that kernel is done
+    c->prefetch_gen = ~0ull;
+    if (lpj_resident_launch(c, c->lpj_alt) == 0) c->prefetch_gen = c->gen;
+  }
   volatile unsigned long long *flag = (volatile unsigned long long *)c->h_theta;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
@@ -1958,7 +2007,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   if (r) return r;
   // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
   // the reference's step() hands Theta^new back, so it rides along
-  r = mailbox_roundtrip(c, learn_mask != 0);
+  r = mailbox_roundtrip(c, learn_mask != 0, /*prefetch=*/true);
   if (r) return r;
   const double *h = c->h_theta + 8;
   if (learn_mask && h[8 + DP_STATUS] == 3.0) {
@@ -1970,7 +2019,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     r = update_params_device(c, learn_mask, /*force_pivot=*/true);
     if (r) return r;
-    r = mailbox_roundtrip(c, true);
+    r = mailbox_roundtrip(c, true, /*prefetch=*/true);
     if (r) return r;
   }
   memcpy(tail_out, h, 8 * sizeof(double));

@@ -71,7 +71,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * writes states) instead of the ceil(H/64) bit words; 0 selects the word path (A/B, tests).
  * "overlap_gemm" (0 / 1 / 2, default 1): evoamd_mstep_device runs the K = N statistics contraction on a
  * second stream beside the H x H elimination chain (single rank, no kernel timing; neither reads what
- * the other writes): never / for the shapes where it was measured to pay (ES3C, large H) / always. */
+ * the other writes): never / for the shapes where it was measured to pay (ES3C, large H) / always.
+ * "prefetch_lpj" (0/1, default 1): evoamd_mstep_device enqueues the next iteration's evoamd_lpj_resident
+ * pass behind its mailbox kernel (the GPU works while the host turns the iteration around); the next
+ * evoamd_lpj_resident call returns at once unless Theta, K^n, the data or an option changed in between. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */

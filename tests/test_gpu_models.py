@@ -238,6 +238,45 @@ def test_state_digest_matches_word_path(engine, algo, H, S):
 
 
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_prefetched_lpj_pass(engine, algo):
+    """evoamd_mstep_device enqueues the next iteration's pass over the resident K^n behind its mailbox
+    kernel (into a second lpj buffer).  Same trajectory with prefetch_lpj = 0; the lpj rows a user reads
+    after step() are still those of the E-step that just ended (the reference's semantics), and a host
+    write to K^n or Theta between two steps drops the prefetched pass."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(4)
+    D, H, S, N = 24, 40, 16, 300
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+    out = []
+    for pf in (1, 0):
+        engine.set_option("prefetch_lpj", pf)
+        try:
+            np.random.seed(3)
+            model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=9)  # K^n stays resident
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 5, 2, 1)
+            rec = []
+            for it in range(5):
+                if it == 3:  # host edits K^n between two steps: datapoint 0 gets fresh random states
+                    suff["ss"][0] = np.random.RandomState(99).random_sample((S, H)) < 0.1
+                    suff["ss"][0, np.arange(S), np.arange(S)] = True  # distinct rows
+                    engine.upload_states(suff["ss"])
+                F, _, _, theta = model.step(theta, suff, my_data)
+                model.sync_to_host(suff)  # downloads only: the prefetched pass stays valid
+                rec.append((F, suff["lpj"].copy(), suff["ss"].copy()))
+            out.append(rec)
+        finally:
+            engine.set_option("prefetch_lpj", 1)
+    for (F1, l1, s1), (F0, l0, s0) in zip(*out):
+        np.testing.assert_array_equal(s1, s0)
+        np.testing.assert_allclose(F1, F0, rtol=1e-10)
+        np.testing.assert_allclose(l1, l0, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 def test_overlap_gemm_option(engine, algo):
     """evoamd_mstep_device forks the K = N statistics contraction onto a second stream beside the
     H x H inverses (default).  The serial schedule (overlap_gemm = 0) must give the same Theta and F:
