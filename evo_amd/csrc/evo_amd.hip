@@ -1825,7 +1825,31 @@ static int launch_inverse(evoamd_ctx *c, double *A, double *B, int n, bool force
 
 // Theta^new from the device accumulator (which evoamd_stats / stats_compute left behind), clamps,
 // precompute and the dense G / B refresh; all stream-ordered, no host arithmetic.
-static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = false) {
+// Second half of the device Theta update: what only the NEXT E-step reads (ES3C state-term tables, G for
+// EBSC, B = Y W).  evoamd_mstep_device enqueues it behind the mailbox kernel, so the host gets F and
+// Theta^new one GEMM earlier and is ahead of the stream again by the time these finish.
+static int refresh_after_update(evoamd_ctx *c) {
+  const int H = c->H, D = c->D;
+  int r = 0;
+  SpanGuard g(c, KID_MSTEP);
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
+                                                                     c->PT, c->GP, c->DG);
+    HIP_TRY(hipGetLastError());
+    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    if (r) return r;
+    c->B_valid = true;
+  } else if (!c->bsc_direct) {
+    r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
+    if (r) return r;
+    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    if (r) return r;
+    c->B_valid = true;
+  }
+  return 0;
+}
+
+static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = false, bool defer_refresh = false) {
   const AccLayout a = acc_layout(c);
   const int H = c->H, D = c->D;
   const i64 HH = (i64)H * H;
@@ -1864,12 +1888,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, n_part, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar);
-    sssc_tables_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1, c->PT,
-                                                             c->GP, c->DG);
     HIP_TRY(hipGetLastError());
-    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
-    if (r) return r;
-    c->B_valid = true;
+    c->B_valid = false;
   } else {
     if (learn & L_W) {  // W^T = solve(Wq, Wp)  (bsc.py:237; lstsq == solve for a non-singular Wq)
       HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1883,15 +1903,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
-    if (!c->bsc_direct) {
-      r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
-      if (r) return r;
-      r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
-      if (r) return r;
-      c->B_valid = true;
-    }
   }
-  return 0;
+  return defer_refresh ? 0 : refresh_after_update(c);
 }
 
 // y_hat = E W^T with E = Es (EBSC) / Ez (ES3C) rows of the last statistics pass (see evoamd_reconstruct)
@@ -1933,7 +1946,7 @@ extern "C" int evoamd_reconstruct(evoamd_ctx *c, double *y_hat) {
 
 // Everything an EM iteration returns to the host goes through the mailbox kernel; the host polls
 // the sequence number (falls back to a blocking synchronise after 20 ms of spinning).
-static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = false) {
+static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = false, bool refresh = false) {
   const AccLayout a = acc_layout(c);
   const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
   MailboxSegs segs = {};
@@ -1955,6 +1968,10 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, c->stream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
                                                               c->mbox_counter, seq);
   HIP_TRY(hipGetLastError());
+  if (refresh) {
+    int rr = refresh_after_update(c);
+    if (rr) return rr;
+  }
   if (prefetch && c->prefetch_lpj && !c->mask_infr) {
     // behind the mailbox kernel in stream order: the host is released as soon as that kernel is done
     c->prefetch_gen = ~0ull;
@@ -1999,7 +2016,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     if (r) return r;
   }
   if (learn_mask) {
-    r = update_params_device(c, learn_mask);
+    r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true);
     if (r) return r;
     c->stats_rows_valid = false;  // the rows belong to the previous Theta now
   }
@@ -2007,7 +2024,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   if (r) return r;
   // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
   // the reference's step() hands Theta^new back, so it rides along
-  r = mailbox_roundtrip(c, learn_mask != 0, /*prefetch=*/true);
+  r = mailbox_roundtrip(c, learn_mask != 0, /*prefetch=*/true, /*refresh=*/learn_mask != 0);
   if (r) return r;
   const double *h = c->h_theta + 8;
   if (learn_mask && h[8 + DP_STATUS] == 3.0) {
@@ -2017,9 +2034,9 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     c->spd_fallbacks++;
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
     HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    r = update_params_device(c, learn_mask, /*force_pivot=*/true);
+    r = update_params_device(c, learn_mask, /*force_pivot=*/true, /*defer_refresh=*/true);
     if (r) return r;
-    r = mailbox_roundtrip(c, true, /*prefetch=*/true);
+    r = mailbox_roundtrip(c, true, /*prefetch=*/true, /*refresh=*/true);
     if (r) return r;
   }
   memcpy(tail_out, h, 8 * sizeof(double));
