@@ -753,6 +753,10 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
       i64 per_xcd = 1;
       double best = 0.0;
       for (i64 pc = 1; pc <= 16; pc++) {
+        // at least 512 rows of K per chunk: below that the ramp of the software pipeline and the atomic
+        // epilogue of every extra chunk cost more than a fuller last round gains (K = 12500, 34 tiles:
+        // 15 chunks per XCD 0.455 ms, 3 chunks 0.374 ms; tools/gemm_sweep.sh)
+        if (pc > 1 && K / (8 * pc) < 512) break;
         const double eff = (double)(real * pc) / (64.0 * (double)cdiv(real * pc, 64));
         if (eff > best + 0.01) {
           best = eff;
