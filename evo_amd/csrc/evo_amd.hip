@@ -728,6 +728,14 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
                           bool c_is_zero = false) {
   // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of the
   // tile size): only its upper tiles are computed, the rest is mirrored
+  if (deterministic && A == B && lda == ldb && M == Nc && M <= 512 && K <= 4096 && sym_row0 < 0) {
+    // G = W^T W of the Theta update: one wave per 16 x 16 block (gram_small_kernel)
+    SpanGuard g(c, KID_GEMM);
+    const int nb16 = (int)cdiv(M, 16);
+    gram_small_kernel<<<dim3(nb16, nb16), 64, 0, c->stream>>>(A, lda, (int)K, M, C, ldc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const bool vec = gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb) && (M % 2) == 0 && (Nc % 2) == 0 && M >= 2 && Nc >= 2;
   // long-K, wide outputs: 128 x 128 tiles (half the L2 traffic per flop)
   const bool big = vec && !deterministic && K >= 8192 && M >= 256 && Nc >= 256 &&

@@ -390,6 +390,47 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
       }
 }
 
+// G = W^T W for the small, launch-latency-bound case (H <= 512): one wavefront per 16 x 16 block of G,
+// the whole K = D reduction in that wave in a fixed order (deterministic: every rank gets the same G from
+// the same W), operands straight from global memory (W is L2 resident, D x H x 8 <= 1 MB).
+// The tiled kernel gives this problem 4..64 workgroups and one software-pipeline ramp: 20 us at c2.
+// Upper blocks only (block row <= block column); lower blocks are written transposed by the same wave.
+__global__ __launch_bounds__(64) void gram_small_kernel(const double *__restrict__ W, int ldw, int D, int H,
+                                                        double *__restrict__ G, int ldg) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi > bj) return;
+  const int lane = threadIdx.x;
+  const int i = bi * 16 + (lane & 15), j = bj * 16 + (lane & 15), kq = lane >> 4;
+  const bool iv = i < H, jv = j < H;
+  v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+  int d0 = 0;
+  for (; d0 + 16 <= D; d0 += 16) {  // four k-steps per trip: eight loads in flight
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const size_t row = (size_t)(d0 + 4 * u + kq) * ldw;
+      a[u] = iv ? W[row + i] : 0.0;
+      b[u] = jv ? W[row + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; d0 < D; d0 += 4) {
+    const int d = d0 + kq;
+    const double a = (iv && d < D) ? W[(size_t)d * ldw + i] : 0.0;
+    const double b = (jv && d < D) ? W[(size_t)d * ldw + j] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = bi * 16 + (lane >> 4) + 4 * r, gj = bj * 16 + (lane & 15);
+    if (gi < H && gj < H) {
+      G[(size_t)gi * ldg + gj] = acc[r];
+      if (bi != bj) G[(size_t)gj * ldg + gi] = acc[r];
+    }
+  }
+}
+
 // S (n x n, ld) <- upper triangle mirrored into the lower one (the SYRK-style launch above computed
 // only tiles with row tile <= column tile; inside diagonal tiles both halves exist already).
 __global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ S, int n, int ld, int tile) {
