@@ -713,6 +713,10 @@ static bool gemm_vec_ok(const double *p, int ld) { return (ld % 2) == 0 && ((uin
 
 static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                                i64 M, int Nc, int K) {
+  if (M <= 1024 && Nc <= 1024 && K <= 1024) {  // parameter-sized: one wave per 16 x 16 block
+    gemm_nn_small_kernel<<<dim3(cdiv(Nc, 16), cdiv(M, 16)), 64, 0, c->stream>>>(A, lda, B, ldb, C, ldc, (int)M, Nc, K);
+    return;
+  }
   const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
   const int rows_per_xcd = (gy + 7) / 8;
   const unsigned grid = (unsigned)(8 * rows_per_xcd * gx);

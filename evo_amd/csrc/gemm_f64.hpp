@@ -431,6 +431,43 @@ __global__ __launch_bounds__(64) void gram_small_kernel(const double *__restrict
   }
 }
 
+// C = A B for parameter-sized products (W = Wp inv(..), M, Nc, K <= 1024): one wavefront per 16 x 16
+// block of C, the K reduction in that wave in a fixed order, operands from global memory (both factors
+// are L2 resident).  The tiled kernel gives these shapes 8..64 workgroups of one K pipeline each:
+// 12 us at c2, 80 us at c5 for 0.5 GFLOP.
+__global__ __launch_bounds__(64) void gemm_nn_small_kernel(const double *__restrict__ A, int lda,
+                                                           const double *__restrict__ B, int ldb,
+                                                           double *__restrict__ C, int ldc, int M, int Nc, int K) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.y * 16 + (lane & 15), j = blockIdx.x * 16 + (lane & 15), kq = lane >> 4;
+  const bool iv = i < M, jv = j < Nc;
+  const double *__restrict__ Ai = A + (size_t)(iv ? i : 0) * lda;
+  v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+  int k0 = 0;
+  for (; k0 + 16 <= K; k0 += 16) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 4 * u + kq;
+      a[u] = iv ? Ai[k] : 0.0;
+      b[u] = jv ? B[(size_t)k * ldb + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k0 < K; k0 += 4) {
+    const int k = k0 + kq;
+    const double a = (iv && k < K) ? Ai[k] : 0.0;
+    const double b = (jv && k < K) ? B[(size_t)k * ldb + j] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = blockIdx.y * 16 + (lane >> 4) + 4 * r, gj = blockIdx.x * 16 + (lane & 15);
+    if (gi < M && gj < Nc) C[(size_t)gi * ldc + gj] = acc[r];
+  }
+}
+
 // S (n x n, ld) <- upper triangle mirrored into the lower one (the SYRK-style launch above computed
 // only tiles with row tile <= column tile; inside diagonal tiles both halves exist already).
 __global__ __launch_bounds__(256) void mirror_lower_kernel(double *__restrict__ S, int n, int ld, int tile) {
