@@ -454,16 +454,19 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
 #pragma unroll
         for (int q = 0; q < SPL; q++) ow[q] = (lane + 64 * q < S) ? ov[q] : INFINITY;
         for (int j = 0; j < M; j++) {
-          double lm = INFINITY;
-          unsigned li = 0xFFFFFFFFu;
+          // this kernel is VALU-issue bound (profiles/r01_c3_vary_kn_pmc.txt): the wave minimum by DPP,
+          // then its lowest index by ballots (state index = lane + 64 q, so the first q with a hit and
+          // the lowest lane in it) instead of a second DPP reduction over tracked indices
+          double lm = ow[0];
 #pragma unroll
-          for (int q = 0; q < SPL; q++)
-            if (ow[q] < lm) {
-              lm = ow[q];
-              li = (unsigned)(lane + 64 * q);
-            }
+          for (int q = 1; q < SPL; q++) lm = fmin(lm, ow[q]);
           const double gm = wave_min(lm);
-          const unsigned gi = wave_min_u32((lm == gm) ? li : 0xFFFFFFFFu);
+          unsigned gi = 0xFFFFFFFFu;
+#pragma unroll
+          for (int q = 0; q < SPL; q++) {
+            const u64 hit = __ballot(ow[q] == gm);
+            if (gi == 0xFFFFFFFFu && hit != 0ull) gi = (unsigned)(64 * q + __ffsll((long long)hit) - 1);
+          }
           if (lane == 0) {
             old_v[wave][j] = gm;
             old_i[wave][j] = (int)gi;

@@ -74,18 +74,19 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     }
   }
   for (int j = 0; j < n_parents; j++) {
-    double bv = INFINITY;
+    double bv = key[0];
+#pragma unroll
+    for (int q = 1; q < SPL; q++) bv = fmin(bv, key[q]);
+    // lexicographic (key, index) minimum over the wave: DPP min of the key, then the lowest index that
+    // holds it by ballots (index = lane + 64 q: first q with a hit, lowest lane in it).  The kernel is
+    // VALU-issue bound; a second DPP reduction over tracked indices cost as much as the first.
+    const double gv = wave_min(bv);
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < SPL; q++)
-      if (key[q] < bv) {
-        bv = key[q];
-        bi = lane + 64 * q;
-      }
-    // lexicographic (key, index) minimum over the wave: DPP min of the key, then of the index among
-    // the lanes that hold it (a __shfl_xor butterfly on the pair is 18 LDS-latency permutes per round)
-    const double gv = wave_min(bv);
-    bi = (int)wave_min_u32((bv == gv) ? (unsigned)bi : 0xFFFFFFFFu);
+    for (int q = 0; q < SPL; q++) {
+      const u64 hit = __ballot(key[q] == gv);
+      if (bi == 0x7fffffff && hit != 0ull) bi = 64 * q + __ffsll((long long)hit) - 1;
+    }
     if (lane == 0) sel[j] = bi;
     if ((bi & 63) == lane) {
 #pragma unroll
