@@ -58,40 +58,46 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
   }
   lmin = wave_min(lmin);
   const double shift = 2.0 * fmin(lmin, 0.0);
+  // Exponential race keys -log(u) / p in SINGLE precision, compared as unsigned integers (the bit pattern
+  // of a non-negative float is monotone): only the ORDER of the keys matters, this mode is statistically,
+  // not bit-wise, tied to the reference's sampler, and the kernel is VALU-issue bound -- one v_log_f32
+  // and one v_rcp_f32 instead of the f64 routines, 32-bit DPP reductions instead of f64 ones.
+  constexpr unsigned KEY_TAKEN = 0x7f800000u;  // +inf: slots that do not exist or were drawn already
+  unsigned ukey[SPL];
 #pragma unroll
   for (int q = 0; q < SPL; q++) {
     int s = lane + 64 * q;
+    unsigned k = KEY_TAKEN;
     if (s < S) {
       const double p = fit_parents ? (key[q] - shift) : 1.0;
       const double u = rng_u01(seed, (u64)n, 1, (u64)s);
-      // exponential race key -log(u) / p: the logarithm in single precision (one v_log_f32 instead of
-      // the ~60-instruction f64 routine, S of them per datapoint); only the ORDER of the keys matters and
-      // this mode is statistically, not bit-wise, tied to the reference's sampler
       const float uf = fmaxf((float)u, 1.17549435e-38f);
-      key[q] = (p > 0.0) ? (double)(-__logf(uf)) / p : 1e300;  // zero-fitness states are taken last
-    } else {
-      key[q] = INFINITY;
+      const float lg = __logf(uf);
+      const float e = lg < 0.0f ? -lg : 0.0f;  // never -0.0f: its bit pattern would sort last
+      float kf = 1e30f;                         // zero-fitness states are taken last
+      if (p > 0.0) kf = fminf(__fdividef(e, (float)p), 3.0e38f);
+      k = __float_as_uint(kf);
     }
+    ukey[q] = k;
   }
   for (int j = 0; j < n_parents; j++) {
-    double bv = key[0];
+    unsigned bv = ukey[0];
 #pragma unroll
-    for (int q = 1; q < SPL; q++) bv = fmin(bv, key[q]);
+    for (int q = 1; q < SPL; q++) bv = ukey[q] < bv ? ukey[q] : bv;
     // lexicographic (key, index) minimum over the wave: DPP min of the key, then the lowest index that
-    // holds it by ballots (index = lane + 64 q: first q with a hit, lowest lane in it).  The kernel is
-    // VALU-issue bound; a second DPP reduction over tracked indices cost as much as the first.
-    const double gv = wave_min(bv);
+    // holds it by ballots (index = lane + 64 q: first q with a hit, lowest lane in it)
+    const unsigned gv = wave_min_u32(bv);
     int bi = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < SPL; q++) {
-      const u64 hit = __ballot(key[q] == gv);
+      const u64 hit = __ballot(ukey[q] == gv);
       if (bi == 0x7fffffff && hit != 0ull) bi = 64 * q + __ffsll((long long)hit) - 1;
     }
     if (lane == 0) sel[j] = bi;
     if ((bi & 63) == lane) {
 #pragma unroll
       for (int q = 0; q < SPL; q++)
-        if (q == (bi >> 6)) key[q] = INFINITY;
+        if (q == (bi >> 6)) ukey[q] = KEY_TAKEN;
     }
   }
   __builtin_amdgcn_wave_barrier();
