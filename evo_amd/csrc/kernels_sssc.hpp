@@ -753,6 +753,8 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 template <int MODE>
 __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc) {
   a.s2inv = a.dpar[DP_S2INV];
+  // every barrier below orders LDS traffic only (the k x k system lives in LDS): lds_barrier() does not
+  // wait for the previous state's global atomics / stores the way __syncthreads() would
   __shared__ int prefix[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   double *Tm = lds;
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     const int c = (int)(e - n * a.C);
     if (a.counts && c >= a.counts[n]) continue;  // uniform
     const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
-    __syncthreads();
+    lds_barrier();
     int k = 0;
     for (int w = 0; w < a.HW; w++) {
       const u64 bits = sp[w];
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       if (q == 0.0) continue;  // uniform
       qn = q / (a.rowsum[n] + EVO_F64_TINY);
     }
-    __syncthreads();
+    lds_barrier();
     const double *Bn = a.Bm + n * a.H;
     double pb = 0.0;
     if (lane < k) {
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     if (a.mask) {
       // incomplete data: G_A of THIS datapoint, W_obs^T W_obs restricted to A -- k (k + 1) / 2 masked dot
       // products over D, lanes over the observables (rows of W^T are contiguous)
-      __syncthreads();
+      lds_barrier();
       const uint8_t *mrow = a.mask + n * a.D;
       for (int i = 0; i < k; i++) {
         const double *wi = a.Wt + (i64)idx[i] * a.D;
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     double rr_part = 0.0;
     if (lane < k) {
       double s = bv[lane];
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       rr_part = muv[lane] * (bv[lane] + s);
     }
     const double rr = a.yy[n] - wave_sum(rr_part);
-    __syncthreads();
+    lds_barrier();
     if (lane < k) {
       double s = 0.0;
       for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
       Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
     bool singular = false;
     for (int p = 0; p < k; p++) {
@@ -889,12 +891,12 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
           wv[piv] = t3;
         }
       }
-      __syncthreads();
+      lds_barrier();
       const double d = Tm[p * k + p];
       if (d == 0.0) singular = true;
       const double r = fast_rcp(d);
       if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
-      __syncthreads();
+      lds_barrier();
       const int m = k - p - 1;
       for (int q = lane; q < m * m; q += 64) {
         const int i = p + 1 + q / m, j = p + 1 + q % m;
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
         }
       }
       if (lane > p && lane < k) wv[lane] -= fv[lane] * wv[p];
-      __syncthreads();
+      lds_barrier();
     }
     double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
     const double logdet = wave_sum(ld);
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       const double r = fast_rcp(Tm[p * k + p]);
       if (lane == 0) wv[p] *= r;
       if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
-      __syncthreads();
+      lds_barrier();
       if (lane < p) wv[lane] -= Tm[lane * k + p] * wv[p];
       if (MODE == 1) {
         for (int q = lane; q < p * k; q += 64) {
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
           Pm[i * k + j] -= Tm[i * k + p] * Pm[p * k + j];
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (singular && lane == 0) atomicOr(a.err, 2);
     if (MODE == 0) {
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
         unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
         unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
       }
-      __syncthreads();
+      lds_barrier();
       for (int q = lane; q < k * k; q += 64) {
         const int i = q / k, j = q - i * k;
         const i64 o = (i64)idx[i] * a.H + idx[j];
