@@ -714,7 +714,7 @@ static bool gemm_vec_ok(const double *p, int ld) { return (ld % 2) == 0 && ((uin
 static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                                i64 M, int Nc, int K) {
   if (M <= 1024 && Nc <= 1024 && K <= 1024) {  // parameter-sized: one wave per 16 x 16 block
-    gemm_nn_small_kernel<<<dim3(cdiv(Nc, 16), cdiv(M, 16)), 64, 0, c->stream>>>(A, lda, B, ldb, C, ldc, (int)M, Nc, K);
+    gemm_nn_small_kernel<<<dim3(cdiv(Nc, 16), cdiv(M, 16)), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, (int)M, Nc, K);
     return;
   }
   const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
@@ -736,7 +736,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     // G = W^T W of the Theta update: one wave per 16 x 16 block (gram_small_kernel)
     SpanGuard g(c, KID_GEMM);
     const int nb16 = (int)cdiv(M, 16);
-    gram_small_kernel<<<dim3(nb16, nb16), 64, 0, c->stream>>>(A, lda, (int)K, M, C, ldc);
+    gram_small_kernel<<<dim3(nb16, nb16), 256, 0, c->stream>>>(A, lda, (int)K, M, C, ldc);
     HIP_TRY(hipGetLastError());
     return 0;
   }

@@ -390,21 +390,43 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
       }
 }
 
-// G = W^T W for the small, launch-latency-bound case (H <= 512): one wavefront per 16 x 16 block of G,
-// the whole K = D reduction in that wave in a fixed order (deterministic: every rank gets the same G from
-// the same W), operands straight from global memory (W is L2 resident, D x H x 8 <= 1 MB).
-// The tiled kernel gives this problem 4..64 workgroups and one software-pipeline ramp: 20 us at c2.
+// The four waves of a small-product workgroup each reduced a quarter of K; partials are added in wave
+// order (fixed: deterministic) by wave 0, which returns the total.
+__device__ __forceinline__ v4f64 small_gemm_reduce4(v4f64 acc, double (*part)[4][64]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] += part[w][r][lane];
+  }
+  return acc;
+}
+
+// G = W^T W for the small, launch-latency-bound case (H <= 512): one workgroup per 16 x 16 block of G,
+// its four waves each reduce a quarter of K = D and the partials are added in a fixed order
+// (deterministic: every rank gets the same G from the same W), operands straight from
+// global memory (W is L2 resident, D x H x 8 <= 1 MB).  The tiled kernel gives this problem 4..64
+// workgroups and one software-pipeline ramp: 20 us at c2.
 // Upper blocks only (block row <= block column); lower blocks are written transposed by the same wave.
-__global__ __launch_bounds__(64) void gram_small_kernel(const double *__restrict__ W, int ldw, int D, int H,
-                                                        double *__restrict__ G, int ldg) {
+__global__ __launch_bounds__(256) void gram_small_kernel(const double *__restrict__ W, int ldw, int D, int H,
+                                                         double *__restrict__ G, int ldg) {
+  __shared__ double part[3][4][64];
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bi > bj) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = bi * 16 + (lane & 15), j = bj * 16 + (lane & 15), kq = lane >> 4;
   const bool iv = i < H, jv = j < H;
+  const int dq = ((D + 15) / 16) * 4;  // rows of K per wave, a multiple of 4
+  const int dbeg = wave * dq, dend = (dbeg + dq < D) ? dbeg + dq : D;
   v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-  int d0 = 0;
-  for (; d0 + 16 <= D; d0 += 16) {  // four k-steps per trip: eight loads in flight
+  int d0 = dbeg;
+  for (; d0 + 16 <= dend; d0 += 16) {  // four k-steps per trip: eight loads in flight
     double a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -415,12 +437,14 @@ __global__ __launch_bounds__(64) void gram_small_kernel(const double *__restrict
 #pragma unroll
     for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
-  for (; d0 < D; d0 += 4) {
+  for (; d0 < dend; d0 += 4) {
     const int d = d0 + kq;
-    const double a = (iv && d < D) ? W[(size_t)d * ldw + i] : 0.0;
-    const double b = (jv && d < D) ? W[(size_t)d * ldw + j] : 0.0;
+    const double a = (iv && d < dend) ? W[(size_t)d * ldw + i] : 0.0;
+    const double b = (jv && d < dend) ? W[(size_t)d * ldw + j] : 0.0;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
+  acc = small_gemm_reduce4(acc, part);
+  if (wave != 0) return;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int gi = bi * 16 + (lane >> 4) + 4 * r, gj = bj * 16 + (lane & 15);
@@ -431,20 +455,23 @@ __global__ __launch_bounds__(64) void gram_small_kernel(const double *__restrict
   }
 }
 
-// C = A B for parameter-sized products (W = Wp inv(..), M, Nc, K <= 1024): one wavefront per 16 x 16
-// block of C, the K reduction in that wave in a fixed order, operands from global memory (both factors
-// are L2 resident).  The tiled kernel gives these shapes 8..64 workgroups of one K pipeline each:
-// 12 us at c2, 80 us at c5 for 0.5 GFLOP.
-__global__ __launch_bounds__(64) void gemm_nn_small_kernel(const double *__restrict__ A, int lda,
-                                                           const double *__restrict__ B, int ldb,
-                                                           double *__restrict__ C, int ldc, int M, int Nc, int K) {
-  const int lane = threadIdx.x;
+// C = A B for parameter-sized products (W = Wp inv(..), M, Nc, K <= 1024): one workgroup per 16 x 16
+// block of C, four waves over quarters of K, fixed-order reduction, operands from global memory (both
+// factors are L2 resident).  The tiled kernel gives these shapes 8..64 workgroups of one K pipeline
+// each: 12 us at c2, 80 us at c5 for 0.5 GFLOP.
+__global__ __launch_bounds__(256) void gemm_nn_small_kernel(const double *__restrict__ A, int lda,
+                                                            const double *__restrict__ B, int ldb,
+                                                            double *__restrict__ C, int ldc, int M, int Nc, int K) {
+  __shared__ double part[3][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.y * 16 + (lane & 15), j = blockIdx.x * 16 + (lane & 15), kq = lane >> 4;
   const bool iv = i < M, jv = j < Nc;
   const double *__restrict__ Ai = A + (size_t)(iv ? i : 0) * lda;
+  const int kw = ((K + 15) / 16) * 4;
+  const int kbeg = wave * kw, kend = (kbeg + kw < K) ? kbeg + kw : K;
   v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-  int k0 = 0;
-  for (; k0 + 16 <= K; k0 += 16) {
+  int k0 = kbeg;
+  for (; k0 + 16 <= kend; k0 += 16) {
     double a[4], b[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -455,12 +482,14 @@ __global__ __launch_bounds__(64) void gemm_nn_small_kernel(const double *__restr
 #pragma unroll
     for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
   }
-  for (; k0 < K; k0 += 4) {
+  for (; k0 < kend; k0 += 4) {
     const int k = k0 + kq;
-    const double a = (iv && k < K) ? Ai[k] : 0.0;
-    const double b = (jv && k < K) ? B[(size_t)k * ldb + j] : 0.0;
+    const double a = (iv && k < kend) ? Ai[k] : 0.0;
+    const double b = (jv && k < kend) ? B[(size_t)k * ldb + j] : 0.0;
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
+  acc = small_gemm_reduce4(acc, part);
+  if (wave != 0) return;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int gi = blockIdx.y * 16 + (lane >> 4) + 4 * r, gj = blockIdx.x * 16 + (lane & 15);
