@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *__res
   const i64 r0 = (i64)blockIdx.y * rows_per_block;
   const i64 r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
   double s = 0.0;
-  if (c < Cn)
-    for (i64 r = r0 + rl; r < r1; r += 4) s += X[r * ldx + c];
+  if (c < Cn && r0 + rl < r1)  // same order of additions, eight loads in flight (see ordered_strided_sum)
+    s = ordered_strided_sum(X + (r0 + rl) * ldx + c, 4 * (i64)ldx, (r1 - (r0 + rl) + 3) / 4);
   sh[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < Cn) part[(i64)blockIdx.y * Cn + c] = ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
