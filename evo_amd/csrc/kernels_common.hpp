@@ -508,7 +508,14 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
         const int j = lane + 64 * q;
         if (j < g) {
           const int bi = new_i[wave][j], wi = old_i[wave][j];
-          for (int w = 0; w < HW; w++) st_n[(i64)wi * HW + w] = cd_n[(i64)bi * HW + w];
+          for (int w0 = 0; w0 < HW; w0 += 8) {  // eight words in flight per lane
+            u64 cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = (w0 + u < HW) ? cd_n[(i64)bi * HW + w0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (w0 + u < HW) st_n[(i64)wi * HW + w0 + u] = cv[u];
+          }
           lpj_n[wi] = new_v[wave][j];
           if (dig) dig[n * (i64)S + wi] = cand_dig[n * (i64)Cmax + bi];
         }

@@ -127,11 +127,20 @@ __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     u64 *dst = cand + (n * (i64)Cmax + kid) * HW;
     u64 d = 0;
     int dk = 0;
-    for (int w = 0; w < HW; w++) {
-      u64 v = par[w];
-      if (w == (mine >> 6)) v ^= (0x8000000000000000ull >> (mine & 63));
-      dst[w] = v;
-      while (v) digest_add(d, dk, w * 64 + pop_msb(v));
+    for (int w0 = 0; w0 < HW; w0 += 8) {  // eight words in flight: a load-then-store loop pays a round trip per word
+      u64 pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) pv[u] = (w0 + u < HW) ? par[w0 + u] : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int w = w0 + u;
+        if (w < HW) {
+          u64 v = pv[u];
+          if (w == (mine >> 6)) v ^= (0x8000000000000000ull >> (mine & 63));
+          dst[w] = v;
+          while (v) digest_add(d, dk, w * 64 + pop_msb(v));
+        }
+      }
     }
     if (cand_dig) cand_dig[n * (i64)Cmax + kid] = digest_close(d, dk);
   }

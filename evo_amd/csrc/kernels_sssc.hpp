@@ -249,14 +249,20 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
 #pragma unroll
     for (int i = 0; i < (K < DIG_SLOTS ? K : DIG_SLOTS); i++) idx[i] = dig_idx(dg, i);
   }
-  for (int w = 0; w < a.HW && !have_dg; w++) {
-    u64 bits = sp[w];
-    while (bits) {
-      const int h = w * 64 + pop_msb(bits);
+  for (int w0 = 0; w0 < a.HW && !have_dg; w0 += 8) {  // eight words in flight per lane
+    u64 wv[8];
 #pragma unroll
-      for (int i = 0; i < K; i++)
-        if (i == k) idx[i] = h;
-      k++;
+    for (int u = 0; u < 8; u++) wv[u] = (w0 + u < a.HW) ? sp[w0 + u] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      u64 bits = wv[u];
+      while (bits) {
+        const int h = (w0 + u) * 64 + pop_msb(bits);
+#pragma unroll
+        for (int i = 0; i < K; i++)
+          if (i == k) idx[i] = h;
+        k++;
+      }
     }
   }
   double b[K], mu[K], v[K], wv[K];
@@ -381,7 +387,13 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
         ktot = dig_k(dg);  // saturates at 255 > K
         have_dg = ktot <= DIG_SLOTS;
       } else {
-        for (int w = 0; w < a.HW; w++) ktot += __popcll(sp[w]);
+        for (int w0 = 0; w0 < a.HW; w0 += 8) {
+          u64 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) wv[u] = (w0 + u < a.HW) ? sp[w0 + u] : 0ull;
+#pragma unroll
+          for (int u = 0; u < 8; u++) ktot += __popcll(wv[u]);
+        }
       }
     }
     const bool over = live && ktot > K;
@@ -776,8 +788,18 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
     lds_barrier();
     int k = 0;
+    // lane w loads word w (one round trip for the whole state), the loop broadcasts them
+    u64 myword = 0ull;
+    if (a.HW <= 64) myword = (lane < a.HW) ? sp[lane] : 0ull;
     for (int w = 0; w < a.HW; w++) {
-      const u64 bits = sp[w];
+      u64 bits;
+      if (a.HW <= 64) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
+        bits = ((u64)hi << 32) | lo;
+      } else {
+        bits = sp[w];
+      }
       const bool on = (bits >> (63 - lane)) & 1ull;
       const u64 m = __ballot(on);
       const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
