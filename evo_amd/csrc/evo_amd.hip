@@ -122,6 +122,7 @@ struct evoamd_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool gemm_forked = false;
+  bool ar_gemm_pending = false;  // with a communicator: the contraction's block of acc is all-reduced at the join
   int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
   // which ES3C overflow levels (K=4, K=8, LDS) the next pass over K^n needs; exact, from the
@@ -1501,12 +1502,20 @@ static int join_fork(evoamd_ctx *c) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     c->gemm_forked = false;
   }
+  if (c->ar_gemm_pending) {  // second piece of the split all-reduce (stats_compute sent the rest before the inverses)
+    c->ar_gemm_pending = false;
+    const AccLayout a = acc_layout(c);
+    RCCL_TRY(g_rccl.AllReduce(c->acc + a.sWp, c->acc + a.sWp, (size_t)(a.y2 - a.sWp), /*ncclDouble*/ 8, /*ncclSum*/ 0,
+                              c->comm, c->stream));
+  }
   return 0;
 }
 
 // fork_gemm: the caller promises to call join_fork before it reads the contraction's block of acc
-// (evoamd_mstep_device: after the H x H inverses).  Not with a communicator (the all-reduce below
-// needs the whole accumulator) and not while kernels are being timed on the main stream.
+// (evoamd_mstep_device: after the H x H inverses).  With a communicator (ES3C) the packed accumulator is
+// all-reduced in two pieces: everything the inverses read here, the contraction's block at the join --
+// all RCCL calls stay on the main stream, in the same order on every rank.  Not while kernels are being
+// timed on the main stream.
 static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
   const bool gemm_timed = c->timing && (c->timing_mask & ((1u << KID_GEMM) | (1u << KID_MSTEP) | (1u << KID_MISC)));
@@ -1514,8 +1523,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // H = 128 and EBSC (H = 256, 1024) lose ~1 %: their contraction fills every CU with long split-K
   // workgroups, the chain's small kernels wait for slots, and the fork/join events cost ~10 us
   const bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
-  fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) && !c->comm && !gemm_timed &&
-              !c->mask_infr;
+  fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) &&
+              (!c->comm || c->model == EVOAMD_MODEL_SSSC) && !gemm_timed && !c->mask_infr;
   {
     int rj = join_fork(c);  // a previous call that failed between fork and join must not race with the memset below
     if (rj) return rj;
@@ -1728,7 +1737,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       HIP_TRY(hipGetLastError());
     }
   }
-  if (c->comm) {
+  if (c->comm && c->gemm_forked) {
+    // [xs | xss | xsz | xszsz] and [y2 | tail] now; [Wp | s_sz | sz_sz] when the contraction has joined
+    RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)a.sWp, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
+    RCCL_TRY(g_rccl.AllReduce(c->acc + a.y2, c->acc + a.y2, (size_t)(c->acc_n - a.y2), 8, 0, c->comm, c->stream));
+    c->ar_gemm_pending = true;
+  } else if (c->comm) {
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
   c->stats_rows_valid = true;

@@ -356,8 +356,11 @@ def test_bench_path_with_rccl_communicator():
     D, H, S, N = 24, 40, 16, 200
     Y = rng.normal(size=(N, D))
     res = []
-    for use_comm in (False, True):
+    for use_comm, overlap in ((False, 1), (True, 1), (True, 2)):
+        # overlap = 2: the statistics contraction runs beside the inverses and the packed accumulator is
+        # all-reduced in two pieces (scattered moments before the inverses, the GEMM block at the join)
         eng = Engine()
+        eng.set_option("overlap_gemm", overlap)
         try:
             comm = parallel.RcclComm(eng, 0, 1, Engine.comm_unique_id()) if use_comm else None
             np.random.seed(4)
@@ -379,6 +382,7 @@ def test_bench_path_with_rccl_communicator():
         finally:
             eng.close()
     np.testing.assert_allclose(res[1], res[0], rtol=1e-9)
+    np.testing.assert_allclose(res[2], res[0], rtol=1e-9)
 
 
 @pytest.mark.parametrize("D,H,S,N,device_mstep", [(64, 64, 20, 300, False), (64, 64, 20, 300, True),
