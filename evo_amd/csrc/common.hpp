@@ -154,9 +154,15 @@ __device__ __forceinline__ int dig_idx(u64 d, int j) {
 __device__ __forceinline__ u64 make_digest(const u64 *sp, int HW) {
   u64 d = 0;
   int k = 0;
-  for (int w = 0; w < HW; w++) {
-    u64 bits = sp[w];
-    while (bits) digest_add(d, k, w * 64 + pop_msb(bits));
+  for (int w0 = 0; w0 < HW; w0 += 8) {  // eight words in flight
+    u64 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) wv[u] = (w0 + u < HW) ? sp[w0 + u] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      u64 bits = wv[u];
+      while (bits) digest_add(d, k, (w0 + u) * 64 + pop_msb(bits));
+    }
   }
   return digest_close(d, k);
 }
