@@ -776,6 +776,11 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
           per_xcd = pc;
         }
       }
+      // measured exception (tools/gemm_sweep.sh, 34 real tiles = the ES3C H = 512 contraction, K = 25k / 50k /
+      // 100k): 8 chunks per XCD beat the fullest split by 5-7 % (2.44 vs 2.59 ms at K = 100k), and so do 16;
+      // other counts between 5 and 15 do not.  The cause was not isolated (chunk count a multiple of the
+      // XCD count in both winners); applied only in that multi-round regime.
+      if (real > 24 && K / 64 >= 384) per_xcd = 8;
       splits = 8 * per_xcd;
     } else {
       splits = (512 + tiles - 1) / tiles;
