@@ -57,6 +57,7 @@ SIGNATURES = {
     "evoamd_reconstruct": (_I, [_vp, _c_dp]),
     "evoamd_upload_masks": (_I, [_vp, _c_u8p, _c_u8p]),
     "evoamd_upload_yrec": (_I, [_vp, _c_dp]),
+    "evoamd_set_reliable_fraction": (_I, [_vp, ctypes.c_double]),
     "evoamd_lpj_single_masked": (_I, [_vp, _c_dp, _c_u8p, _c_u8p, _I, _c_dp, _c_i32p]),
     "evoamd_inverse": (_I, [_vp, _c_dp, _c_dp, _I, _c_dp]),
     "evoamd_gemm_tn": (_I, [_vp, _c_dp, _c_dp, _c_dp, _I64, _I, _I, _I]),

@@ -122,6 +122,7 @@ struct evoamd_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool gemm_forked = false;
+  double rel_frac = -1.0;  // EBSC incomplete data: sum(x_infr) / N over all ranks (evoamd_set_reliable_fraction)
   bool ar_gemm_pending = false;  // with a communicator: the contraction's block of acc is all-reduced at the join
   int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
@@ -645,6 +646,12 @@ extern "C" int evoamd_upload_masks(evoamd_ctx *c, const uint8_t *x_infr, const u
   return 0;
 }
 
+extern "C" int evoamd_set_reliable_fraction(evoamd_ctx *c, double reliable_per_datapoint) {
+  REQUIRE(c, "ctx is NULL");
+  c->rel_frac = reliable_per_datapoint;
+  return 0;
+}
+
 extern "C" int evoamd_upload_yrec(evoamd_ctx *c, const double *y_rec) {
   REQUIRE(c && c->configured && c->mask_infr && y_rec, "upload_masks first");
   HIP_TRY(hipSetDevice(c->device));
@@ -825,8 +832,8 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC, "context is not configured for BSC");
   REQUIRE(W, "W is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  // bsc.py:111-121 (complete data)
-  c->ljc = c->H * log(1.0 - pi) - c->D / 2.0 * log(2 * M_PI * sigma * sigma);
+  // bsc.py:111-121; incomplete data: the normaliser counts the reliable entries (bsc.py:113-118)
+  c->ljc = c->H * log(1.0 - pi) - (c->rel_frac >= 0.0 ? c->rel_frac : (double)c->D) / 2.0 * log(2 * M_PI * sigma * sigma);
   if (ljc) *ljc = c->ljc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // pinned mirrors may still be in flight
   memset(c->h_dpar, 0, DP_COUNT * sizeof(double));
@@ -1935,7 +1942,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H);
       transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
     }
-    bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar);
+    bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar,
+                                                  c->mask_infr ? c->rel_frac : -1.0);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   }
@@ -2040,14 +2048,16 @@ static int mailbox_errors(evoamd_ctx *c) {
 
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
-  REQUIRE(!(c && c->mask_infr), "incomplete data: the Theta update runs on the host (bsc.py:113-118,266-272)");
+  REQUIRE(!(c && c->mask_infr && c->model == EVOAMD_MODEL_SSSC),
+          "ES3C on incomplete data: the Theta update runs on the host (sssc.py:352-357,747-755)");
+  REQUIRE(!(c && c->mask_infr && c->rel_frac < 0.0), "incomplete data: evoamd_set_reliable_fraction first (bsc.py:113-118)");
   int r = stats_compute(c, /*fork_gemm=*/true);
   if (r) return r;
   c->h_theta_fresh = false;
   const bool want_rec = (learn_mask & 32) != 0;
   learn_mask &= 31;
-  if (want_rec) {  // under the Theta the E-step used, i.e. before the update
-    r = compute_reconstruction(c);
+  if (want_rec && !c->yhat_valid) {  // under the Theta the E-step used, i.e. before the update
+    r = compute_reconstruction(c);   // (incomplete data: the statistics pass formed it already)
     if (r) return r;
   }
   if (learn_mask) {

@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
 __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restrict__ pies_sum,
                                                            const double *__restrict__ sig_sum, int H, int D,
                                                            const double *__restrict__ Nptr, int learn,
-                                                           double *__restrict__ dpar) {
+                                                           double *__restrict__ dpar, double rel_frac) {
+  // rel_frac >= 0: incomplete data, mean reliable entries per datapoint (bsc.py:113-118, 266-272)
   __shared__ double sh[MS_T];
   const int t = threadIdx.x;
   const double N = *Nptr;
@@ -1028,7 +1029,12 @@ __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restr
   if (t == 0) {
     double pi = dpar[DP_PI], sigma = dpar[DP_SIGMA];
     if (learn & L_PI) pi = sh[0] / H;
-    if (learn & L_SIGMA) sigma = sqrt(sig_sum[0] / N / D);
+    if (learn & L_SIGMA) {
+      if (rel_frac >= 0.0)  // as written in the reference: OLD sigma^2 x the count of reliable entries is added
+        sigma = sqrt((sig_sum[0] + (rel_frac * N) * (sigma * sigma)) / N / D);
+      else
+        sigma = sqrt(sig_sum[0] / N / D);
+    }
     if (pi < 1e-5) pi = 1e-5;
     if (pi >= 1.0 - 1e-5) pi = 1.0 - 1e-5;
     if (sigma < 1e-5) sigma = 1e-5;
@@ -1037,7 +1043,7 @@ __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restr
     dpar[DP_PRE1] = -1.0 / 2.0 / sigma / sigma;
     dpar[DP_PILBAR] = log(pi / (1.0 - pi));
     dpar[DP_LJC_PREV] = dpar[DP_LJC];
-    dpar[DP_LJC] = H * log(1.0 - pi) - D / 2.0 * log(2 * M_PI * sigma * sigma);
+    dpar[DP_LJC] = H * log(1.0 - pi) - (rel_frac >= 0.0 ? rel_frac : (double)D) / 2.0 * log(2 * M_PI * sigma * sigma);
     if (!(sigma == sigma) || !(pi == pi)) dpar[DP_STATUS] = 2.0;
   }
 }

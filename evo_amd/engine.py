@@ -169,6 +169,10 @@ class Engine:
         assert y_rec.shape == (self.N, self.D)
         check(self.lib.evoamd_upload_yrec(self._h, dptr(y_rec)))
 
+    def set_reliable_fraction(self, r):
+        """Mean reliable entries per datapoint over all ranks (bsc.py:113-118,266-272); None / negative: complete data."""
+        check(self.lib.evoamd_set_reliable_fraction(self._h, -1.0 if r is None else float(r)))
+
     def vary_kn(self, Mprime, want_sums=True):
         sums = np.zeros(2, dtype=np.float64)
         check(self.lib.evoamd_vary_kn(self._h, int(Mprime), dptr(sums) if want_sums else None))

@@ -134,9 +134,9 @@ class Model:
         if new_masks:  # checked once per array object, like the Y upload below
             self._incomplete = not xi.all()
             if self._incomplete:
-                if self.device_mstep:
-                    raise NotImplementedError("missing data: use device_mstep=False (the Theta update of bsc.py:113-118,"
-                                              "266-272 / sssc.py:352-357,747-755 runs on the host)")
+                if self.device_mstep and self.model_name != "bsc":
+                    raise NotImplementedError("ES3C on missing data: use device_mstep=False (the Theta update of "
+                                              "sssc.py:352-357,747-755 runs on the host)")
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])
@@ -262,9 +262,14 @@ class Model:
             self._candidates_device(eng, my_suff_stat)
         eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
         self._n_steps += 1
+        if self._incomplete and do_reconstruction:
+            # y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211): formed inside the statistics pass
+            eng.set_option("reconstruct_in_stats", 1)
         tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction)
         if do_reconstruction:
             self._write_reconstruction(my_data)
+            if self._incomplete:
+                self._yrec_token = id(my_data["y_reconstructed"])  # the device already holds it
         if self.sync_host:
             self.sync_to_host(my_suff_stat)
         my_suff_stat["reset_lpj_isnan"] = int(tail["reset_isnan"])

@@ -26,6 +26,11 @@ class BSC(Model):
 
     # ---- E-step ------------------------------------------------------------------------------
     def _push_params(self, model_params):
+        n_rel = getattr(self, "_n_reliable", None)
+        if n_rel is not None:  # incomplete data: mean reliable entries per datapoint over all ranks (bsc.py:113-118)
+            self.engine.set_reliable_fraction(n_rel / float(self._n_total))
+        else:
+            self.engine.set_reliable_fraction(None)
         self.engine.set_params_bsc(model_params["W"], model_params["pi"], model_params["sigma"])
 
     def _pull_params(self, dpar):
@@ -46,6 +51,7 @@ class BSC(Model):
             self._n_reliable = None
         else:  # bsc.py:113-118: the Gaussian normaliser counts the reliable entries
             N = self.comm.allreduce(xi.shape[0])
+            self._n_total = N
             self._n_reliable = self.comm.allreduce(int(xi.sum()))
             model_params["ljc"] = (self.H * np.log(1.0 - pi)
                                    - np.log(2 * np.pi * sigma * sigma) * self._n_reliable / N / 2)

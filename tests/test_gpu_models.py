@@ -456,7 +456,8 @@ def test_reconstruction_against_reference(engine, algo, device_mstep):
         assert np.array_equal(got[x], Y[x])
 
 
-def test_missing_data_ebsc_against_reference(engine):
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_missing_data_ebsc_against_reference(engine, device_mstep):
     """EBSC on incomplete data (image-inpainting set-up: NaN at the missing entries, x_infr = x = ~isnan):
     standard_init, masked lpj / selection, reconstruction feeding the same step's M-step, the step that
     reuses an older y_reconstructed -- against tests/golden/missing_ebsc.npz recorded from the reference."""
@@ -465,7 +466,9 @@ def test_missing_data_ebsc_against_reference(engine):
     D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
     Y, x_infr = g["Y"], g["x_infr"]
     my_data = {"y": Y, "x_infr": x_infr, "x": x_infr.copy()}
-    model = BSC(D, H, S, engine=engine)
+    # device_mstep: the Theta update of bsc.py:226-277 on the device too (reliable-entry count in the sigma
+    # update and in ljc, bsc.py:113-118,266-272)
+    model = BSC(D, H, S, engine=engine, device_mstep=device_mstep)
     theta = {k: np.array(g["t0_in_%s" % k]) for k in BSC_KEYS}
     for k in ("pi", "sigma"):
         theta[k] = np.float64(theta[k])
