@@ -890,8 +890,12 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
     }
     l = (double)acc;
   }
-  l -= D / 2.0 * log(2 * M_PI);
-  l -= 0.5 * (D * (double)logl(s2));
+  if (c->rel_frac >= 0.0) {  // sssc.py:352-357: the Gaussian normaliser counts the reliable entries
+    l += (-log(2 * M_PI) - log(sigma2)) * c->rel_frac / 2.0;
+  } else {
+    l -= D / 2.0 * log(2 * M_PI);
+    l -= 0.5 * (D * (double)logl(s2));
+  }
   c->ljc = l;
   if (ljc) *ljc = l;
   HIP_TRY(hipStreamSynchronize(c->stream));  // the pinned staging area may still be in flight
@@ -1875,6 +1879,10 @@ static int refresh_after_update(evoamd_ctx *c) {
   int r = 0;
   SpanGuard g(c, KID_MSTEP);
   if (c->model == EVOAMD_MODEL_SSSC) {
+    if (c->mask_infr) {  // incomplete data: the wavefront kernel forms W_obs^T W_obs from W^T (sssc.py:276)
+      if (!c->Wt) ALLOC(c->Wt, (size_t)H * D);
+      transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->W, D, H, c->Wt);
+    }
     sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
                                                                      c->PT, c->GP, c->DG);
     HIP_TRY(hipGetLastError());
@@ -1926,10 +1934,12 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     const int n_part = (int)std::min<i64>(1024, cdiv(HH, 1024));
     r = ensure_colpart(c, (size_t)n_part);
     if (r) return r;
-    if (learn & L_SIGMA2)
+    const bool masked = c->mask_infr != nullptr;  // sssc.py:747-755: the trace term arrives in tail[7]
+    if ((learn & L_SIGMA2) && !masked)
       sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
-    sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, n_part, H, Nptr, learn,
-                                                            c->pies, c->pilbar_v, c->dpar);
+    sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, masked ? 0 : n_part, H, Nptr, learn,
+                                                            c->pies, c->pilbar_v, c->dpar, masked ? c->rel_frac : -1.0,
+                                                            c->acc + a.tail + 7);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   } else {
@@ -2048,8 +2058,6 @@ static int mailbox_errors(evoamd_ctx *c) {
 
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
-  REQUIRE(!(c && c->mask_infr && c->model == EVOAMD_MODEL_SSSC),
-          "ES3C on incomplete data: the Theta update runs on the host (sssc.py:352-357,747-755)");
   REQUIRE(!(c && c->mask_infr && c->rel_frac < 0.0), "incomplete data: evoamd_set_reliable_fraction first (bsc.py:113-118)");
   int r = stats_compute(c, /*fork_gemm=*/true);
   if (r) return r;

@@ -967,7 +967,9 @@ __global__ __launch_bounds__(256) void sssc_trace_partial_kernel(const double *_
 __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     const double *__restrict__ y2, int D, const double *__restrict__ trace_part, int n_part, int H,
     const double *__restrict__ Nptr, int learn, const double *__restrict__ pies, double *__restrict__ pil_bar,
-    double *__restrict__ dpar) {
+    double *__restrict__ dpar, double rel_frac, const double *__restrict__ pad) {
+  // rel_frac >= 0: incomplete data (sssc.py:352-357, 747-755): no trace partials (n_part = 0); *pad = the
+  // masked square sum of y_hat, the reliable-entry count times the OLD sigma2 is added
   __shared__ double sh[MS_T];
   const int t = threadIdx.x;
   double s = 0.0;
@@ -998,12 +1000,20 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
   }
   if (t == 0) {
     double s2 = dpar[DP_SIGMA2];
-    if (learn & L_SIGMA2) s2 = (tot / (*Nptr) / (double)D) + 1e-5;
+    if (learn & L_SIGMA2) {
+      if (rel_frac >= 0.0)
+        s2 = (((tot - pad[0]) + (rel_frac * (*Nptr)) * s2) / (*Nptr) / (double)D) + 1e-5;
+      else
+        s2 = (tot / (*Nptr) / (double)D) + 1e-5;
+    }
     if (s2 < 1e-5) s2 = 1e-5;  // check_params
     dpar[DP_SIGMA2] = s2;
     dpar[DP_S2INV] = 1.0 / s2;
     dpar[DP_LJC_PREV] = dpar[DP_LJC];
-    dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - 0.5 * (D * log(s2));
+    if (rel_frac >= 0.0)
+      dpar[DP_LJC] = sh[0] + (-log(2 * M_PI) - log(s2)) * rel_frac / 2.0;
+    else
+      dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - 0.5 * (D * log(s2));
     if (!(s2 == s2) || isinf(s2)) dpar[DP_STATUS] = 2.0;
   }
 }

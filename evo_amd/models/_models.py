@@ -133,10 +133,6 @@ class Model:
         new_masks = self._x_infr_token != xi_token
         if new_masks:  # checked once per array object, like the Y upload below
             self._incomplete = not xi.all()
-            if self._incomplete:
-                if self.device_mstep and self.model_name != "bsc":
-                    raise NotImplementedError("ES3C on missing data: use device_mstep=False (the Theta update of "
-                                              "sssc.py:352-357,747-755 runs on the host)")
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])

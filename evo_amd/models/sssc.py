@@ -94,6 +94,8 @@ class SSSC(Model):
 
     # ---- E-step ------------------------------------------------------------------------------
     def _push_params(self, model_params):
+        n_rel = getattr(self, "_n_reliable", None)  # incomplete data: mean reliable entries per datapoint (sssc.py:352-357)
+        self.engine.set_reliable_fraction(None if n_rel is None else n_rel / float(self._n_total))
         self.engine.set_params_sssc(model_params["W"], model_params["pies"], model_params["mus"],
                                     model_params["Psi"], float(model_params["sigma2"]))
 
@@ -117,6 +119,7 @@ class SSSC(Model):
         self._n_reliable = None
         if not xi.all():  # sssc.py:352-357: the Gaussian normaliser counts the reliable entries
             N = self.comm.allreduce(xi.shape[0])
+            self._n_total = N
             self._n_reliable = self.comm.allreduce(int(xi.sum()))
             model_params["ljc"] = (np.log(1.0 - pies).sum()
                                    + (-np.log(2 * np.pi) - np.log(model_params["sigma2"])) * self._n_reliable / N / 2)
@@ -131,6 +134,9 @@ class SSSC(Model):
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """check_params -> fused EM_step (sssc.py:407-417)."""
         if self.device_mstep:
+            if not my_data["x_infr"].all() and not do_reconstruction:
+                raise ValueError("ES3C on incomplete data needs do_reconstruction=True in every step: the reference's "
+                                 "Wp accumulation reads the reconstructed row (sssc.py:630-633)")
             return self._step_device(model_params, my_suff_stat, my_data, do_reconstruction)
         model_params = self.check_params(model_params)
         return self.EM_step(model_params, my_suff_stat, my_data, do_reconstruction)

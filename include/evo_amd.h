@@ -186,11 +186,11 @@ int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, doubl
  * Theta update for incomplete data stays on the host (evoamd_mstep_device refuses). */
 int evoamd_upload_masks(evoamd_ctx *ctx, const uint8_t *x_infr, const uint8_t *x);
 int evoamd_upload_yrec(evoamd_ctx *ctx, const double *y_reconstructed);
-/* EBSC on incomplete data with the device Theta update (evoamd_mstep_device): the mean number of reliable
- * entries per datapoint over ALL ranks, sum(x_infr) / N.  bsc.py:113-118 puts it into the Gaussian
- * normaliser of ljc, bsc.py:266-272 into the sigma update (as written there: old sigma^2 times the
- * count of reliable entries is added to the residual sum).  Negative: complete data (default).  Call
- * before evoamd_set_params_bsc. */
+/* Incomplete data with the device Theta update (evoamd_mstep_device): the mean number of reliable
+ * entries per datapoint over ALL ranks, sum(x_infr) / N.  bsc.py:113-118 / sssc.py:352-357 put it into
+ * the Gaussian normaliser of ljc, bsc.py:266-272 / sssc.py:747-755 into the sigma / sigma2 update (as
+ * written there: the old variance times the count of reliable entries is added to the residual sum).
+ * Negative: complete data (default).  Call before evoamd_set_params_bsc / _sssc. */
 int evoamd_set_reliable_fraction(evoamd_ctx *ctx, double reliable_per_datapoint);
 /* evoamd_lpj_single with this datapoint's x_infr row (D bool bytes): log_pseudo_joint reading
  * my_data["this_x_infr"] (bsc.py:80-95). */

@@ -496,7 +496,8 @@ def test_missing_data_ebsc_against_reference(engine, device_mstep):
     np.testing.assert_allclose(one, orc.bsc_lpj(th, suff["ss"][n], Y[n], orc.new_counters(), x_infr[n]), rtol=1e-10)
 
 
-def test_missing_data_es3c_against_reference(engine):
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_missing_data_es3c_against_reference(engine, device_mstep):
     """ES3C on incomplete data (per-datapoint W_obs^T W_obs formed inside the wavefront kernel): F, K^n, lpj,
     y_reconstructed and Theta of two chained steps against tests/golden/missing_es3c.npz (reference with
     use_storage=False, do_reconstruction=True)."""
@@ -505,7 +506,7 @@ def test_missing_data_es3c_against_reference(engine):
     D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
     Y, x_infr = g["Y"], g["x_infr"]
     my_data = {"y": Y, "x_infr": x_infr, "x": x_infr.copy()}
-    model = SSSC(D, H, S, engine=engine)
+    model = SSSC(D, H, S, engine=engine, device_mstep=device_mstep)  # device: sssc.py:352-357,747-755 in the kernels
     theta = {k: np.array(g["t0_in_%s" % k]) for k in SSSC_KEYS}
     theta["sigma2"] = np.float64(theta["sigma2"])
     suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
