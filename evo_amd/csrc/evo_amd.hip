@@ -149,6 +149,7 @@ struct evoamd_ctx {
   // changes what that pass computes (Theta, K^n, data, options).
   unsigned long long gen = 0, prefetch_gen = ~0ull;
   bool prefetch_lpj = true;  // option "prefetch_lpj"
+  int spd_block = 0;        // SPD elimination, columns per launch (option "inverse_block"): 0 = 32 from n = 256 on, else 16; 16 / 32 force
   bool use_digest = true;   // lpj / statistics kernels read the state digests (option "state_digest")
   bool spd_inverse = true;  // M-step H x H systems: SPD block Gauss-Jordan first, pivoted path on a bad pivot
   long spd_fallbacks = 0;   // how often the pivoted repeat was needed
@@ -413,6 +414,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->prefetch_lpj = value != 0;
     return 0;
   }
+  if (strcmp(name, "inverse_block") == 0) {
+    if (value != 0 && value != 16 && value != 32) return fail(EVOAMD_E_INVALID, "inverse_block: 0 (auto), 16 or 32");
+    c->spd_block = value;
+    return 0;
+  }
   if (strcmp(name, "overlap_gemm") == 0) {
     c->overlap_gemm = value;
     return 0;
@@ -528,7 +534,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->tmpC, (size_t)H * H);
   // two ping-pong H x H partners | pivoted path: D, Pn (2 x H x 32 each), ipiv, perm (unblocked,
   // H > 1024: colp | rowp | perm in the same place) | SPD path: Pinv (2 x 2 x 256), diag (2 x H)
-  ALLOC(c->gjwork, (size_t)2 * H * H + (size_t)132 * H + 1040);
+  ALLOC(c->gjwork, (size_t)2 * H * H + (size_t)132 * H + 1040 + 4 * GJS32 * GJS32);  // + pivot inverses of the 32-column path
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Es, (size_t)N * H);
   } else {
@@ -1850,6 +1856,22 @@ static int launch_inverse_spd(evoamd_ctx *c, double *A, double *B, int n) {
   gm.w[1] = c->gjwork + (size_t)n * n;
   double *Pinv = c->gjwork + (size_t)2 * n * n + (size_t)130 * n + 8;
   double *d0 = Pinv + 2 * 2 * GJS_B * GJS_B;
+  // measured per inverse pair (tools/bench_inverse.py): n = 128 71 vs 73 us, 256 129 vs 141, 512 241 vs 286,
+  // 1024 629 vs 774 -- the wider step pays from n = 256 on ("inverse_block" = 32 forces it from n = 32 for the tests)
+  if (n >= GJS32 && (c->spd_block == 32 || (c->spd_block == 0 && n >= 256))) {
+    double *Pinv32 = c->gjwork + (size_t)2 * n * n + (size_t)132 * n + 1040;
+    gjs32_first_kernel<<<nmat, 64, 0, c->stream>>>(gm, n, Pinv32, d0, c->dpar + DP_STATUS);
+    const dim3 grid32(cdiv(n, 64), cdiv(n, 64), nmat);
+    int flip32 = 0;
+    for (int p0 = 0; p0 < n; p0 += GJS32, flip32 ^= 1)
+      gjs32_step_kernel<<<grid32, 256, 0, c->stream>>>(gm, n, p0, flip32, Pinv32, d0, c->dpar + DP_STATUS);
+    HIP_TRY(hipGetLastError());
+    if (flip32) {
+      for (int k = 0; k < nmat; k++)
+        HIP_TRY(hipMemcpyAsync(gm.a[k], gm.w[k], (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+  }
   gjs_first_kernel<<<nmat, 64, 0, c->stream>>>(gm, n, Pinv, d0, c->dpar + DP_STATUS);
   const dim3 grid(cdiv(n, 64), cdiv(n, 64), nmat);
   int flip = 0;

@@ -793,6 +793,287 @@ __global__ __launch_bounds__(256) void gjs_step_kernel(GjMats m, int n, int p0, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 32-column block steps (n >= 32).  A 16-column step costs ~8.5 us whatever n is: ~2 us launch, ~2.5 us
+// of tile loads / MFMA / stores and ~2.5 us for the chain of 16 scalar pivots of the next diagonal block,
+// with only the last part depending on the block width.  Here one launch eliminates 32 columns and the
+// 32 x 32 pivot block is inverted by ONE wave entirely in registers through its Schur complement:
+//   X = A11^-1,  U = X A21^T,  S = A22 - A21 U,  Y = S^-1,
+//   inv = [ X + U Y U^T , -(Y U^T)^T ; -Y U^T , Y ]
+// Two register inversions of 16 x 16 blocks plus 24 MFMAs: with lane = (g = lane >> 4, i = lane & 15) a block
+// is held as a[kk] = B[i][4 kk + g] ("A layout", what the MFMA A operand wants and what the register
+// inversion works in); the MFMA result layout acc[r] = B[g + 4 r][i] is also the B-operand layout; the four
+// changes of layout go through a wave-private 16 x 17 LDS tile.  Nothing assumes symmetry (xpt_szsz is
+// not symmetric once Psi is not, quirk Q2).  (A 64-column variant with the pivot
+// block in LDS was measured slower than 16 columns; this one keeps the pivot chain in registers.)
+// ---------------------------------------------------------------------------------------
+#define GJS32 32
+template <int Q>
+__device__ __forceinline__ void inv16a_step(double (&a)[4], int i, int g, double dreg, bool &ok) {
+  constexpr int KQ = Q >> 2, GQ = Q & 3;  // column Q lives in register KQ of lane group GQ
+  double pr[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) pr[kk] = row_bcast_f64<Q>(a[kk]);  // pivot row, my columns 4 kk + g
+  const double piv = readlane_f64_dyn(a[KQ], Q + 16 * GQ);
+  const double f = bpermute_f64(a[KQ], i + 16 * GQ);                // my row's multiplier B[i][Q]
+  if (!(piv > 1e-13 * readlane_f64_dyn(dreg, Q))) ok = false;
+  const double rinv = fast_rcp(piv);
+  const double gmul = f * rinv;
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const int c = 4 * kk + g;
+    double v;
+    if (i == Q) v = (c == Q) ? rinv : pr[kk] * rinv;
+    else v = (c == Q) ? -gmul : fma(-gmul, pr[kk], a[kk]);
+    a[kk] = v;
+  }
+}
+// in-register inverse of an SPD 16 x 16 block held in the A layout; dreg = original diagonal of row i
+__device__ __forceinline__ bool inv16a_spd(double (&a)[4], double dreg) {
+  const int l = lane_id(), i = l & 15, g = l >> 4;
+  bool ok = true;
+  inv16a_step<0>(a, i, g, dreg, ok);
+  inv16a_step<1>(a, i, g, dreg, ok);
+  inv16a_step<2>(a, i, g, dreg, ok);
+  inv16a_step<3>(a, i, g, dreg, ok);
+  inv16a_step<4>(a, i, g, dreg, ok);
+  inv16a_step<5>(a, i, g, dreg, ok);
+  inv16a_step<6>(a, i, g, dreg, ok);
+  inv16a_step<7>(a, i, g, dreg, ok);
+  inv16a_step<8>(a, i, g, dreg, ok);
+  inv16a_step<9>(a, i, g, dreg, ok);
+  inv16a_step<10>(a, i, g, dreg, ok);
+  inv16a_step<11>(a, i, g, dreg, ok);
+  inv16a_step<12>(a, i, g, dreg, ok);
+  inv16a_step<13>(a, i, g, dreg, ok);
+  inv16a_step<14>(a, i, g, dreg, ok);
+  inv16a_step<15>(a, i, g, dreg, ok);
+  return ok;
+}
+__device__ __forceinline__ v4f64 mfma4(const double (&a)[4], const double (&b)[4], v4f64 acc) {
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc, 0, 0, 0);
+  return acc;
+}
+// 16 x 16 transpose between the two register layouts through a wave-private LDS tile: in[kk] = B[i][4 kk + g]
+// (A layout) <-> out[r] = B[g + 4 r][i] (accumulator = B-operand layout); the same code maps either way.
+__device__ __forceinline__ void lds_transpose16(const double (&in)[4], double (&out)[4], double (*T)[GJS_B + 1]) {
+  const int l = lane_id(), i = l & 15, g = l >> 4;
+  lds_wave_fence();  // earlier reads of T by this wave are done
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) T[i][4 * kk + g] = in[kk];
+  lds_wave_fence();
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[r] = T[g + 4 * r][i];
+}
+// One wave: inverse of the 32 x 32 block M (LDS, row stride 33; diagonal-dominant enough for elimination
+// without interchanges: the M-step's moment matrices, which are NOT exactly symmetric -- xpt_szsz inherits
+// the asymmetry of Psi, quirk Q2 -- so nothing below assumes symmetry), written row-major (stride 32) to P:
+//   X = A11^-1, U = X A12, V = A21 X, S = A22 - A21 U, Y = S^-1,
+//   inv = [ X + U Y V , -U Y ; -Y V , Y ]
+// dA / dB: original diagonal entries of rows i and 16 + i.  T: wave-private 16 x 17 scratch.
+__device__ __forceinline__ bool inv32_wave(double (*M)[GJS32 + 1], double (*T)[GJS_B + 1], double dA, double dB,
+                                           double *__restrict__ P) {
+  const int l = lane_id(), i = l & 15, g = l >> 4;
+  const v4f64 zero = (v4f64){0.0, 0.0, 0.0, 0.0};
+  double x[4], a21[4], a12b[4], a22b[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    x[kk] = M[i][4 * kk + g];              // A layout of A11
+    a21[kk] = M[16 + i][4 * kk + g];       // A layout of A21
+    a12b[kk] = M[g + 4 * kk][16 + i];      // B layout of A12
+    a22b[kk] = M[16 + g + 4 * kk][16 + i]; // accumulator layout of A22
+  }
+  bool ok = inv16a_spd(x, dA);             // X (A layout)
+  double xb[4];
+  lds_transpose16(x, xb, T);               // X (B / accumulator layout)
+  const v4f64 U = mfma4(x, a12b, zero);    // U = X A12
+  const v4f64 V = mfma4(a21, xb, zero);    // V = A21 X
+  double ub[4], vb[4], ua[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    ub[r] = U[r];
+    vb[r] = V[r];
+  }
+  const v4f64 Mu = mfma4(a21, ub, zero);   // A21 U
+  double sb[4], y[4], yb[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) sb[r] = a22b[r] - Mu[r];
+  lds_transpose16(sb, y, T);               // S: accumulator layout -> A layout (same index map)
+  ok = inv16a_spd(y, dB) && ok;            // Y (A layout)
+  lds_transpose16(y, yb, T);               // Y (B layout)
+  lds_transpose16(ub, ua, T);              // U (A layout)
+  const v4f64 N21 = mfma4(y, vb, zero);    // Y V
+  const v4f64 N12 = mfma4(ua, yb, zero);   // U Y
+  double n21b[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) n21b[r] = N21[r];
+  v4f64 I11 = (v4f64){xb[0], xb[1], xb[2], xb[3]};
+  I11 = mfma4(ua, n21b, I11);              // X + U (Y V)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = g + 4 * r;
+    P[row * GJS32 + i] = I11[r];
+    P[row * GJS32 + 16 + i] = -N12[r];
+    P[(16 + row) * GJS32 + i] = -N21[r];
+    P[(16 + row) * GJS32 + 16 + i] = yb[r];
+  }
+  return ok;
+}
+
+// Stashes diag(A) and inverts the first 32 x 32 diagonal block: <<<nmat, 64>>>.
+__global__ __launch_bounds__(64) void gjs32_first_kernel(GjMats m, int n, double *__restrict__ Pinv_all,
+                                                         double *__restrict__ d0_all, double *__restrict__ status) {
+  __shared__ double Mb[GJS32][GJS32 + 1];
+  __shared__ double T[GJS_B][GJS_B + 1];
+  const int mat = blockIdx.x, l = threadIdx.x, i = l & 15;
+  const double *__restrict__ A = m.a[mat];
+  double *__restrict__ d0 = d0_all + (size_t)mat * n;
+  double *__restrict__ Pinv = Pinv_all + (size_t)mat * 2 * GJS32 * GJS32;
+  for (int k = l; k < n; k += 64) d0[k] = A[(size_t)k * n + k];
+  for (int e = l; e < GJS32 * GJS32; e += 64) {  // identity padding beyond the matrix
+    const int r = e >> 5, cc = e & 31;
+    Mb[r][cc] = (r < n && cc < n) ? A[(size_t)r * n + cc] : ((r == cc) ? 1.0 : 0.0);
+  }
+  const double dA = (i < n) ? A[(size_t)i * n + i] : 1.0;
+  const double dB = (16 + i < n) ? A[(size_t)(16 + i) * n + 16 + i] : 1.0;
+  lds_wave_fence();
+  const bool ok = inv32_wave(Mb, T, dA, dB, Pinv);
+  if (!ok && l == 0) status[0] = 3.0;
+}
+
+// One 32-column block step: grid (ceil(n/64), ceil(n/64), nmat), 256 threads.
+__global__ __launch_bounds__(256) void gjs32_step_kernel(GjMats m, int n, int p0, int flip,
+                                                        double *__restrict__ Pinv_all,
+                                                        const double *__restrict__ d0_all,
+                                                        double *__restrict__ status) {
+  constexpr int NB = GJS32;
+  const int mat = blockIdx.z;
+  const double *__restrict__ src = (flip & 1) ? m.w[mat] : m.a[mat];
+  double *__restrict__ dst = (flip & 1) ? m.a[mat] : m.w[mat];
+  const int kstep = p0 / NB;
+  const double *__restrict__ Pin = Pinv_all + ((size_t)mat * 2 + (kstep & 1)) * NB * NB;
+  double *__restrict__ Pout = Pinv_all + ((size_t)mat * 2 + ((kstep + 1) & 1)) * NB * NB;
+  const double *__restrict__ d0 = d0_all + (size_t)mat * n;
+  __shared__ double Pi[NB][NB + 1];
+  __shared__ double Ar[64][NB + 1];
+  __shared__ double Ds[NB][80];
+  __shared__ double Rs[NB][80];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nb = (p0 + NB <= n) ? NB : n - p0;
+#pragma unroll
+  for (int e0 = 0; e0 < NB * NB; e0 += 256) {
+    const int e = e0 + t;
+    Pi[e >> 5][e & 31] = Pin[e];
+  }
+#pragma unroll
+  for (int e0 = 0; e0 < 64 * NB; e0 += 256) {
+    const int e = e0 + t;
+    {  // tile row mi, pivot column cc
+      const int mi = e >> 5, cc = e & 31, row = m0 + mi;
+      Ar[mi][cc] = (row < n && cc < nb) ? src[(size_t)row * n + p0 + cc] : 0.0;
+    }
+    {  // pivot row kr, tile column jc; zero inside the block's own columns
+      const int kr = e >> 6, jc = e & 63, col = n0 + jc;
+      const bool inside = col >= p0 && col < p0 + nb;
+      Rs[kr][jc] = (kr < nb && col < n && !inside) ? src[(size_t)(p0 + kr) * n + col] : 0.0;
+    }
+  }
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        const bool inside = col >= p0 && col < p0 + nb;
+        acc[i][j][r] = (row < n && col < n && !inside) ? src[(size_t)row * n + col] : 0.0;
+      }
+  __syncthreads();
+  {  // D = E - I_J = -(Ar Pi) for the tile's 64 rows on the matrix cores: wave -> 16 rows, both halves of
+     // the 32 pivot columns.  (Scalar FMAs with both operands in LDS cost 2 ds_reads per FMA: 512 reads per
+     // thread at this width, ~4 us of LDS bandwidth per step.)
+    const int mi0 = wave * 16, li = lane & 15, lg = lane >> 4;
+    v4f64 ad[2];
+    ad[0] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    ad[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; kk++) {
+      const double a = Ar[mi0 + li][4 * kk + lg];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const double b = Pi[4 * kk + lg][16 * h + li];
+        ad[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, ad[h], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int mi = mi0 + lg + 4 * r, k = 16 * h + li, row = m0 + mi;
+        const bool inJ = row >= p0 && row < p0 + nb;
+        double v = -ad[h][r];
+        if (inJ) v = Pi[row - p0][k] - ((row - p0 == k) ? 1.0 : 0.0);
+        Ds[k][mi] = (k < nb) ? v : 0.0;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; kk++) {
+    const int kl = kk * 4 + (lane >> 4);
+    double a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) a[i] = Ds[kl][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+    for (int j = 0; j < 2; j++) b[j] = Rs[kl][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  // next diagonal block: rows / columns p1 .. p1 + 31 are exactly one wave's 32 x 32 quarter of a tile
+  const int p1 = p0 + NB;
+  const bool diag_tile = p1 < n && m0 == (p1 / 64) * 64 && n0 == m0;
+  const int dl = p1 - m0;  // 0 or 32
+  const bool owner = diag_tile && dl == wm * 32 && dl == wn * 32;  // wave-uniform
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int lr = wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int row = m0 + lr;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        double v = acc[i][j][r];
+        if (col >= p0 && col < p0 + nb) v = Ds[col - p0][lr] + ((row == col) ? 1.0 : 0.0);  // E = D + I_J
+        if (row < n && col < n) dst[(size_t)row * n + col] = v;
+        // what the owner wave inverts next: identity padding beyond the matrix
+        acc[i][j][r] = (row < n && col < n) ? v : ((row == col) ? 1.0 : 0.0);
+      }
+  if (owner) {  // wave-uniform; Pi / Ar are dead since the barrier after the panel product
+    double(*Mb)[GJS32 + 1] = Pi;
+    double(*T)[GJS_B + 1] = (double(*)[GJS_B + 1]) & Ar[0][0];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Mb[i * 16 + (lane >> 4) + 4 * r][j * 16 + (lane & 15)] = acc[i][j][r];
+    const int i = lane & 15;
+    const double dA = (p1 + i < n) ? d0[p1 + i] : 1.0;
+    const double dB = (p1 + 16 + i < n) ? d0[p1 + 16 + i] : 1.0;
+    lds_wave_fence();
+    const bool ok = inv32_wave(Mb, T, dA, dB, Pout);
+    if (!ok && lane == 0) status[0] = 3.0;
+  }
+}
+
 // column permutation that undoes all recorded interchanges (perm from the panel kernels); one
 // workgroup per (row, matrix).  The row passes through registers, so src == dst is fine.
 __global__ __launch_bounds__(256) void gjp_unscramble_kernel(GjMats m, int n, int from_w,

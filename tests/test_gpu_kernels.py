@@ -220,7 +220,7 @@ def _moment_matrix(rng, n, cond_boost=0.05):
     return X @ X.T / (3 * n) + cond_boost * np.eye(n)
 
 
-@pytest.mark.parametrize("n", [7, 16, 40, 64, 65, 100, 128, 130, 192, 200, 500])
+@pytest.mark.parametrize("n", [7, 16, 31, 32, 33, 40, 48, 64, 65, 100, 128, 130, 192, 200, 500])
 def test_inverse_spd_block_path(engine, n):
     """The M-step's H x H solver on Gram-type (SPD) matrices -- the shape np.linalg.inv is given
     at sssc.py:693,738 and lstsq at bsc.py:237 -- against numpy, two matrices per call."""
@@ -239,6 +239,35 @@ def test_inverse_spd_block_path(engine, n):
     engine.set_option("inverse_spd", 1)
     assert np.abs(Ap - Ai).max() <= 1e-11 * np.abs(Ai).max()
     assert np.abs(Bp - Bi).max() <= 1e-11 * np.abs(Bi).max()
+    # n >= 32 ran with 32-column block steps (32 x 32 pivot block inverted in registers through its Schur
+    # complement); the 16-column steps must agree to rounding
+    engine.set_option("inverse_block", 16)
+    A16, B16, _ = engine.inverse(A, B)
+    engine.set_option("inverse_block", 32)
+    A32, B32, _ = engine.inverse(A, B)
+    engine.set_option("inverse_block", 0)  # default: 32 columns from n = 256 on
+    for Mi2 in (A16, A32):
+        assert np.abs(Mi2 - Ai).max() <= 1e-11 * np.abs(Ai).max()
+    for Mi2 in (B16, B32):
+        assert np.abs(Mi2 - Bi).max() <= 1e-11 * np.abs(Bi).max()
+
+
+@pytest.mark.parametrize("n", [40, 96, 256, 300])
+def test_inverse_block32_nonsymmetric(engine, n):
+    """xpt_szsz is not symmetric once Psi is not (quirk Q2): the 32-column steps invert the 32 x 32 pivot block
+    through its Schur complement WITHOUT assuming symmetry.  Diagonally dominant non-symmetric matrices."""
+    rng = np.random.default_rng(50 + n)
+    engine.configure("bsc", 8, 4, n, 4, 0, 4)
+    A = _moment_matrix(rng, n) + 0.05 * rng.standard_normal((n, n)) / np.sqrt(n)
+    B = _moment_matrix(rng, n, 0.2) + 0.1 * np.triu(rng.standard_normal((n, n))) / np.sqrt(n)
+    engine.set_option("inverse_block", 32)
+    try:
+        Ai, Bi, _ = engine.inverse(A, B)
+    finally:
+        engine.set_option("inverse_block", 0)
+    for M, Mi in ((A, Ai), (B, Bi)):
+        ref = np.linalg.inv(M)
+        assert np.abs(Mi - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("n", [33, 128, 200, 300])

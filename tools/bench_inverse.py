@@ -22,6 +22,10 @@ for n in [int(a) for a in sys.argv[1:]] or [40, 100, 128, 200, 256, 500, 512, 10
     eng.set_option("inverse_spd", 0)
     Ai_p, A2i_p, ms_piv = min((eng.inverse(A, A2) for _ in range(4)), key=lambda r: r[2])
     eng.set_option("inverse_spd", 1)
+    eng.set_option("inverse_block", 16)
+    ms_16 = min((eng.inverse(A, A2) for _ in range(4)), key=lambda r: r[2])[2]
+    eng.set_option("inverse_block", 0)
+    print("n %5d  SPD pair with 16-column steps %8.3f ms" % (n, ms_16))
     print("n %5d  SPD pair: block path %8.3f ms  pivoted %8.3f ms   |AiA-I| %.2e %.2e   spd vs pivoted rel %.2e"
           % (n, ms_spd, ms_piv, np.abs(Ai_s @ A - np.eye(n)).max(), np.abs(A2i_s @ A2 - np.eye(n)).max(),
              np.abs(Ai_s - Ai_p).max() / np.abs(Ai_p).max()), flush=True)
