@@ -728,21 +728,19 @@ __global__ __launch_bounds__(256) void gjs_step_kernel(GjMats m, int n, int p0, 
         acc[i][j][r] = (row < n && col < n && !inside) ? src[(size_t)row * n + col] : 0.0;
       }
   __syncthreads();
-  {  // D = E - I_J for the tile's 64 rows: thread -> row mi, 4 of the 16 columns
-    const int mi = t & 63, k0 = (t >> 6) * 4, row = m0 + mi;
-    const bool inJ = row >= p0 && row < p0 + nb;
+  {  // D = E - I_J = -(Ar Pi) for the tile's 64 rows on the matrix cores: wave -> 16 rows x 16 pivot columns
+     // (as scalar FMAs with both operands in LDS: 128 ds_reads per thread, ~1 us of every step)
+    const int mi0 = wave * 16, li = lane & 15, lg = lane >> 4;
+    v4f64 ad = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const int k = k0 + kk;
-      double v;
-      if (inJ) {
-        v = Pi[row - p0][k] - ((row - p0 == k) ? 1.0 : 0.0);
-      } else {
-        double sacc = 0.0;
+    for (int kk = 0; kk < GJS_B / 4; kk++)
+      ad = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[mi0 + li][4 * kk + lg], Pi[4 * kk + lg][li], ad, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < GJS_B; j++) sacc = fma(Ar[mi][j], Pi[j][k], sacc);
-        v = -sacc;
-      }
+    for (int r = 0; r < 4; r++) {
+      const int mi = mi0 + lg + 4 * r, k = li, row = m0 + mi;
+      const bool inJ = row >= p0 && row < p0 + nb;
+      double v = -ad[r];
+      if (inJ) v = Pi[row - p0][k] - ((row - p0 == k) ? 1.0 : 0.0);
       Ds[k][mi] = (k < nb) ? v : 0.0;
     }
   }
