@@ -72,6 +72,11 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "overlap_gemm" (0 / 1 / 2, default 1): evoamd_mstep_device runs the K = N statistics contraction on a
  * second stream beside the H x H elimination chain (single rank, no kernel timing; neither reads what
  * the other writes): never / for the shapes where it was measured to pay (ES3C, large H) / always.
+ * "inverse_spd" (0/1, default 1): the H x H inverses of the device Theta update by the SPD block
+ * Gauss-Jordan (diagonal blocks as pivots; a bad pivot reports status 3 and the update is repeated with
+ * partial pivoting) / always the partially pivoted elimination.  "reconstruct_in_stats" (one-shot): the
+ * next statistics pass forms y_reconstructed between the moment rows and the Wp contraction
+ * (bsc.py:184-189, sssc.py:630-633).
  * "inverse_block" (0 / 16 / 32, default 0): columns eliminated per launch by the SPD block Gauss-Jordan;
  * 0 = 32 from n = 256 on (32 x 32 pivot block inverted in registers through its Schur complement), else 16.
  * "prefetch_lpj" (0/1, default 1): evoamd_mstep_device enqueues the next iteration's evoamd_lpj_resident

@@ -210,6 +210,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.evoamd_abi_version() == 1
 
 
+def test_every_option_is_documented():
+    """Each name evoamd_set_option accepts (csrc/evo_amd.hip) is described in include/evo_amd.h and listed in
+    INTEGRATION.md -- the options are part of the boundary a maintainer binds."""
+    src = open(os.path.join(ROOT, "evo_amd", "csrc", "evo_amd.hip")).read()
+    body = src[src.index('extern "C" int evoamd_set_option'):]
+    body = body[:body.index("unknown option")]
+    names = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', body))
+    assert {"bsc_direct", "state_digest", "prefetch_lpj", "overlap_gemm", "inverse_block"} <= names
+    header = open(os.path.join(ROOT, "include", "evo_amd.h")).read()
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in sorted(names):
+        assert '"%s"' % n in header, "include/evo_amd.h does not document option " + n
+        assert '"%s"' % n in integ, "INTEGRATION.md does not list option " + n
+
+
 def test_product_path_has_no_cpu_fallback():
     """evo_amd must not import the oracle, and creating an engine without a GPU must raise."""
     import evo_amd
