@@ -19,6 +19,7 @@ MODEL_BSC, MODEL_SSSC = 0, 1
 KERNEL_IDS = {
     "lpj_resident": 0, "lpj_candidates": 1, "lpj_overflow": 2, "row_lse": 3, "vary_kn": 4,
     "stats": 5, "stats_overflow": 6, "gemm_f64": 7, "evolve": 8, "misc": 9, "mstep_device": 10,
+    "lpj_pass": 11, "stats_pass": 12,
 }
 
 _c_dp = ctypes.POINTER(ctypes.c_double)
@@ -40,6 +41,8 @@ SIGNATURES = {
     "evoamd_upload_data": (_I, [_vp, _c_dp]),
     "evoamd_upload_states": (_I, [_vp, _c_u8p]),
     "evoamd_download_states": (_I, [_vp, _c_u8p]),
+    "evoamd_upload_states_packed": (_I, [_vp, _c_u8p, _I64, _I64]),
+    "evoamd_download_states_packed": (_I, [_vp, _c_u8p, _I64, _I64]),
     "evoamd_upload_lpj": (_I, [_vp, _c_dp]),
     "evoamd_download_lpj": (_I, [_vp, _c_dp]),
     "evoamd_set_params_bsc": (_I, [_vp, _c_dp, _DBL, _DBL, _c_dp]),

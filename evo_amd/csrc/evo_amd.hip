@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,8 @@ enum {  // internal kernel ids (see evoamd_kernel_name)
   KID_EVOLVE,
   KID_MISC,
   KID_MSTEP,
+  KID_LPJ_PASS,    // the whole pass over the resident K^n: main kernel + every overflow level it spawns
+  KID_STATS_PASS,  // the whole statistics pass: scatter kernels + overflow levels + column sums + finish (no GEMM)
   KID_COUNT
 };
 
@@ -133,6 +136,11 @@ struct evoamd_ctx {
   double res_cnt[3] = {0, 0, 0};  // how many resident states exceeded 2 / 4 / 8 active latents
   bool cand_from_device = false;  // resident candidate batch came from evolve_randflip (k <= k_parent + 1)
   bool lists_clean = false;       // overflow counters are zero (a previous kernel cleared them)
+  int pending_skip = 0;           // overflow levels the last lpj chain(s) did not launch: the kernel that clears the
+                                  // list counters next checks that their lists stayed empty (err |= 4 otherwise)
+  bool conservative_levels = false;  // the pass being enqueued runs before the host has seen the counts of the
+                                     // K^n it evaluates (prefetched pass): choose its levels like a candidate batch
+  int pays_agreed = -1;           // split all-reduce: -1 not yet agreed over the ranks, else the common decision
   int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
                      // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
@@ -525,9 +533,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   ALLOC(c->partial, (size_t)3 * c->n_partial);
   ALLOC(c->partial2, (size_t)c->n_partial);
   ALLOC(c->diag, (size_t)H);
-  const int SC = S > Cmax ? S : Cmax;
-  c->stage_bytes = (size_t)N * SC * H;
-  ALLOC(c->stage, c->stage_bytes);
+  const int SC = S > Cmax ? S : Cmax;  // the bool staging area (N x SC x H bytes at most) grows on demand: ensure_stage
   ALLOC(c->W, (size_t)D * H);
   ALLOC(c->tmpA, (size_t)H * H);
   ALLOC(c->tmpB, (size_t)H * H);
@@ -591,6 +597,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->configured = true;
+  c->pays_agreed = -1;
+  c->pending_skip = 0;
   c->gen++;
   c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
   if (c->tmpWt) (void)hipFree(c->tmpWt);  // sized by (H, D): rebuilt on demand
@@ -667,9 +675,14 @@ extern "C" int evoamd_upload_yrec(evoamd_ctx *c, const double *y_rec) {
   return 0;
 }
 
+static int ensure_stage(evoamd_ctx *c, size_t bytes);
+
 static int pack_to_device(evoamd_ctx *c, const uint8_t *host_bool, i64 nstates, u64 *dst) {
   const size_t bytes = (size_t)nstates * c->H;
-  if (bytes > c->stage_bytes) return fail(EVOAMD_E_INVALID, "state batch larger than staging buffer");
+  {
+    int rs = ensure_stage(c, bytes);
+    if (rs) return rs;
+  }
   HIP_TRY(hipMemcpyAsync(c->stage, host_bool, bytes, hipMemcpyHostToDevice, c->stream));
   pack_states_kernel<<<cdiv(nstates * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, nstates, c->H, c->HW);
   if (dst == c->states) c->gen++;
@@ -695,9 +708,55 @@ extern "C" int evoamd_download_states(evoamd_ctx *c, uint8_t *ss_bool) {
   REQUIRE(ss_bool, "ss is NULL");
   HIP_TRY(hipSetDevice(c->device));
   const i64 ns = c->N * (i64)c->S;
+  {
+    int rs = ensure_stage(c, (size_t)ns * c->H);
+    if (rs) return rs;
+  }
   unpack_states_kernel<<<cdiv(ns * c->H, 256), 256, 0, c->stream>>>(c->states, c->stage, ns, c->H, c->HW);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ss_bool, c->stage, (size_t)ns * c->H, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// K^n rows [n0, n0 + n) as np.packbits makes them: (n, S, ceil(H/8)) bytes, latent h in byte h/8 at bit 7-(h%8).
+extern "C" int evoamd_upload_states_packed(evoamd_ctx *c, const uint8_t *packed, int64_t n0, int64_t n) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(packed && n0 >= 0 && n > 0 && n0 + n <= c->N, "bad row range");
+  HIP_TRY(hipSetDevice(c->device));
+  const int PB = (c->H + 7) / 8;
+  const i64 ns = n * (i64)c->S;
+  const size_t bytes = (size_t)ns * PB;
+  {
+    int rs = ensure_stage(c, bytes);
+    if (rs) return rs;
+  }
+  HIP_TRY(hipMemcpyAsync(c->stage, packed, bytes, hipMemcpyHostToDevice, c->stream));
+  u64 *dst = c->states + (size_t)n0 * c->S * c->HW;
+  words_from_packbits_kernel<<<cdiv(ns * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, ns, PB, c->HW);
+  if (c->dig) digest_kernel<<<cdiv(ns, 256), 256, 0, c->stream>>>(dst, c->dig + (size_t)n0 * c->S, ns, c->HW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->gen++;
+  c->need_known = false;
+  return 0;
+}
+
+extern "C" int evoamd_download_states_packed(evoamd_ctx *c, uint8_t *packed, int64_t n0, int64_t n) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(packed && n0 >= 0 && n > 0 && n0 + n <= c->N, "bad row range");
+  HIP_TRY(hipSetDevice(c->device));
+  const int PB = (c->H + 7) / 8;
+  const i64 ns = n * (i64)c->S;
+  const size_t bytes = (size_t)ns * PB;
+  {
+    int rs = ensure_stage(c, bytes);
+    if (rs) return rs;
+  }
+  packbits_from_words_kernel<<<cdiv(ns * PB, 256), 256, 0, c->stream>>>(c->states + (size_t)n0 * c->S * c->HW, c->stage, ns,
+                                                                         PB, c->HW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(packed, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1090,6 +1149,7 @@ static unsigned list_grid(i64 total, unsigned cap) {
 static unsigned level_grid(const evoamd_ctx *c, int level, int tag, i64 total, unsigned cap, unsigned per_block) {
   unsigned g = list_grid(total, cap);
   if (!c->need_known || tag == 2) return g;
+  if (tag == 0 && c->conservative_levels) tag = 1;  // counts describe the previous K^n: size it like its children
   // candidates / final K^n can exceed a level if a resident state exceeds the level below
   const int src = (tag == 0) ? level : (level > 0 ? level - 1 : 0);
   double expect = c->res_cnt[src] * ((tag == 0) ? 1.0 : 1.0 + (double)c->Cmax / (double)c->S);
@@ -1104,16 +1164,25 @@ static unsigned level_grid(const evoamd_ctx *c, int level, int tag, i64 total, u
 static bool use_k8_kernel(const evoamd_ctx *c, int tag) {
   if (c->k8_mode >= 0) return c->k8_mode != 0;
   if (!c->need_known || tag == 2) return true;
+  if (tag == 0 && c->conservative_levels) tag = 1;
   const double expect = c->res_cnt[tag == 0 ? 1 : 0] * (tag == 0 ? 1.0 : (double)c->Cmax / (double)c->S) +
                         (tag == 0 ? 0.0 : c->res_cnt[1]);
   return expect > 8192.0;
 }
 
 static int zero_lists(evoamd_ctx *c) {
-  if (!c->lists_clean) HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+  if (!c->lists_clean) {
+    if (c->pending_skip)  // no clearing kernel ran since the last chain: check its skipped levels here
+      check_lists_kernel<<<1, 256, 0, c->stream>>>(c->list_n, 4 * LIST_SHARDS, c->pending_skip, c->err);
+    else
+      HIP_TRY(hipMemsetAsync(c->list_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+    c->pending_skip = 0;
+  }
   c->lists_clean = false;  // the chain about to be launched appends to them
   return 0;
 }
+
+static int skip_mask(const bool need[3]) { return (need[0] ? 0 : 1) | (need[1] ? 0 : 2) | (need[2] ? 0 : 4); }
 
 #define MAIN_LPJ_LDS_MAX (48 * 1024)  // three 512-thread workgroups (3072 pairs) per CU at the limit
 
@@ -1141,6 +1210,7 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
   const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                 o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
   const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
+  c->pending_skip |= skip_mask(need);
   {
     SpanGuard g(c, kid_main);
     // 512-thread workgroups: measured 13.8-17.5 us without overflow and 20.0 us at 8 % overflow on
@@ -1191,11 +1261,13 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
 static void levels_for(const evoamd_ctx *c, int tag, bool need[3]) {
   need[0] = need[1] = need[2] = true;
   if (!c->need_known) return;
-  if (tag == 0) {
+  if (tag == 0 && !c->conservative_levels) {
     need[0] = c->res_need[0];
     need[1] = c->res_need[1];
     need[2] = c->res_need[2];
-  } else if (tag == 1 && c->cand_from_device) {
+  } else if (tag == 0 || (tag == 1 && c->cand_from_device)) {
+    // K^n(k) = K^n(k-1) + one-bit children (and a prefetched pass only knows the counts of K^n(k-1)): a state
+    // can exceed a level only if some state the counts describe exceeded the level below
     need[0] = true;
     need[1] = c->res_need[0];
     need[2] = c->res_need[1];
@@ -1251,6 +1323,7 @@ static int lpj_resident_launch(evoamd_ctx *c, double *out) {
   }
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, out, c->L, c->S_perm, c->flags, KID_LPJ_RES, 0};
   b.mask = c->mask_infr;
+  SpanGuard pass(c, KID_LPJ_PASS);  // main kernel + every overflow level: everything that produces the N x S lpj
   return launch_lpj(c, b);  // stream-ordered; device-side errors surface at the next host-returning call
 }
 
@@ -1435,7 +1508,8 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
                                                                  c->cand_counts, c->N, c->S, c->S_perm, c->HW,   \
                                                                  c->Cmax, Mprime, c->rowmax,                      \
                                                                  c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS, \
-                                                                 c->dig, c->cand_dig, (c->use_digest && c->dig) ? 1 : 0)
+                                                                 c->dig, c->cand_dig, (c->use_digest && c->dig) ? 1 : 0, \
+                                                                 c->pending_skip, c->err)
     const bool c1 = c->Cmax <= 64;
     if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
     else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }
@@ -1447,6 +1521,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
     HIP_TRY(hipGetLastError());
     c->rows_fresh = true;
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;  // vary_kn zeroed the overflow counters
+    if (c->lists_clean) c->pending_skip = 0;          // ... and checked the skipped levels of the chain before it
   }
   if (sums_out) {
     HIP_TRY(hipMemcpyAsync(sums_out, c->dpar + DP_ECNT0, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1477,7 +1552,7 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
                                                                     c->HW, n_parents, n_children, c->Cmax, seed,  \
                                                                     fit_parents, c->cand, c->cand_counts, c->list_n,   \
                                                                     c->model == EVOAMD_MODEL_SSSC ? 4 * LIST_SHARDS : 0, \
-                                                                    c->cand_dig)
+                                                                    c->cand_dig, c->pending_skip, c->err)
     if (c->S <= 64) EV_LAUNCH(1);
     else if (c->S <= 128) EV_LAUNCH(2);
     else if (c->S <= 256) EV_LAUNCH(4);
@@ -1486,6 +1561,7 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
 #undef EV_LAUNCH
     HIP_TRY(hipGetLastError());
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
+    if (c->lists_clean) c->pending_skip = 0;
     c->cand_from_device = true;
   }
   int r = eval_candidates(c);
@@ -1544,7 +1620,18 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // measured (tools/ab.sh, MI355X): ES3C H = 512 gains 3-4 % of the iteration (N = 12.5k and 100k); ES3C
   // H = 128 and EBSC (H = 256, 1024) lose ~1 %: their contraction fills every CU with long split-K
   // workgroups, the chain's small kernels wait for slots, and the fork/join events cost ~10 us
-  const bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
+  bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
+  if (c->comm && c->model == EVOAMD_MODEL_SSSC) {
+    // np.array_split shards differ by one row, so a shard size next to the threshold would make some ranks
+    // issue three all-reduces and others one: agree once per geometry (max over ranks), same call on every rank
+    if (c->pays_agreed < 0) {
+      double v = pays ? 1.0 : 0.0;
+      int ra = evoamd_comm_allreduce_host(c, &v, 1, 1);
+      if (ra) return ra;
+      c->pays_agreed = v > 0.0 ? 1 : 0;
+    }
+    pays = c->pays_agreed == 1;
+  }
   fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) &&
               (!c->comm || c->model == EVOAMD_MODEL_SSSC) && !gemm_timed && !c->mask_infr;
   {
@@ -1580,6 +1667,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const i64 rpb = std::max<i64>(256, cdiv(N, 128));
   const int nblk = (int)cdiv(N, rpb);
   int skipped = 0;
+  // the whole statistics pass (everything that reads K^n + lpj and leaves the M-step sums, the GEMM aside)
+  std::unique_ptr<SpanGuard> pass(new SpanGuard(c, KID_STATS_PASS));
   if (c->model == EVOAMD_MODEL_BSC) {
     {
       SpanGuard g(c, KID_STATS);
@@ -1607,6 +1696,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                                                        c->partial2, cdiv(N, 4), c->acc + a.sigma);
       HIP_TRY(hipGetLastError());
     }
+    pass.reset();
     const double *Ywp = c->Y;
     int ldwp = c->ldY;
     if (c->mask_infr) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211)
@@ -1704,11 +1794,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
       // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
       // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
-      for (int j = 0; j < 3; j++)
-        if (!need[j]) {
-          skipped |= 1 << j;
-          break;
-        }
+      skipped = skip_mask(need);
     }
     {
       SpanGuard g(c, KID_MISC);
@@ -1722,6 +1808,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                                                  masked ? nullptr : c->PT);
       HIP_TRY(hipGetLastError());
     }
+    pass.reset();
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
     // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
     if (masked) {
@@ -1754,6 +1841,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                           c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped);
     HIP_TRY(hipGetLastError());
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
+    if (c->lists_clean) c->pending_skip = 0;
     if (c->model == EVOAMD_MODEL_SSSC && c->mask_infr) {  // tail[7] = sum over reliable entries of y_hat^2
       masked_sqsum_kernel<<<256, 256, 0, c->stream>>>(c->yhat, c->mask_infr, N * (i64)D, c->acc + a.tail + 7);
       HIP_TRY(hipGetLastError());
@@ -2049,8 +2137,13 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   }
   if (prefetch && c->prefetch_lpj && !c->mask_infr) {
     // behind the mailbox kernel in stream order: the host is released as soon as that kernel is done
+    // the host has not read this iteration's overflow counts yet (they arrive with the mailbox being polled
+    // below), so res_need / res_cnt still describe the K^n of the PREVIOUS iteration: conservative levels
     c->prefetch_gen = ~0ull;
-    if (lpj_resident_launch(c, c->lpj_alt) == 0) c->prefetch_gen = c->gen;
+    c->conservative_levels = true;
+    const int rp = lpj_resident_launch(c, c->lpj_alt);
+    c->conservative_levels = false;
+    if (rp == 0) c->prefetch_gen = c->gen;
   }
   volatile unsigned long long *flag = (volatile unsigned long long *)c->h_theta;
   const auto t0 = std::chrono::steady_clock::now();
@@ -2123,6 +2216,12 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   c->h_theta_fresh = learn_mask != 0 && c->h_dpar[DP_STATUS] == 0.0;
   if (c->h_dpar[DP_STATUS] != 0.0) {
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
+    // the refresh and the prefetched pass behind the mailbox ran with the failed update's Theta: drop the pass and
+    // the clamp flags it may have raised (the caller re-installs a Theta before anything else is evaluated)
+    c->prefetch_gen = ~0ull;
+    c->have_params = false;
+    HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * c->N * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->err, 0, 2 * sizeof(int), c->stream));
     return fail(EVOAMD_E_SINGULAR, "device Theta update: %s",
                 c->h_dpar[DP_STATUS] == 1.0 ? "singular H x H system (the reference falls back to pinv / lstsq here)"
                                             : "non-finite sigma / pi");
@@ -2284,6 +2383,7 @@ extern "C" int evoamd_comm_init(evoamd_ctx *c, const uint8_t id_in[128], int ran
   RcclId id;
   memcpy(id.internal, id_in, 128);
   RCCL_TRY(g_rccl.CommInitRank(&c->comm, world, id, rank));
+  c->pays_agreed = -1;
   c->rank = rank;
   c->world = world;
   return 0;
@@ -2355,6 +2455,7 @@ extern "C" int evoamd_kernel_time_ms(evoamd_ctx *c, int kid, double *avg_ms, int
 
 extern "C" const char *evoamd_kernel_name(int kid) {
   static const char *names[KID_COUNT] = {"lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse",  "vary_kn",
-                                         "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc", "mstep_device"};
+                                         "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc", "mstep_device",
+                                         "lpj_pass",     "stats_pass"};
   return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }

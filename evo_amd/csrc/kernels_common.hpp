@@ -4,6 +4,46 @@
 #include "common.hpp"
 #include "kernels_mstep.hpp"
 
+// Zeroes the overflow-list counters for the chain that follows (block 0 of the calling kernel) and,
+// on the way, verifies the chain that just ended: a level the host did not launch (bit j of
+// skipped_mask = level j, which consumes list j) must have found its list empty, else err[0] |= 4.
+__device__ __forceinline__ void clear_lists_checked(int *__restrict__ list_n, int n_list, int skipped_mask,
+                                                    int *__restrict__ err) {
+  const int per = n_list / 4;
+  for (int i = threadIdx.x; i < n_list; i += blockDim.x) {
+    if (skipped_mask && list_n[i] != 0 && ((skipped_mask >> (i / per)) & 1)) atomicOr(err, 4);
+    list_n[i] = 0;
+  }
+}
+
+// the same check on its own (paths where a memset clears the counters)
+__global__ void check_lists_kernel(int *__restrict__ list_n, int n_list, int skipped_mask, int *__restrict__ err) {
+  clear_lists_checked(list_n, n_list, skipped_mask, err);
+}
+
+// np.packbits rows (nstates, PB = ceil(H/8) bytes, latent h in byte h/8 at bit 7-(h%8)) <-> device words.
+__global__ __launch_bounds__(256) void words_from_packbits_kernel(const uint8_t *__restrict__ in, u64 *__restrict__ out,
+                                                                  i64 nstates, int PB, int HW) {
+  const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nstates * HW) return;
+  const i64 st = idx / HW;
+  const int w = (int)(idx - st * HW);
+  const uint8_t *p = in + st * PB + w * 8;
+  int nb = PB - w * 8;
+  if (nb > 8) nb = 8;
+  u64 v = 0;
+  for (int b = 0; b < nb; b++) v |= (u64)p[b] << (56 - 8 * b);
+  out[idx] = v;
+}
+__global__ __launch_bounds__(256) void packbits_from_words_kernel(const u64 *__restrict__ in, uint8_t *__restrict__ out,
+                                                                  i64 nstates, int PB, int HW) {
+  const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nstates * PB) return;
+  const i64 st = idx / PB;
+  const int b = (int)(idx - st * PB);
+  out[idx] = (uint8_t)(in[st * HW + (b >> 3)] >> (56 - 8 * (b & 7)));
+}
+
 // bool (nstates, H) -> packed (nstates, HW); one thread per output word.
 __global__ __launch_bounds__(256) void pack_states_kernel(const uint8_t *__restrict__ in,
                                                           u64 *__restrict__ out, i64 nstates, int H,
@@ -328,10 +368,10 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
                                                       double *__restrict__ rowsum, double *__restrict__ fpartial,
                                                       int *__restrict__ list_n, int n_list,
                                                       u64 *__restrict__ dig, const u64 *__restrict__ cand_dig,
-                                                      int dig_dedup) {
+                                                      int dig_dedup, int skipped_mask, int *__restrict__ err) {
   __shared__ int blk_uniq[4], blk_sub[4];
   if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
-    for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
+    clear_lists_checked(list_n, n_list, skipped_mask, err);
   __shared__ double wsum[4];
   __shared__ double new_v[4][64 * CPL], old_v[4][64 * CPL];
   __shared__ int new_i[4][64 * CPL], old_i[4][64 * CPL];

@@ -15,6 +15,7 @@
 // selection kernel (vary_kn_kernel) applies the reference's de-duplication rules.
 #pragma once
 #include "common.hpp"
+#include "kernels_common.hpp"
 
 __device__ __forceinline__ u64 mix64(u64 x) {
   x ^= x >> 30;
@@ -38,10 +39,11 @@ template <int SPL>
 __global__ __launch_bounds__(256) void evolve_randflip_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, i64 N, int S, int S_perm, int H, int HW,
     int n_parents, int n_children, int Cmax, u64 seed, int fit_parents, u64 *__restrict__ cand,
-    int *__restrict__ counts, int *__restrict__ list_n, int n_list, u64 *__restrict__ cand_dig) {
+    int *__restrict__ counts, int *__restrict__ list_n, int n_list, u64 *__restrict__ cand_dig, int skipped_mask,
+    int *__restrict__ err) {
   __shared__ int sel_sh[4][64];
   if (blockIdx.x == 0 && list_n)  // the candidate lpj chain that follows appends to fresh overflow lists
-    for (int i = threadIdx.x; i < n_list; i += 256) list_n[i] = 0;
+    clear_lists_checked(list_n, n_list, skipped_mask, err);
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;
   if (n >= N) return;

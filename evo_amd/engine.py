@@ -11,7 +11,17 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import MODEL_BSC, MODEL_SSSC, as_bool_bytes, as_f64, check, dptr, i32ptr, u8ptr
+from ._lib import MODEL_BSC, MODEL_SSSC, EvoAmdError, as_bool_bytes, as_f64, check, dptr, i32ptr, u8ptr
+
+
+class SingularUpdate(EvoAmdError):
+    """evoamd_mstep_device: the H x H system of the Theta update is exactly singular.  The E-step results
+    of the same call are valid and ride along (``tail``, ``dpar``) so that the caller can finish the step
+    with the reference's host formulas (lstsq / pinv fallbacks, bsc.py:236-250, sssc.py:692-708)."""
+
+    def __init__(self, msg, tail, dpar):
+        EvoAmdError.__init__(self, msg)
+        self.tail, self.dpar = tail, dpar
 
 
 def default_device():
@@ -77,6 +87,18 @@ class Engine:
             out = np.empty((self.N, self.S, self.H), dtype=np.bool_)
         assert out.shape == (self.N, self.S, self.H) and out.dtype == np.bool_ and out.flags.c_contiguous
         check(self.lib.evoamd_download_states(self._h, u8ptr(out.view(np.uint8))))
+        return out
+
+    def upload_states_packed(self, packed, n0=0):
+        """K^n rows [n0, n0 + n) as np.packbits(ss, axis=-1) lays them out: uint8 (n, S, ceil(H/8))."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        assert packed.ndim == 3 and packed.shape[1:] == (self.S, (self.H + 7) // 8), packed.shape
+        check(self.lib.evoamd_upload_states_packed(self._h, u8ptr(packed), int(n0), packed.shape[0]))
+
+    def download_states_packed(self, n0=0, n=None):
+        n = self.N - n0 if n is None else int(n)
+        out = np.empty((n, self.S, (self.H + 7) // 8), dtype=np.uint8)
+        check(self.lib.evoamd_download_states_packed(self._h, u8ptr(out), int(n0), n))
         return out
 
     def upload_lpj(self, lpj):
@@ -207,10 +229,13 @@ class Engine:
             mask |= self.LEARN_BITS[name]
         tail = np.zeros(8)
         dpar = np.zeros(16)
-        check(self.lib.evoamd_mstep_device(self._h, mask, dptr(tail), dptr(dpar)))
+        rc = self.lib.evoamd_mstep_device(self._h, mask, dptr(tail), dptr(dpar))
         d = {k: dpar[i] for k, i in self.DPAR.items()}
         # ljc of the Theta the E-step ran with: the update kernels move it to ljc_prev
         d["ljc_estep"] = d["ljc_prev"] if mask else d["ljc"]
+        if rc == -6 and d["status"] == 1.0:  # EVOAMD_E_SINGULAR from the Theta update (tail / dpar were delivered)
+            raise SingularUpdate(self.lib.evoamd_last_error().decode(), dict(zip(TAIL, tail)), d)
+        check(rc)
         return dict(zip(TAIL, tail)), d
 
     def inverse(self, A, B=None):

@@ -102,6 +102,10 @@ class Model:
         self.eps_lpj = F64_MIN
         self._engine = engine
         self._device = device
+        # Device residency of my_data["y"], the masks and y_reconstructed is keyed on the array OBJECTS: the
+        # model keeps a reference to what it uploaded and compares with `is`, so a new array of the same shape
+        # (a fresh minibatch / epoch) is always uploaded, whatever address CPython recycles.  In-place edits of
+        # an uploaded array are not seen: call invalidate() after them.
         self._y_token = None
         self._x_infr_token = None
         self._incomplete = False
@@ -125,12 +129,35 @@ class Model:
             eas.cross, eas.cross_randflip, eas.cross_sparseflip) else n_par * n_child
         return max(1, per_gen * my_suff_stat["n_generations"])
 
+    def invalidate(self):
+        """Forget what is resident on the device: the next call uploads my_data["y"], the masks,
+        y_reconstructed and K^n again.  Needed after IN-PLACE edits of those arrays (the reference re-reads
+        my_data every step; here an unchanged array object is taken to hold unchanged data)."""
+        self._y_token = self._x_infr_token = self._yrec_token = None
+        self._resident = False
+        self._dev_theta = None
+
+    @staticmethod
+    def _same_objects(token, *objs):
+        return token is not None and len(token) == len(objs) and all(a is b for a, b in zip(token, objs))
+
+    def attach_resident_states(self, my_suff_stat, my_data, packed_chunks):
+        """Hand K^n over bit-packed and in chunks instead of as my_suff_stat["ss"] (bool (N,S,H): 10 GB at the
+        north-star shape N=100k, S=200, H=512).  ``packed_chunks`` yields (n0, uint8 (n, S, ceil(H/8))) in
+        np.packbits layout.  K^n is then device-resident (sync_host=False); my_suff_stat["ss"] is not read."""
+        if self.sync_host:
+            raise ValueError("attach_resident_states needs sync_host=False")
+        eng = self._prepare(my_suff_stat, my_data, upload_states=False)
+        for n0, chunk in packed_chunks:
+            eng.upload_states_packed(chunk, n0)
+        self._resident = True
+
     def _prepare(self, my_suff_stat, my_data, upload_states=True):
         """Configure the engine for this rank's shard and make Y / K^n resident."""
         Y = my_data["y"]
         xi = my_data["x_infr"]
-        xi_token = (id(xi), xi.shape, id(my_data.get("x")))
-        new_masks = self._x_infr_token != xi_token
+        xi_objs = (xi, my_data.get("x"))
+        new_masks = not self._same_objects(self._x_infr_token, *xi_objs)
         if new_masks:  # checked once per array object, like the Y upload below
             self._incomplete = not xi.all()
         N, D = Y.shape
@@ -144,10 +171,9 @@ class Model:
             eng.configure(self.model_name, N, D, self.H, self.S, S_perm, cmax)
             self._y_token = None
             self._resident = False
-        token = (id(Y), Y.shape)
-        if self._y_token != token:
+        if not self._same_objects(self._y_token, Y):
             eng.upload_data(Y)
-            self._y_token = token
+            self._y_token = (Y,)
             new_masks = True
         if new_masks:
             if self._incomplete:
@@ -157,12 +183,12 @@ class Model:
                 eng.upload_masks(None)
                 eng.upload_data(Y)
             self._had_masks = self._incomplete
-            self._x_infr_token = xi_token
+            self._x_infr_token = xi_objs
         if self._incomplete and "y_reconstructed" in my_data:
             yr = my_data["y_reconstructed"]
-            if self._yrec_token != id(yr):  # an older reconstruction the M-step should read (bsc.py:186)
+            if not self._same_objects(self._yrec_token, yr):  # an older reconstruction the M-step should read (bsc.py:186)
                 eng.upload_yrec(np.where(np.isnan(yr), 0.0, yr))
-                self._yrec_token = id(yr)
+                self._yrec_token = (yr,)
         if upload_states and (self.sync_host or not self._resident):
             eng.upload_states(my_suff_stat["ss"])
             self._resident = True
@@ -261,11 +287,14 @@ class Model:
         if self._incomplete and do_reconstruction:
             # y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211): formed inside the statistics pass
             eng.set_option("reconstruct_in_stats", 1)
-        tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction)
+        try:
+            tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction)
+        except _engine.SingularUpdate as e:
+            return self._step_device_singular(model_params, my_suff_stat, my_data, do_reconstruction, e.tail, e.dpar)
         if do_reconstruction:
             self._write_reconstruction(my_data)
             if self._incomplete:
-                self._yrec_token = id(my_data["y_reconstructed"])  # the device already holds it
+                self._yrec_token = (my_data["y_reconstructed"],)  # the device already holds it
         if self.sync_host:
             self.sync_to_host(my_suff_stat)
         my_suff_stat["reset_lpj_isnan"] = int(tail["reset_isnan"])
@@ -275,6 +304,37 @@ class Model:
         self._dev_theta = model_params
         N = tail["N"]
         return dpar["ljc_estep"] + tail["Fs"] / N, tail["sum_nunique"] / N, tail["sum_sub"] / N, model_params
+
+    def _step_device_singular(self, model_params, my_suff_stat, my_data, do_reconstruction, tail, dpar):
+        """The device Theta update met an exactly singular H x H system (a latent that never occurs in any
+        K^n, N < H ...).  The reference absorbs that case (lstsq / pinv + noise, bsc.py:236-250,
+        sssc.py:692-708); so does this path: the E-step results of the failed call stand (``tail``: F term,
+        counters); the Theta the E-step ran with -- the host still holds it in ``model_params`` -- goes back
+        to the device (the failed update overwrote it), the statistics are summed again from the unchanged
+        K^n / lpj, and the reference's host formulas, fallbacks and np.random draws included, give Theta^new."""
+        eng = self.engine
+        self.E_step_precompute(model_params, my_suff_stat, my_data)
+        if self._incomplete and do_reconstruction:
+            eng.set_option("reconstruct_in_stats", 1)
+        acc = eng.stats()
+        v = dict(eng.acc_views(acc))
+        for k in ("Fs", "sum_nunique", "sum_sub", "N", "reset_isnan", "reset_smaller_eps", "reset_isinf"):
+            v[k] = tail[k]  # set_params cleared the device-side E-step scalars; the failed call delivered them
+        if do_reconstruction:
+            self._write_reconstruction(my_data)
+            if self._incomplete:
+                self._yrec_token = (my_data["y_reconstructed"],)
+        if self.sync_host:
+            self.sync_to_host(my_suff_stat)
+        my_suff_stat["reset_lpj_isnan"] = int(v["reset_isnan"])
+        my_suff_stat["reset_lpj_smaller_eps_lpj"] = int(v["reset_smaller_eps"])
+        my_suff_stat["reset_lpj_isinf"] = int(v["reset_isinf"])
+        N = float(v["N"])
+        F = dpar["ljc_estep"] + float(v["Fs"]) / N
+        with small_blas(self.H):
+            model_params = self.update_params(model_params, v, N)
+        self._dev_theta = None  # the next step clamps, precomputes and uploads this host Theta
+        return F, float(v["sum_nunique"]) / N, float(v["sum_sub"]) / N, model_params
 
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """One EM iteration (_models.py:161-203): check_params -> E_step -> M_step."""
@@ -442,7 +502,7 @@ class Model:
         acc = eng.stats()
         if self._incomplete and _reconstruct:
             self._write_reconstruction(my_data)
-            self._yrec_token = id(my_data["y_reconstructed"])  # the device already holds it
+            self._yrec_token = (my_data["y_reconstructed"],)  # the device already holds it
         if not getattr(self.comm, "device_reduces", False):
             acc = _reduce_array(self.comm, acc)
         v = eng.acc_views(acc)
@@ -452,6 +512,7 @@ class Model:
         my_suff_stat["reset_lpj_smaller_eps_lpj"] = int(v["reset_smaller_eps"])
         my_suff_stat["reset_lpj_isinf"] = int(v["reset_isinf"])
         self._acc = acc if _keep_acc else None
+        self.last_acc = acc  # the globally summed packed accumulator of this E-step (engine.acc_views names its blocks)
         N = float(v["N"])
         F = model_params["ljc"] + float(v["Fs"]) / N
         return F, float(v["sum_nunique"]) / N, float(v["sum_sub"]) / N
@@ -509,7 +570,22 @@ class Model:
         return model_params["ljc"] + self.comm.allreduce(Fs) / N
 
     def reconstruct(self, my_data, my_suff_stat, model_params):
-        raise NotImplementedError("reconstruct() is outside the accelerated path (SURVEY 8f rank 3)")
+        """(Re-)estimate the entries with my_data["x"] False from the posterior predictive distribution under
+        ``model_params`` and the caller's K^n / lpj; adds my_data["y_reconstructed"] (_models.py:614-665).
+        The reference loops over datapoints calling modelmean(); here the statistics pass writes E_q[s]
+        (EBSC) / E_q[s o z] (ES3C) per datapoint and ONE f64 MFMA product with W^T gives every estimate."""
+        eng = self._prepare(my_suff_stat, my_data)
+        self.E_step_precompute(model_params, my_suff_stat, my_data)
+        if self.sync_host or not self._resident:
+            eng.upload_lpj(my_suff_stat["lpj"])
+        if self._incomplete:
+            eng.set_option("reconstruct_in_stats", 1)
+        eng.stats()
+        self._write_reconstruction(my_data)
+        if self._incomplete:
+            self._yrec_token = (my_data["y_reconstructed"],)
 
     def modelmean(self, model_params, this_data, this_suff_stat):
-        raise NotImplementedError("modelmean() is outside the accelerated path (SURVEY 8f rank 3)")
+        """Per-datapoint operator of the reference's reconstruct loop: (D_miss, S) means of the entries to be
+        reconstructed, one column per state of this_suff_stat["ss"] (bsc.py:279-287, sssc.py:368-405)."""
+        raise NotImplementedError

@@ -63,6 +63,12 @@ class BSC(Model):
     def _allzero_lpj(self, model_params, yy):
         return model_params["pre1"] * yy  # bsc.py:72
 
+    def modelmean(self, model_params, this_data, this_suff_stat):
+        """(D_miss, S): W[~x, :] s for every state s of the datapoint (bsc.py:279-287).  Per-datapoint operator
+        of the reference's reconstruct loop; Model.reconstruct computes all datapoints in one GPU pass."""
+        miss = np.logical_not(this_data["x"])
+        return np.dot(this_suff_stat["ss"], model_params["W"].T[:, miss]).T
+
     # ---- M-step ------------------------------------------------------------------------------
     def update_params(self, model_params, sums, N):
         """Theta^new from the globally summed statistics (bsc.py:226-277).  ``sums`` holds Wp (H,D),

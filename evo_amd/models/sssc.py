@@ -131,6 +131,28 @@ class SSSC(Model):
     def _allzero_lpj(self, model_params, yy):
         return -0.5 * yy * model_params["sigma2_inv"]  # sssc.py:237
 
+    def modelmean(self, model_params, this_data, this_suff_stat):
+        """(D_miss, S): W[~x, :] (s o kappa_s) for every state s of the datapoint (sssc.py:368-405), with
+        kappa_s = Lam_s W_s^T (y_obs - W_s mu_s) / sigma2 + mu_s, Lam_s = (W_s^T W_s / sigma2 + Psi_s^-1)^-1
+        over the reliable entries (sssc.py:276-300,574-575).  The reference reads these terms from the
+        `storage` its log_pseudo_joint filled; here they are formed directly (host NumPy, S small k x k
+        systems): this is the per-datapoint operator, Model.reconstruct does all datapoints in one GPU pass."""
+        W, mus, Psi = model_params["W"], model_params["mus"], model_params["Psi"]
+        s2 = float(model_params["sigma2"])
+        obs = this_data["x_infr"]
+        y_obs = this_data["y"][obs]
+        ss = this_suff_stat["ss"]
+        sz = np.zeros((self.H, ss.shape[0]))
+        W_obs = W[obs]
+        for s in range(ss.shape[0]):
+            on = ss[s]
+            if not on.any():
+                continue
+            Ws = W_obs[:, on]
+            lam = np.linalg.inv(np.dot(Ws.T, Ws) / s2 + np.linalg.inv(Psi[on][:, on]))
+            sz[on, s] = np.dot(lam, np.dot(Ws.T, y_obs - np.dot(Ws, mus[on]))) / s2 + mus[on]
+        return np.dot(W[np.logical_not(this_data["x"])], sz)
+
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """check_params -> fused EM_step (sssc.py:407-417)."""
         if self.device_mstep:

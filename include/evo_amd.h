@@ -97,6 +97,12 @@ int evoamd_upload_data(evoamd_ctx *ctx, const double *Y);
 /* my_suff_stat["ss"] (N,S,H) bool <-> device K^n (bit-packed on the device). */
 int evoamd_upload_states(evoamd_ctx *ctx, const uint8_t *ss_bool);
 int evoamd_download_states(evoamd_ctx *ctx, uint8_t *ss_bool);
+/* The same K^n, bit-packed on the host side too: rows [n0, n0 + n) as np.packbits(ss, axis=-1) lays them out
+ * ((n, S, ceil(H/8)) bytes, latent h in byte h/8 at bit 7-(h%8)).  For shards whose bool form
+ * (variational/utils.py:95: 1 byte per latent, 10 GB at N=100k S=200 H=512) should not exist on the host;
+ * any row range, so a large K^n can be handed over in chunks. */
+int evoamd_upload_states_packed(evoamd_ctx *ctx, const uint8_t *packed, int64_t n0, int64_t n);
+int evoamd_download_states_packed(evoamd_ctx *ctx, uint8_t *packed, int64_t n0, int64_t n);
 /* my_suff_stat["lpj"] (N,S_perm+S) float64. */
 int evoamd_upload_lpj(evoamd_ctx *ctx, const double *lpj);
 int evoamd_download_lpj(evoamd_ctx *ctx, double *lpj);
@@ -258,7 +264,9 @@ enum {
   EVOAMD_K_EVOLVE = 8,
   EVOAMD_K_MISC = 9,
   EVOAMD_K_MSTEP_DEVICE = 10,  /* device Theta update (inverse, GEMMs, precompute) */
-  EVOAMD_K_COUNT = 11
+  EVOAMD_K_LPJ_PASS = 11,      /* whole pass over the resident K^n: main kernel + every overflow level (one span) */
+  EVOAMD_K_STATS_PASS = 12,    /* whole statistics pass: scatter + overflow levels + column sums + finish, GEMM aside */
+  EVOAMD_K_COUNT = 13
 };
 /* on = bit mask of kernel classes to time (bit k = class k; -1 = all, 0 = off).  Each timed span
  * records two HIP events on the compute stream, which costs about 10 us of stream time per span:

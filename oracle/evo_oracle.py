@@ -497,7 +497,14 @@ def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma"), n_reliable=N
     enters with the count of RELIABLE entries, as the reference writes it)."""
     if "W" in to_learn:
         rcond = None if float(np.__version__[2:]) >= 14.0 else -1
-        theta["W"] = np.linalg.lstsq(sums["Wq"], sums["Wp"], rcond=rcond)[0].T
+        try:
+            theta["W"] = np.linalg.lstsq(sums["Wq"], sums["Wp"], rcond=rcond)[0].T
+        except np.linalg.LinAlgError:  # bsc.py:238-250 (lstsq raises only when its SVD does not converge)
+            try:
+                noise = np.random.normal(0, EPS_W, H)
+                theta["W"] = np.dot(np.linalg.pinv(sums["Wq"] + np.outer(noise, noise)), sums["Wp"]).T
+            except np.linalg.LinAlgError:
+                theta["W"] = (theta["W"].T + (EPS_W * np.random.normal(0, 1, [H, D]))).T
     if "pi" in to_learn:
         pies_new = sums["pies"] / N
         theta["pi"] = pies_new.sum() / H
@@ -792,7 +799,14 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
     built from first moments and the *new* W (Q4).  Mutates and returns theta."""
     sigma2_old = theta["sigma2"]
     if "W" in to_learn:
-        theta["W"] = np.dot(acc["Wp"], np.linalg.inv(acc["xpt_szsz"]))
+        try:
+            theta["W"] = np.dot(acc["Wp"], np.linalg.inv(acc["xpt_szsz"]))
+        except np.linalg.LinAlgError:  # sssc.py:696-708: pinv of the sum plus a rank-one noise term, else W + noise
+            try:
+                noise = np.random.normal(0, EPS_W, H)
+                theta["W"] = np.dot(acc["Wp"], np.linalg.pinv(acc["xpt_szsz"] + np.outer(noise, noise)))
+            except np.linalg.LinAlgError:
+                theta["W"] = theta["W"] + (EPS_W * np.random.normal(0, 1, [D, H]))
     if "pies" in to_learn:
         pies = acc["xpt_s"] / N
         pies[pies <= EPS_PIES] = EPS_PIES

@@ -9,6 +9,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)  # _sketch.py: the compact summaries the BASELINE-shape fixtures hold
 
 
 def pytest_configure(config):
@@ -22,6 +24,17 @@ def unpack_bits(packed, H):
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+SHAPE_FIXTURES_SMALL = ["c2_small", "c3_small", "c4_small", "c5_small", "c3_wide"]
+SHAPE_FIXTURES_FULL = ["c2", "c3", "c4", "c5"]
+
+
+def sketch_close(got, want, rtol, name=""):
+    """assert_allclose for _sketch.sketch values: atol relative to the largest reference entry."""
+    want = np.asarray(want)
+    scale = float(np.abs(want).max()) if want.size else 1.0
+    np.testing.assert_allclose(np.asarray(got), want, rtol=rtol, atol=rtol * max(scale, 1e-300), err_msg=name)
 
 
 @pytest.fixture

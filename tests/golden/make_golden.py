@@ -28,6 +28,7 @@ sys.path.insert(0, "/root/reference")
 import numpy as np  # noqa: E402
 
 import _mpi_standin  # noqa: E402
+import _sketch  # noqa: E402
 
 COMM = _mpi_standin.install()
 
@@ -73,6 +74,7 @@ def theta_arrays(prefix, theta, keys):
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 BSC_SUMS = ("Wp", "Wq", "pies", "sigma")
+PERM_ZERO = {"background": False, "allzero": True, "singletons": False}
 
 
 def run_steps(model, keys, theta, suff, my_data, n_steps, seed0):
@@ -122,7 +124,7 @@ def run_steps(model, keys, theta, suff, my_data, n_steps, seed0):
 
 
 def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=("fit", "randflip", 10, 1, 1),
-                      bitflip_prob=None, Mprime=None, p_init=None, use_storage=True):
+                      bitflip_prob=None, Mprime=None, p_init=None, use_storage=True, permanent=None):
     np.random.seed(seed)
     if algo == "ebsc":
         model = BSC(D, H, S)
@@ -137,10 +139,10 @@ def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=
         Y = np.random.randn(N, D)
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
     theta = model.check_params(model.standard_init(my_data))
-    suff = init_states(N, S, H, ea[0], ea[1], ea[2], ea[3], ea[4], bitflip_prob, Mprime, p_init)
+    suff = init_states(N, S, H, ea[0], ea[1], ea[2], ea[3], ea[4], bitflip_prob, Mprime, p_init, permanent)
     out = {
         "algo": np.array(algo), "D": np.int64(D), "H": np.int64(H), "S": np.int64(S), "N": np.int64(N),
-        "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y": Y,
+        "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y": Y, "S_perm": np.int64(suff["S_perm"]),
         "ea_parent_selection": np.array(ea[0]), "ea_mutation": np.array(ea[1]),
         "ea_n_parents": np.int64(suff["n_parents"]), "ea_n_children": np.int64(suff["n_children"]),
         "ea_n_generations": np.int64(suff["n_generations"]),
@@ -418,12 +420,110 @@ def make_missing_fixture(name="ebsc", D=25, H=10, S=8, N=40, seed=31, n_steps=3)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_shape_fixture(name, algo, D, H, S, N, seed, n_steps=2, ea=("fit", "randflip", 10, 1, 1)):
+    """EM steps of the reference at a BASELINE.json shape (true D, H, S).  Raw outputs would be tens of MB
+    (W 1-2 MB, K^n up to 100 MB), so the fixture holds what _sketch.py makes of them: one hash per
+    datapoint for K^n and for the candidate batch (bit-exactness is an equality test), three numbers per
+    lpj row, probe products of every accumulator and of Theta^new.  Inputs are not stored either: Y, Theta^init and K^n(0)
+    come from np.random.seed(seed) through randn / standard_init / init_states (hashes stored, so a
+    replay that draws differently fails loudly)."""
+    np.random.seed(seed)
+    if algo == "ebsc":
+        model = BSC(D, H, S)
+        keys = BSC_KEYS
+    else:
+        model = SSSC(D, H, S, use_storage=False)  # the only memory-scalable mode (BASELINE.md section 3)
+        keys = SSSC_KEYS
+    Y = np.random.randn(N, D)
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, ea[0], ea[1], ea[2], ea[3], ea[4])
+    out = {
+        "algo": np.array(algo), "D": np.int64(D), "H": np.int64(H), "S": np.int64(S), "N": np.int64(N),
+        "seed": np.int64(seed), "n_steps": np.int64(n_steps), "Y_sha1": np.array(_sketch.array_sha1(Y)),
+        "ea_parent_selection": np.array(ea[0]), "ea_mutation": np.array(ea[1]),
+        "ea_n_parents": np.int64(suff["n_parents"]), "ea_n_children": np.int64(suff["n_children"]),
+        "ea_n_generations": np.int64(suff["n_generations"]), "ea_bitflip_prob": np.float64(np.nan),
+        "ea_Mprime": np.int64(suff["Mprime"]), "ss_in_hash": _sketch.state_hashes(suff["ss"]),
+    }
+    for k in keys:
+        out["in_sha1_" + k] = np.array(_sketch.array_sha1(np.asarray(theta[k], dtype=np.float64)))
+    import time
+    for t in range(n_steps):
+        np.random.seed(1000 + seed + t)
+        TRACE.clear()
+        COMM.log.clear()
+        COMM.recording = True
+        t0 = time.time()
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+        dt = time.time() - t0
+        COMM.recording = False
+        out["t%d_F" % t] = np.float64(F)
+        out["t%d_S_nunique" % t] = np.float64(nu)
+        out["t%d_S_sub" % t] = np.float64(nsub)
+        out["t%d_ss_hash" % t] = _sketch.state_hashes(suff["ss"])
+        out["t%d_k_sum" % t] = suff["ss"].sum(axis=(1, 2)).astype(np.int64)
+        out["t%d_lpj_rows" % t] = _sketch.lpj_rows(suff["lpj"])
+        out["t%d_cand_counts" % t] = np.array([s.shape[0] for s, _ in TRACE], dtype=np.int64)
+        out["t%d_cand_hash" % t] = _sketch.ragged_hashes([s for s, _ in TRACE])
+        out["t%d_cand_lpj_sum" % t] = np.array([l.sum() for _, l in TRACE])
+        bufs = [p for kind, p in COMM.log if kind == "Allreduce"]
+        scal = [float(p) for kind, p in COMM.log if kind == "allreduce" and np.ndim(p) == 0]
+        if algo == "ebsc":
+            names = ["Wp", "Wq", "pies"]
+            out["t%d_sum_sigma" % t] = np.float64(scal[-1])
+        else:
+            names = ["xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag"]
+        out["t%d_sum_Fs" % t] = np.float64(scal[4])
+        assert len(bufs) == len(names), (len(bufs), names)
+        conds = []
+        worst = 1.0
+        for nm, b in zip(names, bufs):
+            out["t%d_sum_%s" % (t, nm)] = _sketch.sketch(b)
+            if nm in ("Wq", "xpt_szsz", "xpt_ss"):  # the matrices the Theta update solves with
+                cn = np.linalg.cond(b)
+                worst = max(worst, cn)
+                conds.append("%s cond %.2e" % (nm, cn))
+        out["t%d_cond" % t] = np.float64(worst)  # tests compare Theta^new only where the update is well posed
+        for k in keys:
+            out["t%d_out_%s" % (t, k)] = _sketch.sketch(theta[k])
+        print("  %s step %d: %.1f s, F %.6f, %s" % (name, t, dt, F, ", ".join(conds)), flush=True)
+    path = os.path.join(HERE, "shape_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", flush=True)
+
+
+SHAPES = {  # name: (algo, D, H, S, N, seed, ea) -- BASELINE.json configs[1..4] at their true D, H, S
+    # small N (seconds per step, BASELINE.md section 2): E-step, selection and every accumulator
+    "c2_small": ("es3c", 256, 128, 64, 24, 52, ("fit", "randflip", 10, 1, 1)),
+    "c3_small": ("ebsc", 64, 256, 128, 48, 53, ("fit", "randflip", 10, 1, 1)),
+    "c4_small": ("es3c", 256, 512, 200, 12, 54, ("fit", "randflip", 10, 1, 1)),
+    "c5_small": ("ebsc", 256, 1024, 256, 24, 55, ("fit", "randflip", 10, 1, 1)),
+    # more than 64 candidates per datapoint (12 parents x 6 children) at the c3 shape
+    "c3_wide": ("ebsc", 64, 256, 128, 40, 56, ("fit", "randflip", 12, 6, 1)),
+    # N a few times H: the Theta update is well posed, so Theta^new and a second, chained step are pinned too
+    "c2": ("es3c", 256, 128, 64, 512, 62, ("fit", "randflip", 10, 1, 1)),
+    "c3": ("ebsc", 64, 256, 128, 1024, 63, ("fit", "randflip", 10, 1, 1)),
+    "c4": ("es3c", 256, 512, 200, 1536, 64, ("fit", "randflip", 10, 1, 1)),
+    "c5": ("ebsc", 256, 1024, 256, 3072, 65, ("fit", "randflip", 10, 1, 1)),
+}
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "missing":  # only the incomplete-data fixture (added later)
         make_missing_fixture()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "missing_es3c":
         make_missing_fixture_es3c()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "shape":  # BASELINE-shape fixtures (minutes each; run selected names in parallel)
+        for nm in (sys.argv[2:] or sorted(SHAPES)):
+            a, D, H, S, N, seed, ea = SHAPES[nm]
+            make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=2, ea=ea)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "perm":  # permanent all-zero state (S_perm = 1), added later
+        make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
+        make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "recon":  # only the reconstruction fixtures (added later)
         make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
@@ -446,3 +546,8 @@ if __name__ == "__main__":
     make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)
     make_missing_fixture()
     make_missing_fixture_es3c()
+    make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
+    make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
+    for nm in sorted(SHAPES):
+        a, D, H, S, N, seed, ea = SHAPES[nm]
+        make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=2, ea=ea)

@@ -104,7 +104,7 @@ def test_vary_kn_kat(engine):
 
 
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm"]
 
 
 @pytest.mark.parametrize("name", STEP_FIXTURES)
@@ -118,7 +118,8 @@ def test_step_kernels(engine, name):
     for t in range(int(g["n_steps"])):
         counts = g["t%d_cand_counts" % t].astype(np.int32)
         Cmax = max(int(counts.max()), 1)
-        engine.configure(algo[1:] if algo == "ebsc" else "sssc", N, D, H, S, 0, Cmax)
+        S_perm = int(g["S_perm"]) if "S_perm" in g else 0  # permanent all-zero state: lpj column 0
+        engine.configure(algo[1:] if algo == "ebsc" else "sssc", N, D, H, S, S_perm, Cmax)
         engine.upload_data(Y)
         engine.upload_states(unpack_bits(g["t%d_ss_in" % t], H))
         if algo == "ebsc":

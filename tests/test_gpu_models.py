@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm"]
 
 
 @pytest.fixture(scope="module")
@@ -28,9 +28,10 @@ def make_suff(g, ss):
     from evo_amd.variational.utils import MUTATION, PARENT_SELECTION
     N, S, H = ss.shape
     bf = float(g["ea_bitflip_prob"])
+    S_perm = int(g["S_perm"]) if "S_perm" in g else 0  # permanent all-zero state (variational/utils.py:39-54)
     return {
-        "ss": ss.copy(), "lpj": np.empty((N, S)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool),
-        "permanent": {"background": False, "allzero": False, "singletons": False}, "sm": None,
+        "ss": ss.copy(), "lpj": np.empty((N, S + S_perm)), "S_perm": S_perm, "incl": np.zeros((S_perm, H), dtype=bool),
+        "permanent": {"background": False, "allzero": S_perm == 1, "singletons": False}, "sm": None,
         "n_parents": int(g["ea_n_parents"]), "n_children": int(g["ea_n_children"]),
         "n_generations": int(g["ea_n_generations"]),
         "parent_selection": PARENT_SELECTION[str(g["ea_parent_selection"])],
@@ -255,7 +256,8 @@ def test_prefetched_lpj_pass(engine, algo):
         engine.set_option("prefetch_lpj", pf)
         try:
             np.random.seed(3)
-            model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=9)  # K^n stays resident
+            # K^n stays resident; the prefetch is enqueued by evoamd_mstep_device only
+            model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=9, device_mstep=True)
             theta = model.check_params(model.standard_init(my_data))
             suff = init_states(N, S, H, "fit", "randflip", 5, 2, 1)
             rec = []
@@ -308,7 +310,7 @@ def test_overlap_gemm_option(engine, algo):
         np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense"])
+@pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense", "ebsc_perm", "es3c_perm"])
 def test_device_mstep_matches_host(engine, name):
     """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
     instead of LAPACK).  Same inputs as the host path => Theta within 1e-8, F and K^n identical
@@ -532,3 +534,232 @@ def test_missing_data_es3c_against_reference(engine, device_mstep):
     th = dict(theta)
     orc.sssc_precompute(th, D, x_infr)
     np.testing.assert_allclose(one, orc.sssc_lpj(th, suff["ss"][n], Y[n], orc.new_counters(), {}, x_infr[n]), rtol=1e-9)
+
+
+# ---- BASELINE.json shapes (true D, H, S) against the reference ---------------------------------------------
+def _shape_problem(g, engine, device_mstep):
+    """Inputs of tests/golden/shape_*.npz regenerated from the seed through evo_amd's own standard_init /
+    init_states; the fixture holds the hashes of what the reference drew."""
+    import _sketch
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    algo = str(g["algo"])
+    D, H, S, N, seed = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"]), int(g["seed"])
+    np.random.seed(seed)
+    Y = np.random.randn(N, D)
+    assert _sketch.array_sha1(Y) == str(g["Y_sha1"])
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    model = (BSC(D, H, S, engine=engine, device_mstep=device_mstep) if algo == "ebsc"
+             else SSSC(D, H, S, use_storage=False, engine=engine, device_mstep=device_mstep))
+    theta = model.check_params(model.standard_init(my_data))
+    for k in keys:
+        assert _sketch.array_sha1(np.asarray(theta[k], dtype=np.float64)) == str(g["in_sha1_" + k]), k
+    suff = init_states(N, S, H, str(g["ea_parent_selection"]), str(g["ea_mutation"]), int(g["ea_n_parents"]),
+                       int(g["ea_n_children"]), int(g["ea_n_generations"]))
+    assert np.array_equal(_sketch.state_hashes(suff["ss"]), g["ss_in_hash"])
+    return model, keys, my_data, theta, suff
+
+
+SUM_NAMES = {"ebsc": ("Wp", "Wq", "pies", "sigma"),
+             "es3c": ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag")}
+
+
+@pytest.mark.parametrize("device_mstep", [False, True])
+@pytest.mark.parametrize("name", ["c2_small", "c3_small", "c4_small", "c5_small", "c3_wide", "c2", "c3", "c4", "c5"])
+def test_shape_trajectory(engine, name, device_mstep):
+    """EM steps at the TRUE (D, H, S) of BASELINE.json configs[1..4] against the reference
+    (tests/golden/shape_*.npz; *_small: N = 12..48, the others N = 3-4 H so that Theta^new is well posed and a
+    second step chains on it; c3_wide: 72 candidates per datapoint).  rng="reference": after every step K^n
+    bit-identical (one hash per datapoint), lpj rows and F to 1e-9, every all-reduced accumulator to 1e-9
+    (host M-step), Theta^new to 1e-6 x condition.  These are the kernel instantiations bench.py runs:
+    sssc_main_lpj<*,2|8>, sssc_stats<2|8>, bsc_lpj_gram2<*,4|16>, bsc_stats<4|16>, vary_kn<1|2|4,1|4>, gjs32 at
+    H = 256 / 512 / 1024 inside evoamd_mstep_device."""
+    import _sketch
+    from conftest import sketch_close
+    g = load_golden("shape_%s.npz" % name)
+    model, keys, my_data, theta, suff = _shape_problem(g, engine, device_mstep)
+    algo, seed = str(g["algo"]), int(g["seed"])
+    for t in range(int(g["n_steps"])):
+        np.random.seed(1000 + seed + t)
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+        assert np.array_equal(_sketch.state_hashes(suff["ss"]), g["t%d_ss_hash" % t]), "K^n differs at step %d" % t
+        np.testing.assert_allclose(_sketch.lpj_rows(suff["lpj"]), g["t%d_lpj_rows" % t], rtol=1e-9)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-9)
+        assert nu == float(g["t%d_S_nunique" % t]) and nsub == float(g["t%d_S_sub" % t])
+        if not device_mstep:
+            v = engine.acc_views(model.last_acc)
+            for nm in SUM_NAMES[algo]:
+                sketch_close(_sketch.sketch(v[nm]), g["t%d_sum_%s" % (t, nm)], 1e-9, "sum %s step %d" % (nm, t))
+            np.testing.assert_allclose(float(v["Fs"]), float(g["t%d_sum_Fs" % t]), rtol=1e-9)
+        cond = float(g["t%d_cond" % t])
+        if cond > 1e8:
+            break  # N << H: Theta^new is rounding noise times the condition number, nothing to compare or chain on
+        for k in keys:
+            sketch_close(_sketch.sketch(theta[k]), g["t%d_out_%s" % (t, k)], max(1e-6, 1e-12 * cond), "%s step %d" % (k, t))
+
+
+def test_prefetch_level_transition(engine):
+    """A prefetched pass over K^n is enqueued before the host has seen the overflow counts of the K^n it
+    evaluates.  K^n starts with singletons only; iteration 1 can add pairs, iteration 2 the first states with
+    three active latents -- the pass prefetched at the end of iteration 2 must launch the k > 2 level although
+    the last counts the host saw (K^n of iteration 1) were zero.  Same trajectory with prefetch_lpj = 0."""
+    from evo_amd.models import SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(12)
+    D, H, S, N = 32, 48, 16, 400
+    W0 = rng.normal(size=(D, H)) * 2.0
+    Y = (rng.random_sample((N, H)) < 4.0 / H).astype(float) @ W0.T + 0.1 * rng.normal(size=(N, D))  # ~4 causes per datapoint
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    W_start = W0 + 0.05 * rng.normal(size=(D, H))
+    singles = np.stack([rng.permutation(H)[:S] for _ in range(N)])  # S distinct singletons per datapoint
+    out = []
+    for pf in (1, 0):
+        engine.set_option("prefetch_lpj", pf)
+        try:
+            np.random.seed(3)
+            model = SSSC(D, H, S, rng="device", sync_host=False, engine=engine, seed=9, device_mstep=True,
+                         to_learn=["W", "sigma2"])
+            theta = model.standard_init(my_data)
+            theta["W"] = W_start.copy()
+            theta = model.check_params(theta)
+            suff = init_states(N, S, H, "fit", "randflip", 8, 2, 1)
+            suff["ss"][:] = False
+            suff["ss"][np.arange(N)[:, None], np.arange(S)[None, :], singles] = True
+            rec = []
+            for it in range(6):
+                F, _, _, theta = model.step(theta, suff, my_data)
+                model.sync_to_host(suff)  # downloads only: the prefetched pass stays valid
+                rec.append((F, suff["lpj"].copy(), suff["ss"].copy()))
+            out.append(rec)
+        finally:
+            engine.set_option("prefetch_lpj", 1)
+    kmax = [int(s.sum(axis=2).max()) for _, _, s in out[0]]
+    assert kmax[0] <= 2 and max(kmax) >= 3, kmax  # the transition happened inside the run
+    for (F1, l1, s1), (F0, l0, s0) in zip(*out):
+        np.testing.assert_array_equal(s1, s0)
+        np.testing.assert_allclose(F1, F0, rtol=1e-10)
+        np.testing.assert_allclose(l1, l0, rtol=1e-9, atol=1e-9)
+
+
+def test_packed_state_roundtrip(engine):
+    """evoamd_upload_states_packed / download: np.packbits rows in chunks == the bool upload."""
+    rng = np.random.RandomState(1)
+    for H in (10, 64, 70, 512):
+        N, S = 37, 9
+        ss = rng.random_sample((N, S, H)) < 0.2
+        engine.configure("bsc", N, 4, H, S, 0, 4)
+        engine.upload_states(ss)
+        ref_words = engine.download_states_packed()
+        assert np.array_equal(ref_words, np.packbits(ss, axis=-1))
+        engine.upload_states(np.zeros_like(ss))
+        packed = np.packbits(ss, axis=-1)
+        engine.upload_states_packed(packed[:20], 0)
+        engine.upload_states_packed(packed[20:], 20)
+        assert np.array_equal(engine.download_states(), ss)
+        assert np.array_equal(engine.download_states_packed(5, 7), packed[5:12])
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_public_reconstruct_and_modelmean(engine, algo):
+    """Model.reconstruct(my_data, my_suff_stat, model_params) (_models.py:614-665) from the caller's K^n / lpj,
+    and the per-datapoint modelmean operator, against the oracle's restatement of both."""
+    from oracle import evo_oracle as orc
+    from evo_amd.models import BSC, SSSC
+    g = load_golden("recon_%s.npz" % algo)
+    D, H, S = int(g["D"]), int(g["H"]), int(g["S"])
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    Y, x = g["Y"], g["x"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool), "x": x}
+    model = (BSC if algo == "ebsc" else SSSC)(D, H, S, engine=engine)
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in keys}
+    for k in ("pi", "sigma", "sigma2"):
+        if k in theta:
+            theta[k] = np.float64(theta[k])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    np.random.seed(1000 + int(g["seed"]))
+    model.E_step(theta, suff, my_data)  # fills suff["lpj"] for the evolved K^n
+    model.reconstruct(my_data, suff, theta)
+    got = my_data["y_reconstructed"]
+    # the reference's step(do_reconstruction=True) reconstructs at exactly this point (_models.py:193-194)
+    want = g["t0_y_reconstructed"]
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())))
+    n = 2
+    this = {"y": Y[n], "x": x[n], "x_infr": my_data["x_infr"][n]}
+    mm = model.modelmean(theta, this, {"ss": suff["ss"][n]})
+    assert mm.shape == (int(np.logical_not(x[n]).sum()), S)
+    B = -suff["lpj"][n].max()
+    q = np.exp(suff["lpj"][n] + B)
+    est = (mm * q[None, :]).sum(axis=1) / q.sum()
+    np.testing.assert_allclose(est, want[n][np.logical_not(x[n])], rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_device_mstep_absorbs_singular_update(engine, algo):
+    """A latent that occurs in no state of any K^n makes the M-step's H x H system exactly singular.  The
+    reference absorbs it (lstsq min-norm solution, bsc.py:237; inv -> LinAlgError -> pinv + noise,
+    sssc.py:692-708).  device_mstep=True must not raise: the step is finished with the reference's host
+    formulas and equals the host-M-step path (same np.random draws)."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(8)
+    D, H, S, N = 16, 12, 6, 80
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    res = []
+    for mode in (False, True):
+        np.random.seed(5)
+        model = (BSC if algo == "ebsc" else SSSC)(D, H, S, engine=engine, device_mstep=mode)
+        theta = model.check_params(model.standard_init(my_data))
+        suff = init_states(N, S, H, "fit", "randflip", 3, 1, 1)
+        suff["ss"][:, :, H - 1] = False  # latent H-1 never fires ...
+        suff["ss"][:, :, :S] |= np.eye(S, dtype=bool)[None]  # ... and the rows stay distinct
+        suff["mutation_algorithm"] = lambda parents, n_children, sparseness, p_bf: _flip_not_last(parents, n_children, H)
+        np.random.seed(6)
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+        assert not suff["ss"][:, :, H - 1].any()
+        res.append((F, {k: np.array(v) for k, v in theta.items()}))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-10)
+    for k in (BSC_KEYS if algo == "ebsc" else SSSC_KEYS):
+        assert np.isfinite(res[1][1][k]).all(), k
+        # the fallback goes through pinv of a singular sum + 5e-5-scale noise: agreement at 1e-4 of the scale
+        a, b = res[1][1][k], res[0][1][k]
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(b).max())), err_msg=k)
+
+
+def _flip_not_last(parents, n_children, H):
+    """randflip restricted to latents 0 .. H-2 (keeps latent H-1 silent); consumes np.random like randflip."""
+    n_par = parents.shape[0]
+    kids = np.repeat(parents, n_children, axis=0)
+    pos = np.random.randint(0, H - 1, size=kids.shape[0])
+    kids[np.arange(kids.shape[0]), pos] ^= True
+    return kids
+
+
+def test_new_array_same_shape_is_uploaded(engine):
+    """Residency is keyed on the array objects the model holds, not on id(): replacing my_data["y"] by a new
+    array of the same shape (a fresh minibatch) must be seen, and invalidate() re-reads in-place edits."""
+    from evo_amd.models import BSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(3)
+    D, H, S, N = 12, 16, 6, 40
+    model = BSC(D, H, S, engine=engine, to_learn=[])
+    np.random.seed(1)
+    Ya = rng.normal(size=(N, D))
+    my_data = {"y": Ya, "x_infr": np.ones((N, D), dtype=bool)}
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, "fit", "randflip", 3, 1, 1)
+    ss0 = suff["ss"].copy()
+    Fa = model.free_energy(my_data, theta, suff, full=False)
+    for _ in range(3):  # same shape, the old array is freed first so CPython may hand its address out again
+        del my_data["y"]
+        Ya = None
+        my_data["y"] = rng.normal(size=(N, D)) * 3.0
+        suff["ss"][:] = ss0
+        Fb = model.free_energy(my_data, theta, suff, full=False)
+        assert abs(Fb - Fa) > 1e-3 * abs(Fa)
+        Fa = Fb
+    my_data["y"][:] = rng.normal(size=(N, D))  # in-place edit: needs invalidate()
+    model.invalidate()
+    Fc = model.free_energy(my_data, theta, suff, full=False)
+    assert abs(Fc - Fa) > 1e-3 * abs(Fa)

@@ -9,7 +9,7 @@ from conftest import load_golden, unpack_bits
 from oracle import evo_oracle as orc
 
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm"]
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 
@@ -17,9 +17,10 @@ SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 def suff_from_fixture(g, ss_bool):
     N, S, H = ss_bool.shape
     bf = float(g["ea_bitflip_prob"])
+    S_perm = int(g["S_perm"]) if "S_perm" in g else 0  # permanent all-zero state (variational/utils.py:39-54)
     return {
-        "ss": ss_bool.copy(), "lpj": np.empty((N, S)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool),
-        "permanent": {"background": False, "allzero": False, "singletons": False}, "sm": None,
+        "ss": ss_bool.copy(), "lpj": np.empty((N, S + S_perm)), "S_perm": S_perm, "incl": np.zeros((S_perm, H), dtype=bool),
+        "permanent": {"background": False, "allzero": S_perm == 1, "singletons": False}, "sm": None,
         "n_parents": int(g["ea_n_parents"]), "n_children": int(g["ea_n_children"]),
         "n_generations": int(g["ea_n_generations"]),
         "parent_selection": orc.PARENT_SELECTION[str(g["ea_parent_selection"])],
@@ -70,6 +71,88 @@ def test_step_replay(name):
             np.testing.assert_allclose(sums[nm], g["t%d_sum_%s" % (t, nm)], rtol=1e-11, atol=1e-13, err_msg=nm)
         for k in keys:
             np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+def _shape_problem(g, n_sub=None):
+    """Inputs of a shape_*.npz fixture, regenerated from its seed through the oracle's own standard_init /
+    init_states (the fixture holds hashes of what the reference drew)."""
+    import _sketch
+    algo = str(g["algo"])
+    D, H, S, N, seed = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"]), int(g["seed"])
+    np.random.seed(seed)
+    Y = np.random.randn(N, D)
+    assert _sketch.array_sha1(Y) == str(g["Y_sha1"])
+    if algo == "ebsc":
+        theta = orc.check_params(orc.bsc_standard_init(Y, H), orc.BSC_POLICY)
+        keys = BSC_KEYS
+    else:
+        theta = orc.check_params(orc.sssc_standard_init(Y, H), orc.SSSC_POLICY)
+        keys = SSSC_KEYS
+    for k in keys:
+        assert _sketch.array_sha1(np.asarray(theta[k], dtype=np.float64)) == str(g["in_sha1_" + k]), k
+    suff = orc.init_states(N, S, H, str(g["ea_parent_selection"]), str(g["ea_mutation"]), int(g["ea_n_parents"]),
+                           int(g["ea_n_children"]), int(g["ea_n_generations"]))
+    assert np.array_equal(_sketch.state_hashes(suff["ss"]), g["ss_in_hash"])
+    if n_sub is not None:  # datapoints are independent given Theta and consume np.random in order: a prefix replays alone
+        Y = Y[:n_sub]
+        suff["ss"], suff["lpj"] = suff["ss"][:n_sub].copy(), suff["lpj"][:n_sub].copy()
+    return algo, keys, Y, theta, suff
+
+
+def _check_shape_estep(g, t, suff, trace, n):
+    import _sketch
+    assert np.array_equal(_sketch.state_hashes(suff["ss"]), g["t%d_ss_hash" % t][:n]), "K^n differs"
+    np.testing.assert_allclose(_sketch.lpj_rows(suff["lpj"]), g["t%d_lpj_rows" % t][:n], rtol=1e-11)
+    assert np.array_equal([c[1].shape[0] for c in trace], g["t%d_cand_counts" % t][:n])
+    assert np.array_equal(_sketch.ragged_hashes([c[1] for c in trace]), g["t%d_cand_hash" % t][:n])
+    np.testing.assert_allclose([c[2].sum() for c in trace], g["t%d_cand_lpj_sum" % t][:n], rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["c2_small", "c3_small", "c4_small", "c5_small", "c3_wide"])
+def test_shape_replay_small(name):
+    """Reference EM steps at the TRUE (D, H, S) of BASELINE.json configs[1..4] with small N: the oracle must
+    reproduce candidate streams, selection, lpj, F, every all-reduced accumulator and -- where the Theta
+    update is well posed (condition number stored with the fixture) -- Theta^new.  A step whose Theta^in
+    came out of an ill-posed update (N << H) is not replayed."""
+    import _sketch
+    from conftest import sketch_close
+    g = load_golden("shape_%s.npz" % name)
+    algo, keys, Y, theta, suff = _shape_problem(g)
+    N, seed = int(g["N"]), int(g["seed"])
+    for t in range(int(g["n_steps"])):
+        trace = []
+        np.random.seed(1000 + seed + t)
+        if algo == "ebsc":
+            F, nu, nsub, theta, sums = orc.bsc_step(theta, suff, Y, trace=trace)
+            sum_names = ("Wp", "Wq", "pies", "sigma", "Fs")
+        else:
+            F, nu, nsub, theta, sums = orc.sssc_step(theta, suff, Y, use_storage=False, trace=trace)
+            sum_names = ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag", "Fs")
+        _check_shape_estep(g, t, suff, trace, N)
+        np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=1e-13)
+        assert nu == float(g["t%d_S_nunique" % t]) and nsub == float(g["t%d_S_sub" % t])
+        for nm in sum_names:
+            sketch_close(_sketch.sketch(sums[nm]), g["t%d_sum_%s" % (t, nm)], 1e-10, nm)
+        cond = float(g["t%d_cond" % t])
+        if cond > 1e8:
+            break  # Theta^new of this step is rounding noise times the condition number: nothing to chain on
+        for k in keys:
+            sketch_close(_sketch.sketch(theta[k]), g["t%d_out_%s" % (t, k)], max(1e-9, 1e-14 * cond), k)
+
+
+@pytest.mark.parametrize("name,n_sub", [("c2", 12), ("c3", 48), ("c4", 4), ("c5", 10)])
+def test_shape_replay_prefix(name, n_sub):
+    """The N ~ 3H fixtures (minutes of reference time): the oracle replays the E-step of the first n_sub
+    datapoints of step 0 (same Theta, same np.random prefix) -- candidate stream, selection and lpj."""
+    g = load_golden("shape_%s.npz" % name)
+    algo, keys, Y, theta, suff = _shape_problem(g, n_sub)
+    trace = []
+    np.random.seed(1000 + int(g["seed"]))
+    if algo == "ebsc":
+        orc.bsc_E_step(theta, suff, Y, trace)
+    else:
+        orc.sssc_EM_accumulate(theta, suff, Y, use_storage=False, trace=trace)
+    _check_shape_estep(g, 0, suff, trace, n_sub)
 
 
 def test_kat_bars_from_seed():
