@@ -1,30 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- EM-iteration throughput of the EVO hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4]
 
-A *step* is one full EM iteration of the product path (evo_amd.models, rng="device", K^n resident
-on the GPU): upload Theta + dense precompute, lpj of all N x S resident states, device candidate
-generation + their lpj, vary_Kn, sufficient statistics + free energy, ONE RCCL all-reduce of the
-packed accumulator when N > 1, and the (tiny) host Theta update that feeds the next step.
-Metric = candidate-state evaluations per second counted as N x S per step (the BASELINE.json
-headline; the extra candidate evaluations are done but not counted), whole job, all ranks.
+`--gpus N` with N > 1 may be called bare: the parent starts N fresh child processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) before anything touches the GPU, waits
+for them and prints rank 0's JSON line.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the
+process is one of the ranks.  No PyTorch anywhere: ranks share the RCCL id through a file
+(evo_amd.utils.parallel) and all-reduce through librccl inside libevo_amd.
 
-Default workload (N=1): BASELINE.json configs[1], "ES3C synthetic Gaussian D=256, H=128, S=64,
-N=10k, float64".  With more GPUs every rank keeps that shard size (weak scaling).
+Workload (default): BASELINE.json's north-star shape, configs[3] -- ES3C D=256 H=512 S=200 N=100k, float64
+-- on ONE GPU for --gpus 1 and split like np.array_split over the ranks for --gpus N (strong scaling: the
+job is the same 100k datapoints whatever N is).  --config c2 | c3 | c5 select the other BASELINE shapes.
 
-One JSON line is printed by rank 0; it also carries
-  roofline      the dominant kernel (lpj over K^n) against the HBM roof, duration from HIP events on
-                the library's stream inside the timed region
-  cpu_baseline  the loop-faithful NumPy restatement of the reference (oracle/, "port") timed on
-                this box's host cores on a bounded sample of the same workload (N=1 only)
-No PyTorch anywhere: ranks find each other through RANK/WORLD_SIZE/LOCAL_RANK set by the launcher
-and share the RCCL id through a file (evo_amd.utils.parallel).
+A *step* is `--em-per-step` (default 10) full EM iterations of the product path (evo_amd.models,
+rng="device", K^n resident on the GPU, device Theta update): per iteration lpj of all N x S resident states,
+device candidate generation + their lpj, vary_Kn, sufficient statistics + free energy, ONE RCCL all-reduce of
+the packed accumulator when N > 1, Theta update, dense precompute for the next E-step.  Ten iterations per
+step keep the timed region of the driver's 20 steps above one second of GPU time.
+Metric = candidate-state evaluations per second counted as N x S per EM iteration (BASELINE.json's headline;
+the candidate evaluations are done but not counted), whole job, all ranks.
+
+The JSON line carries
+  roofline        the WHOLE pass over the resident K^n (main kernel + every overflow level it spawns, one
+                  HIP-event span on the library's stream inside the timed region) against the HBM roof
+  roofline_stats  the whole statistics pass (scatter kernels + overflow levels + column sums) likewise
+  cpu_baseline    the loop-faithful NumPy restatement of the reference (oracle/, "port") timed on every host
+                  core this process may use, on a bounded sample of the same workload (N=1 only)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,71 +41,171 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-CONFIGS = {  # BASELINE.json "configs", per-GPU shard sizes
+CONFIGS = {  # BASELINE.json "configs": the whole job (N_total is split over the ranks)
     "c1": dict(algo="ebsc", D=25, H=10, S=32, N=500, name="bars-test EBSC D=25 H=10 S=32 N=500"),
     "c2": dict(algo="es3c", D=256, H=128, S=64, N=10000, name="ES3C synthetic Gaussian D=256 H=128 S=64 N=10k f64"),
     "c3": dict(algo="ebsc", D=64, H=256, S=128, N=50000, name="EBSC 8x8 patches D=64 H=256 S=128 N=50k f64"),
-    "c4": dict(algo="es3c", D=256, H=512, S=200, N=12500, name="ES3C D=256 H=512 S=200 N=100k/8 per GPU f64"),
-    "c4full": dict(algo="es3c", D=256, H=512, S=200, N=100000, name="ES3C D=256 H=512 S=200 N=100k on one GPU f64"),
-    "c5": dict(algo="ebsc", D=256, H=1024, S=256, N=25000, name="EBSC D=256 H=1024 S=256 N=200k/8 per GPU (f64)"),
+    "c4": dict(algo="es3c", D=256, H=512, S=200, N=100000, name="ES3C D=256 H=512 S=200 N=100k f64 (north-star shape)"),
+    "c4shard": dict(algo="es3c", D=256, H=512, S=200, N=12500, name="ES3C D=256 H=512 S=200 N=12.5k (one eighth of c4) f64"),
+    "c5": dict(algo="ebsc", D=256, H=1024, S=256, N=200000, name="EBSC D=256 H=1024 S=256 N=200k (f64; the reference has no f32)"),
+    "c5shard": dict(algo="ebsc", D=256, H=1024, S=256, N=25000, name="EBSC D=256 H=1024 S=256 N=25k (one eighth of c5) f64"),
 }
+CONFIGS["c4full"] = CONFIGS["c4"]  # round-1 name
 EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector peak
-# dominant kernel per model (the pass over all N x S resident states) as rocprofv3 names it
-def roofline_kernel(cfg):
-    """Name of the kernel that evaluates all N x S resident states (its template arguments carry the
-    number of 64-bit words per state), as rocprofv3 prints it."""
+# oracle (the timed "port") vs the imported reference, same container, same inputs, 1 core:
+# ES3C c2 shape 32.7 vs 37.4 ms per datapoint, EBSC c3 shape 2.33 vs 2.50 -- the port is 7-13 % FASTER
+ORACLE_VS_REFERENCE = "oracle is 7-13 % faster than the imported reference (ES3C c2 shape 32.7 vs 37.4 ms per " \
+                      "datapoint, EBSC c3 shape 2.33 vs 2.50; build container, 1 core), i.e. inside the +-15 % band"
+
+
+def log(msg):
+    """Progress on stderr (rank 0): a silent run of several minutes is taken for a hang by the job runner."""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[bench %6.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (the GPU box
+    shows all 256 hardware threads of the host but grants a share of 16 through cpu.max)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read().split()[0])
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(round(float(quota) / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pass_kernels(cfg):
+    """Kernels of the pass over all N x S resident states, as rocprofv3 names them (TAG 0 = the pass over K^n)."""
     hw = (cfg["H"] + 63) // 64
     if cfg["algo"] == "es3c":
-        return "void sssc_main_lpj_kernel<0, 512, %d, 2>" % (hw if hw in (1, 2, 4, 8, 16) else 0)
-    return "void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)
+        return ["void sssc_main_lpj_kernel<0, 512, %d, 2>" % (hw if hw in (1, 2, 4, 8, 16) else 0),
+                "void sssc_small_kernel<4, 0, 0, 256>", "void sssc_small_kernel<8, 0, 0, 256>",
+                "void sssc_big_kernel<0, 0>"]
+    return ["void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)]
 
 
-def pmc_traffic(config, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes
-    (profiles/<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
-    path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % config)
+def stats_kernels(cfg):
+    hw = (cfg["H"] + 63) // 64
+    hwt = hw if hw in (1, 2, 4, 8, 16) else 0
+    if cfg["algo"] == "es3c":
+        return ["void sssc_stats_kernel<%d>" % hwt, "void sssc_small_kernel<4, 1, 2, 256>",
+                "void sssc_small_kernel<8, 1, 2, 256>", "void sssc_big_kernel<1, 2>", "colsum_partial_kernel",
+                "sssc_finish_kernel"]
+    return ["void bsc_stats_kernel<%d>" % hwt, "colsum_partial_kernel", "bsc_finish_kernel"]
+
+
+def pmc_traffic(config, kernels):
+    """HBM bytes per pass = sum over `kernels` of bytes per launch from the committed rocprofv3 counter passes
+    (profiles/r02_<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs, read side corrected as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % config)
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d[kernel]["traffic_bytes_2xfetch_plus_write"])
     except Exception:
         return None
+    total, seen = 0.0, False
+    for k in kernels:
+        for name, rec in d.items():
+            if name.startswith(k):
+                total += float(rec["traffic_bytes_2xfetch_plus_write"]) * float(rec.get("launches_per_pass", 1.0))
+                seen = True
+    return total if seen else None
 
 
-def algorithmic_bytes_lpj(cfg, N):
-    """lpj pass, per datapoint D*w + C*(ceil(H/8) + w) with w = 8, C = S."""
+def algorithmic_bytes_pass(cfg, N):
+    """lpj pass and statistics pass alike, per datapoint D*w + C*(ceil(H/8) + w) with w = 8, C = S."""
     return N * (cfg["D"] * 8 + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
 
 
 def layout_bytes_lpj(cfg, N):
-    """Compulsory bytes of the same pass in THIS implementation's HBM layout: per datapoint the row of
+    """Compulsory bytes of the lpj pass in THIS implementation's HBM layout: per datapoint the row of
     B = Y W (H doubles, replaces y_n in the Gram form) and per state one 8-byte digest (count + first
     active latents, replaces the ceil(H/8) bit words) plus the 8-byte lpj written."""
     return N * (cfg["H"] * 8 + cfg["S"] * (8 + 8))
 
 
-def gemm_flops_per_step(cfg):
+def gemm_flops_per_iteration(cfg, N):
     """Dense f64 contractions of one EM iteration in steady state (the launches timed under
     kernel class "gemm_f64"): the K = N statistics contraction, G = W^T W and B = Y W."""
-    N, D, H = cfg["N"], cfg["D"], cfg["H"]
+    D, H = cfg["D"], cfg["H"]
     if cfg["algo"] == "es3c":
         return 2.0 * N * (D + 2 * H) * H + 2.0 * D * H * H + 2.0 * N * D * H
     return 2.0 * N * H * D + 2.0 * D * H * H + 2.0 * N * D * H
 
 
-def make_problem(cfg, seed, model, dense=False):
+# ---------------------------------------------------------------------------------------------
+# K^n(0): init_states (variational/utils.py:155-228) per chunk on the host cores, handed over bit-packed
+# ---------------------------------------------------------------------------------------------
+def _init_chunk(args):
+    n, S, H, seed, p_init = args
+    import numpy as np  # noqa: F811
     from evo_amd.variational import init_states
     np.random.seed(seed)
-    Y = np.random.randn(cfg["N"], cfg["D"])
-    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
-    theta = model.check_params(model.standard_init(my_data))
-    suff = init_states(cfg["N"], cfg["S"], cfg["H"], EA["parent_selection"], EA["mutation"], EA["n_parents"],
-                       EA["n_children"], EA["n_generations"],
-                       p_init_Kn=(8.0 / cfg["H"]) if dense else None)  # SURVEY 8d dense-state stress variant
-    return my_data, theta, suff
+    suff = init_states(n, S, H, EA["parent_selection"], EA["mutation"], EA["n_parents"], EA["n_children"],
+                       EA["n_generations"], p_init_Kn=p_init)
+    return np.packbits(suff["ss"], axis=-1)
+
+
+def init_states_packed(cfg, n_rows, seed, workers, dense=False, chunk=2000):
+    """Yields (n0, packed uint8 (n, S, ceil(H/8))): the reference's init_states run chunk by chunk in a process
+    pool (the bool form of the north-star K^n would be 10 GB, and one core needs minutes for 100k datapoints)."""
+    import multiprocessing as mp
+    p_init = (8.0 / cfg["H"]) if dense else None  # SURVEY 8d dense-state stress variant
+    jobs, n0 = [], 0
+    while n0 < n_rows:
+        n = min(chunk, n_rows - n0)
+        jobs.append((n0, (n, cfg["S"], cfg["H"], seed + 7919 * len(jobs), p_init)))
+        n0 += n
+    if workers <= 1 or len(jobs) == 1:
+        for n0, a in jobs:
+            yield n0, _init_chunk(a)
+        return
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        for (n0, _), packed in zip(jobs, pool.imap(_init_chunk, [a for _, a in jobs])):
+            yield n0, packed
+
+
+def ea_suff(cfg):
+    """my_suff_stat without the K^n arrays (they live on the device): the EA knobs init_states stores."""
+    from evo_amd.variational import eas
+    return {"ss": None, "lpj": None, "S_perm": 0, "incl": np.zeros((0, cfg["H"]), dtype=bool), "sm": None,
+            "permanent": {"background": False, "allzero": False, "singletons": False},
+            "n_parents": EA["n_parents"], "n_children": EA["n_children"], "n_generations": EA["n_generations"],
+            "parent_selection": eas.fitparents, "mutation_algorithm": eas.randflip, "bitflip_prob": None,
+            "Mprime": cfg["S"]}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -119,8 +226,8 @@ def _cpu_worker(args):
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        # the per-datapoint loops only (E-step + sufficient statistics); the Theta solve is left out
-        # because a small sample (N < H) makes it singular -- it is O(H^3) once per step, negligible
+        # the per-datapoint loops (E-step + sufficient statistics); the Theta solve is timed apart
+        # (_cpu_theta_solve): a sample with N < H would make it singular
         if algo == "ebsc":
             orc.bsc_E_step(theta, suff, Y)
             orc.bsc_accumulate(theta, suff, Y)
@@ -132,11 +239,28 @@ def _cpu_worker(args):
     return best
 
 
+def _cpu_theta_solve(cfg):
+    """The once-per-iteration H x H part of the reference's Theta update (bsc.py:237 lstsq; sssc.py:693,738
+    two inverses + W = Wp inv), timed on well-conditioned stand-ins of the same sizes, one process,
+    BLAS threads as the reference would have them (unrestricted)."""
+    rng = np.random.RandomState(0)
+    H, D = cfg["H"], cfg["D"]
+    A = rng.normal(size=(H, H))
+    A = A @ A.T + H * np.eye(H)
+    t0 = time.perf_counter()
+    if cfg["algo"] == "ebsc":
+        np.linalg.lstsq(A, rng.normal(size=(H, D)), rcond=-1)
+    else:
+        np.dot(rng.normal(size=(D, H)), np.linalg.inv(A))
+        np.linalg.inv(A + 1e-5 * np.eye(H))
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(cfg, budget_s=20.0):
-    """Time the oracle on a bounded sample (about budget_s seconds of wall time): every core runs
-    the reference-style per-datapoint loop on its own shard, like one MPI rank per core."""
+    """Time the oracle on a bounded sample (about budget_s seconds of wall time): every core this process may
+    use runs the reference-style per-datapoint loop on its own shard, like one MPI rank per core."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     # probe one datapoint-step cost on one core, then size the sample
     t_probe = _cpu_worker((cfg["algo"], cfg["D"], cfg["H"], cfg["S"], 2, 99, 1)) / 2
     per_core = int(max(2, min(2048, (budget_s / 2.0) / max(t_probe, 1e-4))))  # two timed steps per worker
@@ -145,14 +269,68 @@ def cpu_baseline(cfg, budget_s=20.0):
     jobs = [(cfg["algo"], cfg["D"], cfg["H"], cfg["S"], per_core, 1234 + i, 2) for i in range(cores)]
     with ctx.Pool(cores) as pool:
         times = pool.map(_cpu_worker, jobs)
+    os.environ.pop("OPENBLAS_NUM_THREADS", None)
     t = max(times)
     n_sub = per_core * cores
+    t_solve = _cpu_theta_solve(cfg)
+    t_full = cfg["N"] * t / n_sub
     return {
         "value": n_sub * cfg["S"] / t, "unit": "N*S state evals/s", "cores": cores, "kind": "port",
-        "sample": "oracle EM step (reference loop structure, use_storage=False) on %d datapoints (%d per core, "
-                  "%d processes, OPENBLAS_NUM_THREADS=1), best of 2, %.2f s; cost is linear in N" % (n_sub, per_core, cores, t),
+        "cpu_model": cpu_model(),
+        "sample": "oracle EM iteration (reference loop structure: E-step + sufficient statistics, use_storage=False) "
+                  "on %d datapoints (%d per core, %d processes = every core of this process's CPU share: affinity "
+                  "capped by the cgroup quota), OPENBLAS_NUM_THREADS=1, best of 2, %.2f s; cost is linear in N"
+                  % (n_sub, per_core, cores, t),
         "ms_per_datapoint_per_core": 1e3 * t / per_core,
+        "theta_solve_s": t_solve,
+        "theta_solve_note": "the H x H solves of the Theta update (once per iteration, every rank redundantly) are not "
+                            "in `value`: %.3f s against %.0f s of loops for the full N on these cores" % (t_solve, t_full),
+        "extrapolated_s_per_iteration_full_N": t_full + t_solve,
+        "port_vs_reference": ORACLE_VS_REFERENCE,
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# --gpus N without a launcher: one fresh child per GPU, started before anything touches the GPU
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, worker=None, timeout_s=None):
+    """Start `n` ranks of this script (or of `worker`, a command list, for the CPU test of this logic), wait,
+    return (rc, rank-0 stdout).  A non-zero exit of any rank is propagated; the others are then terminated."""
+    port = free_port()
+    nonce = "%d_%d" % (os.getpid(), int(time.time() * 1e3))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EVO_AMD_LAUNCH_NONCE=nonce,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = (worker or [sys.executable, os.path.abspath(__file__)]) + list(argv)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, rc = b"", 0
+    t0 = time.time()
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout_s)
+        rc = procs[0].returncode
+        for p in procs[1:]:
+            left = None if timeout_s is None else max(1.0, timeout_s - (time.time() - t0))
+            p.wait(timeout=left)
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    return rc, out0.decode(errors="replace")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -161,7 +339,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
+    ap.add_argument("--em-per-step", type=int, default=10, help="EM iterations per step (default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-mstep", action="store_true", help="Theta update with host NumPy (reference formulas)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -170,23 +349,40 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="evoamd_set_option before the run (A/B of a kernel path, e.g. overlap_gemm=0)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `bench.py --gpus N`: this parent never initialises HIP; it only starts the ranks and relays rank 0
+        rc, out = launch_ranks(args.gpus, sys.argv[1:])
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        sys.exit(rc)
     cfg = dict(CONFIGS[args.config])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with one process per GPU "
-                     "(python -m torch.distributed.run --nproc-per-node %d bench.py ...)" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world  # under a launcher the world it built is what runs
+    iters = max(1, args.em_per_step)
 
     # CPU baseline first: it forks worker processes and must run before HIP is initialised
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("CPU baseline (oracle on %d cores, ~%.0f s) ..." % (host_cores(), args.cpu_seconds))
         cpu = cpu_baseline(cfg, args.cpu_seconds)
+        log("CPU baseline: %.3g evals/s" % cpu["value"])
+
+    from evo_amd.utils import parallel
+    b = parallel.shard_bounds(cfg["N"], world)  # np.array_split order (evo/utils/parallel.py:102-112)
+    n_loc = int(b[rank + 1] - b[rank])
+    # the same job whatever the number of ranks: one dataset, each rank keeps its block
+    t_setup = time.perf_counter()
+    np.random.seed(1234 + 2)
+    Y = np.ascontiguousarray(np.random.randn(cfg["N"], cfg["D"])[b[rank]:b[rank + 1]])
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    workers = max(1, host_cores() // world)
+    log("data ready (%d x %d); init_states for %d datapoints on %d workers ..." % (n_loc, cfg["D"], n_loc, workers))
+    chunks = list(init_states_packed(cfg, n_loc, 4321 + 100003 * rank, workers, dense=args.dense_states))
+    log("K^n(0) ready")
 
     from evo_amd.engine import Engine
     from evo_amd.models import BSC, SSSC
-    from evo_amd.utils import parallel
 
     eng = Engine()  # LOCAL_RANK selects the GPU
     for kv in args.option:
@@ -196,89 +392,118 @@ def main():
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
     model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17,
                 device_mstep=not args.host_mstep)
-    my_data, theta, suff = make_problem(cfg, 1234 + 2 + 1000 * rank, model, dense=args.dense_states)
-    if world > 1:  # every rank must start from the same Theta (the reference broadcasts rank 0's)
-        theta = {k: comm.bcast(v) for k, v in theta.items()}
+    np.random.seed(99)
+    theta = model.check_params(model.standard_init(my_data))  # data moments all-reduced, W noise broadcast from rank 0
+    suff = ea_suff(cfg)
+    model.attach_resident_states(suff, my_data, chunks)
+    del chunks
+    t_setup = time.perf_counter() - t_setup
+    log("device resident; warm-up %d + timed %d EM iterations ..." % (args.warmup * iters, args.steps * iters))
 
     def barrier():
         eng.synchronize()
         comm.Barrier()
         eng.synchronize()
 
-    F = None
-    for _ in range(args.warmup):
+    F = nu = nsub = None
+    for _ in range(args.warmup * iters):
         F, nu, nsub, theta = model.step(theta, suff, my_data)
-    # Timed region: HIP events only around the roofline kernel (every timed span costs ~10 us of
-    # stream time, so the other classes are measured in a separate instrumented pass below).
-    eng.timing(["lpj_resident"])
+    # Timed region: HIP events only around the two roofline spans (every timed span costs ~10 us of stream
+    # time, so the per-kernel classes are measured in a separate instrumented pass below).
+    eng.timing(["lpj_pass", "stats_pass"])
     eng.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps * iters):
         F, nu, nsub, theta = model.step(theta, suff, my_data)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         dt = comm.allreduce_max(dt)
-    lpj_ms, lpj_n = eng.kernel_time_ms("lpj_resident")
+    log("timed region %.3f s" % dt)
+    lpj_ms, lpj_n = eng.kernel_time_ms("lpj_pass")
+    st_ms, st_n = eng.kernel_time_ms("stats_pass")
+    n_gt2 = float(getattr(model, "last_dpar", {}).get("n_gt2", float("nan")))
     F_timed, nu_timed, nsub_timed = F, nu, nsub
     # instrumented pass (not part of `value`): per-class device time of a few more iterations
-    prof_steps = max(1, min(args.steps, 5))
+    prof_iters = 5
     eng.timing(True)
     eng.timing_reset()
-    for _ in range(prof_steps):
+    for _ in range(prof_iters):
         _F, _nu, _nsub, theta = model.step(theta, suff, my_data)
     barrier()
     kernel_ms = {}
     for name in ("lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse", "vary_kn", "stats", "stats_overflow",
-                 "gemm_f64", "evolve", "misc", "mstep_device"):
+                 "gemm_f64", "evolve", "misc", "mstep_device", "lpj_pass", "stats_pass"):
         avg, n = eng.kernel_time_ms(name)
         if n:
-            kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_step": n / prof_steps}
+            kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_iteration": n / prof_iters}
     eng.timing(False)
     F, nu, nsub = F_timed, nu_timed, nsub_timed
 
     if rank == 0:
-        N_tot = cfg["N"] * world
-        evals = N_tot * cfg["S"] * args.steps
-        alg_bytes = algorithmic_bytes_lpj(cfg, cfg["N"])
-        achieved = (alg_bytes / (lpj_ms * 1e-3) / 1e9) if lpj_ms > 0 else 0.0
+        total_iters = args.steps * iters
+        evals = float(cfg["N"]) * cfg["S"] * total_iters
+        alg_bytes = algorithmic_bytes_pass(cfg, n_loc)  # per launch = this rank's shard
+        lay_bytes = layout_bytes_lpj(cfg, n_loc)
+
+        def roof(ms, launches, kernels, what):
+            ach = (alg_bytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+            return {"bound": "hbm", "kernel": what, "kernels_in_span": kernels,
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(args.config, kernels),
+                    "traffic_note": "HBM bytes per pass, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, read "
+                                    "side corrected for gfx950, summed over the kernels of the span; profiles/r02_*",
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "algorithmic_bytes_note": "SURVEY 8d: N_rank x (D*8 + S*(ceil(H/8) + 8)), states priced bit-packed",
+                    "avg_launch_ms": ms, "launches_timed": launches}
+
+        r_lpj = roof(lpj_ms, lpj_n, pass_kernels(cfg), "whole pass over the resident K^n: lpj of all N x S states "
+                     "(main kernel + every overflow level it spawns), one HIP-event span per pass")
+        r_lpj["states_in_main_kernel"] = (1.0 - n_gt2 / (float(n_loc) * cfg["S"])) if n_gt2 == n_gt2 else None
+        r_lpj["layout_bytes_per_launch"] = lay_bytes
+        r_lpj["frac_of_layout_bytes"] = (lay_bytes / (lpj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpj_ms > 0 else 0.0
+        r_lpj["layout_note"] = ("`achieved` / `frac` price SURVEY 8d's algorithmic bytes (bit-packed states + y_n); the kernels "
+                                "read an 8-byte digest per state and the row of B = Y W instead: frac_of_layout_bytes prices that")
+        if r_lpj["frac"] > 1.0:
+            # at large H the digest layout moves fewer bytes than SURVEY 8d prices: a fraction above 1 says nothing
+            # about the kernel, so the headline fraction becomes the layout one and the other keeps its own name
+            r_lpj["frac_algorithmic_bytes_over_roof"] = r_lpj["frac"]
+            r_lpj["frac"] = r_lpj["frac_of_layout_bytes"]
+            r_lpj["frac_basis"] = "layout bytes (algorithmic-byte pricing exceeds the roof for this layout)"
+        r_st = roof(st_ms, st_n, stats_kernels(cfg), "whole statistics pass over the resident K^n (scatter kernel + overflow "
+                    "levels + column sums + finish; the MFMA contraction is priced under `mfma`)")
         out = {
             "metric": "E-step candidate-state evals/sec (NxS), full EM iteration", "value": evals / dt,
             "unit": "state evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_per_gpu": cfg["N"], "N_total": N_tot,
-                       "D": cfg["D"], "H": cfg["H"], "S": cfg["S"], "ea": "fit/randflip 10 parents x 1 child x 1 gen",
+            "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_total": cfg["N"], "N_rank0": n_loc,
+                       "D": cfg["D"], "H": cfg["H"], "S": cfg["S"],
+                       "step": "%d full EM iterations" % iters, "em_iterations_per_step": iters,
+                       "em_iterations_timed": total_iters, "ms_per_em_iteration": 1e3 * dt / total_iters,
+                       "timed_region_s": dt, "world_size_rccl": comm.size,
+                       "ea": "fit/randflip 10 parents x 1 child x 1 gen",
                        "states": "p_init_Kn=8/H (dense stress variant)" if args.dense_states else "p_init_Kn=1/H (init_states default)",
-                       "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world, "free_energy_last": F,
-                       "S_nunique_last": nu, "S_sub_last": nsub, "kernel_ms": kernel_ms,
-                       "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_steps},
-            "roofline": {"bound": "hbm", "kernel": roofline_kernel(cfg) + " (lpj of all N x S resident states)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.config, roofline_kernel(cfg)),
-                         "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                                         "2 x FETCH + WRITE (gfx950 read-side correction); committed under profiles/",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": lpj_ms,
-                         "launches_timed": lpj_n,
-                         "layout_bytes_per_launch": layout_bytes_lpj(cfg, cfg["N"]),
-                         "frac_of_layout_bytes": (layout_bytes_lpj(cfg, cfg["N"]) / (lpj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpj_ms > 0 else 0.0,
-                         "layout_note": "achieved/frac price SURVEY 8d's algorithmic bytes (bit-packed states, y_n); the kernel "
-                                        "reads an 8-byte digest per state and the B = Y W row instead, so at large H it moves "
-                                        "fewer bytes than that figure and frac can exceed 1; frac_of_layout_bytes prices what "
-                                        "this layout must move"},
+                       "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world,
+                       "sharding": "np.array_split over N (evo/utils/parallel.py:102-112), one packed RCCL all-reduce per iteration",
+                       "free_energy_last": F, "S_nunique_last": nu, "S_sub_last": nsub, "setup_s": round(t_setup, 1),
+                       "kernel_ms": kernel_ms,
+                       "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_iters},
+            "roofline": r_lpj, "roofline_stats": r_st,
         }
         g = kernel_ms.get("gemm_f64")
         if g:
-            t_ms = g["avg_ms"] * g["launches_per_step"]
-            out["mfma"] = {"kernels": "gemm_tn_f64 + gemm_nn_f64 (v_mfma_f64_16x16x4_f64)", "flops_per_step": gemm_flops_per_step(cfg),
-                           "ms_per_step": t_ms, "achieved": gemm_flops_per_step(cfg) / (t_ms * 1e-3) / 1e12,
-                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": gemm_flops_per_step(cfg) / (t_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
+            t_ms = g["avg_ms"] * g["launches_per_iteration"]
+            fl = gemm_flops_per_iteration(cfg, n_loc)
+            out["mfma"] = {"kernels": "gemm_tn_f64 / gemm_tn128_f64 + gemm_nn_f64 (v_mfma_f64_16x16x4_f64)",
+                           "flops_per_iteration": fl, "ms_per_iteration": t_ms,
+                           "achieved": fl / (t_ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": fl / (t_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         comm.Barrier()
         comm.close()

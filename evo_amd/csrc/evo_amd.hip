@@ -43,6 +43,20 @@ static int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                                   \
   } while (0)
 
+// EVOAMD_DEBUG_SYNC=1: synchronise after every launch group and say which one on stderr, so that a GPU fault
+// (the runtime aborts the process at the next synchronisation) is attributed to the kernel that caused it.
+static const bool g_dbg_sync = getenv("EVOAMD_DEBUG_SYNC") != nullptr;
+#define DBG_SYNC(c, what)                                                    \
+  do {                                                                       \
+    if (g_dbg_sync) {                                                        \
+      fprintf(stderr, "[evoamd] %s ...", what);                              \
+      fflush(stderr);                                                        \
+      hipError_t _de = hipStreamSynchronize((c)->stream);                    \
+      fprintf(stderr, " %s\n", hipGetErrorString(_de));                      \
+      fflush(stderr);                                                        \
+    }                                                                        \
+  } while (0)
+
 #define REQUIRE(cond, msg)                                   \
   do {                                                       \
     if (!(cond)) return fail(EVOAMD_E_INVALID, "%s", msg);   \
@@ -359,6 +373,10 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              112 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -596,6 +614,14 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->acc_base, 0, ((size_t)c->ovf_n + c->acc_n + DP_COUNT) * sizeof(double), c->stream));
   HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // masks / reconstructions belong to the previous geometry (their buffers are N x D of THAT shard)
+  if (c->mask_infr) (void)hipFree(c->mask_infr);
+  if (c->mask_x) (void)hipFree(c->mask_x);
+  if (c->Yrec) (void)hipFree(c->Yrec);
+  c->mask_infr = c->mask_x = nullptr;
+  c->Yrec = nullptr;
+  c->yrec_valid = c->rec_in_stats = false;
+  c->rel_frac = -1.0;
   c->configured = true;
   c->pays_agreed = -1;
   c->pending_skip = 0;
@@ -984,8 +1010,10 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   }
   int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
   if (r) return r;
+  DBG_SYNC(c, "set_params_sssc: G = W^T W");
   sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
                                                                      c->PT, c->GP, c->DG);
+  DBG_SYNC(c, "set_params_sssc: tables");
   if (c->mask_infr) {  // incomplete data: the per-datapoint Gram blocks read W^T
     if (!c->Wt) ALLOC(c->Wt, (size_t)H * D);
     transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->W, D, H, c->Wt);
@@ -1009,6 +1037,7 @@ static int ensure_B(evoamd_ctx *c) {
   if (c->B_valid || (c->model == EVOAMD_MODEL_BSC && c->bsc_direct)) return 0;
   int r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
   if (r) return r;
+  DBG_SYNC(c, "B = Y W");
   c->B_valid = true;
   return 0;
 }
@@ -1233,24 +1262,30 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     } else
       sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "sssc lpj main");
   }
   if (need[0] || need[1] || need[2]) {
     SpanGuard g(c, KID_LPJ_OVF);
+    // the levels carry the pass's TAG in their names, so a kernel trace separates the pass over K^n from the
+    // candidate batch level by level
     if (need[0])
-      sssc_small_kernel<4, 0, 2, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
+      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
+    DBG_SYNC(c, "sssc lpj K=4 level");
     const ListOut none_out = {nullptr, nullptr, 0};
     if (use_k8_kernel(c, TAG)) {
       if (need[1])
-        sssc_small_kernel<8, 0, 2, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
+        sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
     } else if (need[1]) {
       // a few thousand states above 4 active latents: the wavefront-per-state kernel, sized for k <= 8
       // (1.9 KiB of LDS, many workgroups per CU); anything denser moves on to list 3
-      sssc_big_kernel<0><<<level_grid(c, 1, TAG, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(a, i2, o3, 8);
+      sssc_big_kernel<0, TAG><<<level_grid(c, 1, TAG, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(a, i2, o3, 8);
     }
+    DBG_SYNC(c, "sssc lpj K=8 level");
     if (need[2])
-      sssc_big_kernel<0><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+      sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
           a, i3, none_out, SSSC_KCAP);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "sssc lpj wavefront level");
   }
   return 0;
 }
@@ -1519,6 +1554,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
 #undef VK_LAUNCH
     reduce3_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(c->N, 4), c->dpar);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "vary_kn");
     c->rows_fresh = true;
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;  // vary_kn zeroed the overflow counters
     if (c->lists_clean) c->pending_skip = 0;          // ... and checked the skipped levels of the chain before it
@@ -1560,6 +1596,7 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
     else EV_LAUNCH(16);
 #undef EV_LAUNCH
     HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "evolve");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
     if (c->lists_clean) c->pending_skip = 0;
     c->cand_from_device = true;
@@ -1686,6 +1723,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
 #undef BSC_STATS
       HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "bsc stats");
     }
     {
       SpanGuard g(c, KID_MISC);
@@ -1774,6 +1812,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
         }
         HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "sssc stats main");
       }
       if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
@@ -1791,6 +1830,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
               sa, i3, none_out, SSSC_KCAP);
         HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "sssc stats overflow levels");
       }
       // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
       // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
@@ -1807,6 +1847,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                                                  c->acc + a.y2, D, sa.xss_o, sa.xszsz_o,
                                                                  masked ? nullptr : c->PT);
       HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "sssc colsum + finish");
     }
     pass.reset();
     // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
@@ -1840,6 +1881,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
                                           c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped);
     HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "stats contraction + tail");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
     if (c->lists_clean) c->pending_skip = 0;
     if (c->model == EVOAMD_MODEL_SSSC && c->mask_infr) {  // tail[7] = sum over reliable entries of y_hat^2
@@ -2215,6 +2257,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   note_levels(c, c->h_dpar);
   c->h_theta_fresh = learn_mask != 0 && c->h_dpar[DP_STATUS] == 0.0;
   if (c->h_dpar[DP_STATUS] != 0.0) {
+    dpar_out[DP_STATUS] = c->h_dpar[DP_STATUS];  // 1 singular, 2 non-finite: the caller may finish the step on the host
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
     // the refresh and the prefetched pass behind the mailbox ran with the failed update's Theta: drop the pass and
     // the clamp flags it may have raised (the caller re-installs a Theta before anything else is evaluated)

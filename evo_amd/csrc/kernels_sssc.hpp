@@ -762,7 +762,9 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 // kc = 8, 98 KiB at kc = 64); pairs above kc go to `lo` (or raise EVOAMD_E_KLIMIT when there is no
 // further level).  G_A and Psi_A are gathered into LDS once (k^2 parallel 16-byte gathers), so the
 // T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
-template <int MODE>
+// TAG as in sssc_small_kernel: profilers then list the levels of the pass over K^n (0), of the candidate batch (1)
+// and everything else (2) under different names.
+template <int MODE, int TAG = 2>
 __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc) {
   a.s2inv = a.dpar[DP_S2INV];
   // every barrier below orders LDS traffic only (the k x k system lives in LDS): lds_barrier() does not

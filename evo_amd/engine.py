@@ -39,6 +39,7 @@ class Engine:
         self.model = None
         self.N = self.D = self.H = self.S = self.S_perm = self.Cmax = 0
         self.ljc = None
+        self.has_masks = False
         self.world = 1
         self.rank = 0
 
@@ -66,6 +67,7 @@ class Engine:
         check(self.lib.evoamd_configure(self._h, self.model, int(N), int(D), int(H), int(S), int(S_perm), int(Cmax)))
         self.N, self.D, self.H, self.S, self.S_perm, self.Cmax = int(N), int(D), int(H), int(S), int(S_perm), int(Cmax)
         self.L = self.S + self.S_perm
+        self.has_masks = False  # evoamd_configure drops the masks of the previous geometry
 
     def same_geometry(self, model, N, D, H, S, S_perm, Cmax):
         m = MODEL_BSC if model in (MODEL_BSC, "bsc", "BSC") else MODEL_SSSC
@@ -180,7 +182,9 @@ class Engine:
         """EBSC incomplete data: reliable entries x_infr (N, D) and keep-mask x (default x_infr); None clears."""
         if x_infr is None:
             check(self.lib.evoamd_upload_masks(self._h, None, None))
+            self.has_masks = False
             return
+        self.has_masks = True
         mi = as_bool_bytes(x_infr)
         mx = as_bool_bytes(x_infr if x is None else x)
         assert mi.shape == (self.N, self.D) and mx.shape == (self.N, self.D)
@@ -233,7 +237,8 @@ class Engine:
         d = {k: dpar[i] for k, i in self.DPAR.items()}
         # ljc of the Theta the E-step ran with: the update kernels move it to ljc_prev
         d["ljc_estep"] = d["ljc_prev"] if mask else d["ljc"]
-        if rc == -6 and d["status"] == 1.0:  # EVOAMD_E_SINGULAR from the Theta update (tail / dpar were delivered)
+        if rc == -6 and d["status"] in (1.0, 2.0):  # EVOAMD_E_SINGULAR from the Theta update: exactly singular H x H
+            # system, or one so ill-conditioned that the update went non-finite (tail / dpar were delivered)
             raise SingularUpdate(self.lib.evoamd_last_error().decode(), dict(zip(TAIL, tail)), d)
         check(rc)
         return dict(zip(TAIL, tail)), d

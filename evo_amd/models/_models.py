@@ -179,7 +179,7 @@ class Model:
             if self._incomplete:
                 eng.upload_masks(xi, my_data.get("x"))
                 self._yrec_token = None
-            elif self._had_masks:
+            elif self._had_masks or eng.has_masks:  # this model's own, or another model's on a shared engine
                 eng.upload_masks(None)
                 eng.upload_data(Y)
             self._had_masks = self._incomplete
@@ -302,6 +302,7 @@ class Model:
         my_suff_stat["reset_lpj_isinf"] = int(tail["reset_isinf"])
         model_params.update(self._pull_params(dpar))
         self._dev_theta = model_params
+        self.last_dpar = dpar  # scalar block of the update (engine.Engine.DPAR): n_gt2 / n_gt4 / n_gt8 = overflow census of K^n
         N = tail["N"]
         return dpar["ljc_estep"] + tail["Fs"] / N, tail["sum_nunique"] / N, tail["sum_sub"] / N, model_params
 

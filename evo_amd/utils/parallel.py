@@ -196,18 +196,35 @@ class RcclComm:
         self.engine.comm_destroy()
 
 
+def _parent_start_time():
+    """Start time (clock ticks since boot) of the parent process: with the parent pid it names ONE launcher
+    process, so a recycled (MASTER_PORT, ppid) pair of an earlier launch cannot match a stale file."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            return f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
+def rendezvous_path(tag=None):
+    if tag is None:
+        tag = "%s_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                               os.environ.get("EVO_AMD_LAUNCH_NONCE") or _parent_start_time(),
+                               os.environ.get("TORCHELASTIC_RUN_ID", "none"))
+    return os.path.join(os.environ.get("EVO_AMD_RDZV_DIR", "/tmp"), "evo_amd_rccl_%s.id" % tag)
+
+
 def rendezvous_unique_id(rank, size, make_id, tag=None, timeout_s=300.0):
     """Share rank 0's RCCL unique id with the other local ranks through a file.
 
-    One node, one process per GPU (the bench contract): the launcher (torchrun) gives every
-    rank the same MASTER_PORT and the same parent pid, which together name the rendezvous file
-    under /tmp.  Rank 0 writes the id atomically (temp file + rename); the others poll."""
+    One node, one process per GPU (the bench contract): the launcher (torchrun, or bench.py's own
+    launch_ranks) gives every rank the same MASTER_PORT and the same parent process, which together name
+    the rendezvous file under /tmp (plus a per-launch nonce / the parent's start time, so a file left by an
+    earlier launch can never match).  Rank 0 writes the id atomically (temp file + rename); the others
+    poll; init_rccl_from_env removes the file once every rank is in the communicator."""
     if size == 1:
         return make_id()
-    if tag is None:
-        tag = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
-                            os.environ.get("TORCHELASTIC_RUN_ID", "none"))
-    path = os.path.join(os.environ.get("EVO_AMD_RDZV_DIR", "/tmp"), "evo_amd_rccl_%s.id" % tag)
+    path = rendezvous_path(tag)
     if rank == 0:
         uid = make_id()
         tmp = path + ".tmp.%d" % os.getpid()
@@ -236,4 +253,11 @@ def init_rccl_from_env(engine):
     if size == 1:
         return SerialComm()
     uid = rendezvous_unique_id(rank, size, engine.comm_unique_id)
-    return RcclComm(engine, rank, size, uid)
+    comm = RcclComm(engine, rank, size, uid)
+    comm.Barrier()  # every rank has read the id file by now
+    if rank == 0:
+        try:
+            os.unlink(rendezvous_path())
+        except OSError:
+            pass
+    return comm
