@@ -351,7 +351,8 @@ def main():
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # bare `bench.py --gpus N`: this parent never initialises HIP; it only starts the ranks and relays rank 0
-        rc, out = launch_ranks(args.gpus, sys.argv[1:])
+        stub = os.environ.get("EVO_AMD_BENCH_WORKER")  # tests: a stand-in rank program (no GPU)
+        rc, out = launch_ranks(args.gpus, sys.argv[1:], worker=[sys.executable, stub] if stub else None)
         sys.stdout.write(out)
         sys.stdout.flush()
         sys.exit(rc)

@@ -14,9 +14,8 @@ satisfies, so a reference user can keep passing their communicator:
     comm.Barrier()
 
 ``SerialComm``      one rank (default).
-``TorchDistComm``   host-side sums over a torch.distributed process group (gloo on CPU); used by
-                    the CPU multi-process tests and usable as a fallback transport.  PyTorch is
-                    imported lazily and only by this class.
+(A gloo transport with the same surface lives in tests/_torch_comm.py: the CPU multi-process tests use it;
+nothing under evo_amd/ imports PyTorch.)
 ``RcclComm``        RCCL through libevo_amd: the device accumulator is reduced in place by
                     ``evoamd_stats``; host scalars go through a tiny device bounce buffer.
 """
@@ -121,38 +120,6 @@ class SerialComm:
 
     def allreduce_array(self, a):
         return a
-
-
-class TorchDistComm:
-    """Sums over an initialised torch.distributed group.  Host tensors (gloo)."""
-    device_reduces = False
-
-    def __init__(self, group=None):
-        import torch.distributed as dist  # lazy: PyTorch is plumbing for this transport only
-        self._dist = dist
-        self._group = group
-        self.rank = dist.get_rank(group)
-        self.size = dist.get_world_size(group)
-
-    def allreduce_array(self, a):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
-        return t.numpy()
-
-    def allreduce(self, value, op=None):
-        if isinstance(value, np.ndarray):
-            return self.allreduce_array(value).reshape(value.shape)
-        out = self.allreduce_array(np.array([value], dtype=np.float64))[0]
-        return type(value)(out) if isinstance(value, (int, np.integer)) else float(out)
-
-    def bcast(self, value, root=0):
-        box = [value]
-        self._dist.broadcast_object_list(box, src=root, group=self._group)
-        return box[0]
-
-    def Barrier(self):
-        self._dist.barrier(group=self._group)
 
 
 class RcclComm:

@@ -92,7 +92,8 @@ int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 int evoamd_configure(evoamd_ctx *ctx, int model, int64_t N, int D, int H, int S, int S_perm,
                      int Cmax);
 
-/* my_data["y"] (N,D) float64, complete data (x_infr all True; SURVEY 8 scope). */
+/* my_data["y"] (N,D) float64.  Missing entries may hold NaN: evoamd_upload_masks (below) then tells the library
+ * which entries are reliable (my_data["x_infr"]) and zeroes the others in the device copy. */
 int evoamd_upload_data(evoamd_ctx *ctx, const double *Y);
 /* my_suff_stat["ss"] (N,S,H) bool <-> device K^n (bit-packed on the device). */
 int evoamd_upload_states(evoamd_ctx *ctx, const uint8_t *ss_bool);
@@ -181,8 +182,13 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * GPU and installs the result as the context's current parameters.  learn_mask bits: 1 W, 2 pies
  * (BSC: pi), 4 mus, 8 sigma2 (BSC: sigma), 16 Psi; 0 = statistics only.  tail_out[8] = accumulator
  * tail, dpar_out[16] = scalar block of the NEW Theta (kernels_mstep.hpp: DP_*; [8] = ljc of the Theta
- * the E-step used when learn_mask != 0, else [3] is).  The H x H systems are solved by Gauss-Jordan with partial
- * pivoting; an exactly singular system returns EVOAMD_E_SINGULAR (the reference: pinv / lstsq). */
+ * the E-step used when learn_mask != 0, else [3] is).  The H x H systems (Gram-type moment matrices) are inverted by
+ * block Gauss-Jordan with the 16 / 32-column diagonal blocks as pivots (options "inverse_spd", "inverse_block"); a
+ * pivot block that is not safely positive repeats the update with the partially pivoted elimination.  An exactly
+ * singular system -- or one so ill-conditioned that Theta^new is not finite -- returns EVOAMD_E_SINGULAR with
+ * tail_out / dpar_out filled in (dpar_out[7] = 1 singular, 2 non-finite): the E-step results stand, Theta on the device is
+ * invalid, and the caller finishes the step with the reference's lstsq / pinv fallbacks (bsc.py:236-250,
+ * sssc.py:692-708; evo_amd.models does) and installs a Theta with evoamd_set_params_*. */
 int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, double *dpar_out);
 /* Incomplete data (examples/image-inpainting/main.py:105-111); EBSC as described, ES3C:
  * every state goes through the wavefront kernel, which forms G_A = W_obs^T W_obs of its datapoint
@@ -195,8 +201,8 @@ int evoamd_mstep_device(evoamd_ctx *ctx, int learn_mask, double *tail_out, doubl
  * datapoint).  The M-step's Wp contraction reads y_reconstructed (bsc.py:184-189): either
  * evoamd_set_option(ctx, "reconstruct_in_stats", 1) before evoamd_stats (it then forms
  * y_hat = Es W^T and y_rec = x ? y : y_hat first; fetch y_hat with evoamd_reconstruct), or hand over an
- * older one with evoamd_upload_yrec.  x_infr == NULL returns to complete data (upload Y again).  The
- * Theta update for incomplete data stays on the host (evoamd_mstep_device refuses). */
+ * older one with evoamd_upload_yrec.  x_infr == NULL returns to complete data (upload Y again); evoamd_configure
+ * drops the masks too.  evoamd_mstep_device handles incomplete data once evoamd_set_reliable_fraction was called. */
 int evoamd_upload_masks(evoamd_ctx *ctx, const uint8_t *x_infr, const uint8_t *x);
 int evoamd_upload_yrec(evoamd_ctx *ctx, const double *y_reconstructed);
 /* Incomplete data with the device Theta update (evoamd_mstep_device): the mean number of reliable
@@ -253,13 +259,13 @@ int evoamd_comm_destroy(evoamd_ctx *ctx);
 /* Kernel-class ids for evoamd_kernel_time_ms: average device time per launch since the last
  * evoamd_timing_reset, measured with hipEvents recorded on the stream the kernels run on. */
 enum {
-  EVOAMD_K_LPJ_RESIDENT = 0,   /* bsc_lpj_kernel / sssc_small_kernel<4,0> on K^n (N x S)   */
-  EVOAMD_K_LPJ_CANDIDATES = 1, /* the same kernels on the candidate batch                  */
-  EVOAMD_K_LPJ_OVERFLOW = 2,   /* ES3C states with k > 4 (register K=8 + LDS wave kernels)  */
-  EVOAMD_K_ROW_LSE = 3,        /* free energy / posterior normalisers                      */
+  EVOAMD_K_LPJ_RESIDENT = 0,   /* main lpj kernel on K^n (N x S): bsc_lpj_gram2_kernel / sssc_main_lpj_kernel (|s| <= 2) */
+  EVOAMD_K_LPJ_CANDIDATES = 1, /* main lpj kernel on the candidate batch                                                  */
+  EVOAMD_K_LPJ_OVERFLOW = 2,   /* ES3C states with |s| > 2: K=4 / K=8 register kernels + LDS wavefront kernel (any batch)   */
+  EVOAMD_K_ROW_LSE = 3,        /* free energy / posterior normalisers when vary_kn did not leave them behind              */
   EVOAMD_K_VARY_KN = 4,
-  EVOAMD_K_STATS = 5,          /* bsc_stats_kernel / sssc_small_kernel<4,1>                 */
-  EVOAMD_K_STATS_OVERFLOW = 6,
+  EVOAMD_K_STATS = 5,          /* bsc_stats_kernel / sssc_stats_kernel (|s| <= 2)                                          */
+  EVOAMD_K_STATS_OVERFLOW = 6, /* ES3C statistics of the states with |s| > 2                                              */
   EVOAMD_K_GEMM = 7,           /* f64 MFMA contractions                                     */
   EVOAMD_K_EVOLVE = 8,
   EVOAMD_K_MISC = 9,

@@ -22,7 +22,8 @@ def main():
     from evo_amd.models import BSC, SSSC
     from evo_amd.utils import parallel
 
-    comm = parallel.TorchDistComm()
+    from _torch_comm import TorchDistComm
+    comm = TorchDistComm()
     g = load_golden("step_%s.npz" % fixture)
     bsc = str(g["algo"]) == "ebsc"
     D, H, S = int(g["D"]), int(g["H"]), int(g["S"])

@@ -234,6 +234,7 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("oracle/", ""), f
+                assert "import torch" not in src and "from torch" not in src, f + " imports PyTorch"
     lib = _lib.load()
     cnt = ctypes.c_int(-1)
     rc = lib.evoamd_device_count(ctypes.byref(cnt))
@@ -260,6 +261,55 @@ def test_rendezvous_file_roundtrip(tmp_path, monkeypatch):
     assert parallel.rendezvous_unique_id(0, 1, lambda: uid) == uid  # single rank: no file
     with pytest.raises(TimeoutError):
         parallel.rendezvous_unique_id(1, 2, lambda: b"", tag="never", timeout_s=0.2)
+
+
+def test_rendezvous_tag_is_per_launch(monkeypatch):
+    """A (MASTER_PORT, parent pid) pair recurs in a container with a persistent /tmp: the file name also carries
+    a per-launch nonce (bench.py's launcher) or the parent's start time, so a stale id file cannot match."""
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setenv("EVO_AMD_LAUNCH_NONCE", "a")
+    pa = parallel.rendezvous_path()
+    monkeypatch.setenv("EVO_AMD_LAUNCH_NONCE", "b")
+    assert parallel.rendezvous_path() != pa
+    monkeypatch.delenv("EVO_AMD_LAUNCH_NONCE")
+    assert parallel._parent_start_time() not in ("", "0") and parallel._parent_start_time() in parallel.rendezvous_path()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`bench.py --gpus N` without a launcher: the parent starts N children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, relays rank 0's stdout and propagates a failing rank's exit code -- checked with a stub
+    worker (no GPU); the parent itself must never import the engine."""
+    import subprocess
+    import sys
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0 and os.environ['EVO_AMD_LAUNCH_NONCE']\n"
+        "if '--fail' in sys.argv and r == w - 1: sys.exit(3)\n"
+        "if r == 0: print(json.dumps({'n_gpus': w, 'argv': sys.argv[1:]}))\n")
+    rc, out = bench.launch_ranks(3, ["--steps", "2"], worker=[sys.executable, str(stub)], timeout_s=60)
+    assert rc == 0
+    import json
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line == {"n_gpus": 3, "argv": ["--steps", "2"]}
+    rc, _ = bench.launch_ranks(2, ["--fail"], worker=[sys.executable, str(stub)], timeout_s=60)
+    assert rc == 3
+    # the bare command line goes through the same function and never touches the GPU in the parent
+    env = dict(os.environ, EVO_AMD_BENCH_WORKER=str(stub))
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+
+
+def test_bench_host_cores_respects_cgroup_quota():
+    import bench
+    n = bench.host_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
 
 
 def test_scatter_gather_single_rank():
