@@ -54,6 +54,8 @@ SIGNATURES = {
     "evoamd_lpj_single": (_I, [_vp, _c_dp, _c_u8p, _I, _c_dp, _c_i32p]),
     "evoamd_vary_kn": (_I, [_vp, _I, _c_dp]),
     "evoamd_evolve_randflip": (_I, [_vp, _I, _I, _U64, _I]),
+    "evoamd_evolve_states": (_I, [_vp, _I, _I, _I, _I, _I, _U64, _DBL, _DBL]),
+    "evoamd_download_candidates": (_I, [_vp, _c_u8p, _c_i32p, _c_dp]),
     "evoamd_acc_size": (_I64, [_vp]),
     "evoamd_stats": (_I, [_vp, _c_dp]),
     "evoamd_mstep_device": (_I, [_vp, _I, _c_dp, _c_dp]),

@@ -197,6 +197,10 @@ struct evoamd_ctx {
   double *lpj_alt = nullptr;  // target of the prefetched pass; swapped with lpj when it is consumed (the rows of the
                               // E-step that just ended stay readable until then: sync_to_host, download_lpj)
   int *cand_counts = nullptr;
+  // general device EA (evolve_general_kernel): raw children of a generation, first slot of the last generation,
+  // "this known state was duplicated by a child" bits; allocated on first use
+  u64 *cand_raw = nullptr, *dupold = nullptr;
+  int *gen_start = nullptr;
   unsigned *flags = nullptr;  // 3 x N: resident | candidates | permanent
   double *rowmax = nullptr, *rowsum = nullptr, *partial = nullptr, *partial2 = nullptr, *diag = nullptr;
   i64 n_partial = 0;
@@ -391,7 +395,7 @@ static void free_all(evoamd_ctx *c) {
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
-                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt};
+                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -622,6 +626,11 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->Yrec = nullptr;
   c->yrec_valid = c->rec_in_stats = false;
   c->rel_frac = -1.0;
+  if (c->cand_raw) (void)hipFree(c->cand_raw);  // sized by the geometry: rebuilt on demand (evoamd_evolve_states)
+  if (c->dupold) (void)hipFree(c->dupold);
+  if (c->gen_start) (void)hipFree(c->gen_start);
+  c->cand_raw = c->dupold = nullptr;
+  c->gen_start = nullptr;
   c->configured = true;
   c->pays_agreed = -1;
   c->pending_skip = 0;
@@ -1604,6 +1613,85 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
   int r = eval_candidates(c);
   if (r) return r;
   c->have_cand = true;
+  return 0;
+}
+
+extern "C" int evoamd_evolve_states(evoamd_ctx *c, int mutation, int fit_parents, int n_parents, int n_children,
+                                    int n_generations, uint64_t seed, double sparseness, double bitflip_prob) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(mutation >= EV_RANDFLIP && mutation <= EV_CROSS_SPARSEFLIP, "unknown mutation operator");
+  REQUIRE(n_parents >= 1 && n_parents <= c->S && n_parents <= 64, "n_parents must be in [1, min(S, 64)]");
+  REQUIRE(n_generations >= 1, "n_generations must be positive");
+  const bool crossing = mutation >= EV_CROSS;
+  const int per_gen = crossing ? n_parents * (n_parents - 1) : n_parents * n_children;
+  REQUIRE(crossing || (n_children >= 1 && n_children <= c->H), "n_children must be in [1, H]");
+  REQUIRE(mutation != EV_RANDFLIP || n_children <= EV_MAX_CHILDREN, "randflip: n_children must be <= 8");
+  REQUIRE((i64)per_gen * n_generations <= c->Cmax, "children per generation x generations exceeds the configured Cmax");
+  REQUIRE(c->S <= EVG_MAX_S && c->Cmax <= EVG_MAX_C, "S <= 1024 and Cmax <= 256");
+  const bool sparse = mutation == EV_SPARSEFLIP || mutation == EV_CROSS_SPARSEFLIP;
+  REQUIRE(!sparse || bitflip_prob == bitflip_prob, "sparseflip needs bitflip_prob (eas.py:69)");
+  REQUIRE(!crossing || c->H >= 2, "crossover needs H >= 2");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->cand_raw) {
+    ALLOC(c->cand_raw, (size_t)c->N * c->Cmax * c->HW);
+    ALLOC(c->dupold, (size_t)c->N * EVG_FLAGW);
+    ALLOC(c->gen_start, (size_t)c->N);
+  }
+  EvolveArgs a = {};
+  a.states = c->states;
+  a.dig = c->use_digest ? c->dig : nullptr;
+  a.lpj = c->lpj;
+  a.cand = c->cand;
+  a.cand_dig = c->cand_dig;
+  a.cand_lpj = c->cand_lpj;
+  a.raw = c->cand_raw;
+  a.counts = c->cand_counts;
+  a.gen_start = c->gen_start;
+  a.dupold = c->dupold;
+  a.N = c->N;
+  a.S = c->S;
+  a.S_perm = c->S_perm;
+  a.H = c->H;
+  a.HW = c->HW;
+  a.Cmax = c->Cmax;
+  a.n_parents = n_parents;
+  a.n_children = n_children;
+  a.kind = mutation;
+  a.fit_parents = fit_parents;
+  a.seed = seed;
+  a.sparseness = sparseness;
+  a.p_bf = bitflip_prob;
+  for (int g = 0; g < n_generations; g++) {
+    a.gen = g;
+    {
+      SpanGuard sg(c, KID_EVOLVE);
+      evolve_general_kernel<<<(unsigned)c->N, 64, 0, c->stream>>>(a);
+      HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "evolve (general)");
+    }
+    // children may differ from every resident state in many bits: no shortcut for the overflow levels
+    c->cand_from_device = false;
+    int r = eval_candidates(c);  // the next generation's pool needs these lpj (eas.py:264)
+    if (r) return r;
+  }
+  c->have_cand = true;
+  return 0;
+}
+
+extern "C" int evoamd_download_candidates(evoamd_ctx *c, uint8_t *cand_bool, int32_t *counts, double *lpj) {
+  REQUIRE(c && c->configured && c->have_cand, "no resident candidate batch");
+  REQUIRE(cand_bool && counts && lpj, "NULL output");
+  HIP_TRY(hipSetDevice(c->device));
+  const i64 ns = c->N * (i64)c->Cmax;
+  int r = ensure_stage(c, (size_t)ns * c->H);
+  if (r) return r;
+  unpack_states_kernel<<<cdiv(ns * c->H, 256), 256, 0, c->stream>>>(c->cand, c->stage, ns, c->H, c->HW);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(cand_bool, c->stage, (size_t)ns * c->H, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(counts, c->cand_counts, (size_t)c->N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(lpj, c->cand_lpj, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (c->model == EVOAMD_MODEL_SSSC) return check_err(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -208,6 +208,23 @@ class Engine:
         check(self.lib.evoamd_evolve_randflip(self._h, int(n_parents), int(n_children), int(seed) & (2 ** 64 - 1),
                                               1 if fit_parents else 0))
 
+    MUTATIONS = {"randflip": 0, "sparseflip": 1, "cross": 2, "cross_randflip": 3, "cross_sparseflip": 4}
+
+    def evolve_states(self, mutation, n_parents, n_children, n_generations, seed, fit_parents=True, sparseness=0.0,
+                      bitflip_prob=None):
+        """All EA operators / generations on the device (eas.py:153-313); fills and evaluates the candidate batch."""
+        check(self.lib.evoamd_evolve_states(self._h, self.MUTATIONS[mutation], 1 if fit_parents else 0, int(n_parents),
+                                            int(n_children), int(n_generations), int(seed) & (2 ** 64 - 1),
+                                            float(sparseness), float("nan") if bitflip_prob is None else float(bitflip_prob)))
+
+    def download_candidates(self):
+        """(cand bool (N,Cmax,H), counts (N,), lpj (N,Cmax)) of the resident candidate batch."""
+        cand = np.empty((self.N, self.Cmax, self.H), dtype=np.bool_)
+        counts = np.empty(self.N, dtype=np.int32)
+        lpj = np.empty((self.N, self.Cmax))
+        check(self.lib.evoamd_download_candidates(self._h, u8ptr(cand.view(np.uint8)), i32ptr(counts), dptr(lpj)))
+        return cand, counts, lpj
+
     def set_estep_counts(self, sum_nunique, sum_sub):
         check(self.lib.evoamd_set_estep_counts(self._h, float(sum_nunique), float(sum_sub)))
 

@@ -281,7 +281,7 @@ class Model:
         if self.rng == "reference":
             self._candidates_reference(eng, model_params, my_suff_stat, my_data)
         else:
-            self._candidates_device(eng, my_suff_stat)
+            self._candidates_device(eng, my_suff_stat, model_params)
         eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
         self._n_steps += 1
         if self._incomplete and do_reconstruction:
@@ -476,12 +476,24 @@ class Model:
             cand_lpj[n, :new.shape[0]] = new_lpj
         eng.set_candidates(cand, counts, cand_lpj)
 
-    def _candidates_device(self, eng, my_suff_stat):
-        if my_suff_stat["mutation_algorithm"] is not eas.randflip or my_suff_stat["n_generations"] != 1:
-            raise NotImplementedError("rng='device' implements randflip with one generation (the examples' default)")
+    _MUTATION_NAMES = {eas.randflip: "randflip", eas.sparseflip: "sparseflip", eas.cross: "cross",
+                       eas.cross_randflip: "cross_randflip", eas.cross_sparseflip: "cross_sparseflip"}
+
+    def _candidates_device(self, eng, my_suff_stat, model_params):
+        """evolve_states (eas.py:153-313) on the device, every operator and any number of generations."""
+        mut = my_suff_stat["mutation_algorithm"]
+        if mut not in self._MUTATION_NAMES:
+            raise NotImplementedError("rng='device' knows the reference's five mutation operators; got %r" % (mut,))
         fit = my_suff_stat["parent_selection"] is eas.fitparents
+        if not fit and my_suff_stat["parent_selection"] is not eas.randparents:
+            raise NotImplementedError("rng='device' knows fitparents and randparents")
         seed = (self.seed * 1000003 + self._n_steps) * max(1, self.comm.size) + self.comm.rank
-        eng.evolve_randflip(min(my_suff_stat["n_parents"], self.S), my_suff_stat["n_children"], seed, fit)
+        n_par = min(my_suff_stat["n_parents"], self.S)
+        if mut is eas.randflip and my_suff_stat["n_generations"] == 1 and my_suff_stat["n_children"] <= 8:
+            eng.evolve_randflip(n_par, my_suff_stat["n_children"], seed, fit)  # the examples' default: fast path
+        else:
+            eng.evolve_states(self._MUTATION_NAMES[mut], n_par, my_suff_stat["n_children"], my_suff_stat["n_generations"],
+                              seed, fit, float(model_params["piH"]), my_suff_stat["bitflip_prob"])
 
     def E_step(self, model_params, my_suff_stat, my_data, _keep_acc=False, _reconstruct=False):
         """New variational states, their lpj, K^n update and the free energy (_models.py:453-565).
@@ -493,7 +505,7 @@ class Model:
         if self.rng == "reference":
             self._candidates_reference(eng, model_params, my_suff_stat, my_data)
         else:
-            self._candidates_device(eng, my_suff_stat)
+            self._candidates_device(eng, my_suff_stat, model_params)
         eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
         self._n_steps += 1
         if self._incomplete and _reconstruct:

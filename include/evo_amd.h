@@ -164,6 +164,23 @@ int evoamd_vary_kn(evoamd_ctx *ctx, int Mprime, double *sums_out);
 int evoamd_evolve_randflip(evoamd_ctx *ctx, int n_parents, int n_children, uint64_t seed,
                            int fit_parents);
 
+/* Every operator of the reference's evolutionary algorithm on the device, any number of generations
+ * (evolve_states eas.py:153-313): mutation 0 randflip (eas.py:10-43), 1 sparseflip (:46-100), 2 cross (:103-125),
+ * 3 cross_randflip, 4 cross_sparseflip (:128-135); fit_parents 1 fitparents (:138-146) / 0 randparents (:149-150);
+ * sparseness = model_params["piH"], bitflip_prob as in my_suff_stat (NaN when unused).  Per generation: parents from
+ * K^n (generation 0) or from the previous generation's new states plus the known states its children duplicated --
+ * with the lpj pairing of eas.py:284-293 as written (off by one when S_perm = 0) --, mutation, de-duplication against
+ * [incl; K^n; earlier new states], lpj of the survivors.  The resident candidate batch then holds what
+ * evolve_states returns (new_states[new_and_unique], lexicographic within a generation) for evoamd_vary_kn;
+ * n_children_per_generation x n_generations <= Cmax.  Counter-based RNG as in evoamd_evolve_randflip, which stays
+ * the fast path for randflip with one generation. */
+int evoamd_evolve_states(evoamd_ctx *ctx, int mutation, int fit_parents, int n_parents, int n_children,
+                         int n_generations, uint64_t seed, double sparseness, double bitflip_prob);
+/* The resident candidate batch back to the host in the reference's layout: cand_bool (N,Cmax,H) bool bytes,
+ * counts (N), lpj (N,Cmax) -- rows >= counts[n] are unspecified.  What evolve_states hands to vary_Kn
+ * (eas.py:313), for callers that keep the reference's two-call structure, and for the distribution tests. */
+int evoamd_download_candidates(evoamd_ctx *ctx, uint8_t *cand_bool, int32_t *counts, double *lpj);
+
 /* ---- M-step sufficient statistics + free energy ------------------------------------- */
 /* Number of doubles in the packed accumulator for the configured model:
  *   BSC : Wp (H,D) | Wq (H,H) | pies (H) | sigma | tail[8]
