@@ -142,6 +142,16 @@ struct evoamd_ctx {
   double rel_frac = -1.0;  // EBSC incomplete data: sum(x_infr) / N over all ranks (evoamd_set_reliable_fraction)
   bool ar_gemm_pending = false;  // with a communicator: the contraction's block of acc is all-reduced at the join
   int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
+  int stats_chunks = 1;  // option "stats_chunks": the statistics pass runs in this many blocks of datapoints, the MFMA
+                         // contraction of block i on the second stream beside the scatter kernels of block i + 1.
+                         // Measured at the north-star shape (N = 100k, H = 512): 1 block 5.47 ms per iteration, 2 blocks
+                         // 5.61, 4 blocks 5.68-5.88, 8 blocks 5.99 -- both kernels live on the memory-side f64 atomic
+                         // units (the contraction's split-K epilogue issues 36 M of them) and they time-slice the CUs
+                         // instead of overlapping; off by default
+  int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
+  double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
+  double *census = nullptr;  // 4 doubles: overflow census of the earlier blocks of a chunked statistics pass
+  hipEvent_t ev_chunk[16] = {};
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
   // which ES3C overflow levels (K=4, K=8, LDS) the next pass over K^n needs; exact, from the
   // counters of the last statistics pass (dpar[DP_NGT*]); unknown -> all
@@ -375,6 +385,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+  HIP_TRY(hipMalloc((void **)&c->census, 4 * sizeof(double)));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -421,6 +433,9 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (int i = 0; i < 16; i++)
+    if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
+  if (c->census) (void)hipFree(c->census);
   delete c;
 }
 
@@ -451,6 +466,15 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "overlap_gemm") == 0) {
     c->overlap_gemm = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_per_xcd") == 0) {
+    c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "stats_chunks") == 0) {
+    if (value < 1 || value > 16) return fail(EVOAMD_E_INVALID, "stats_chunks: 1 .. 16");
+    c->stats_chunks = value;
     return 0;
   }
   if (strcmp(name, "state_digest") == 0) {
@@ -835,9 +859,11 @@ static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const do
 }
 
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
+// accumulate: C += A^T B with the atomic epilogue whatever the split (C holds earlier blocks of the same product: the
+// chunked statistics pass); mirror = false leaves the lower tiles of a symmetric block for a later call.
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                           int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1,
-                          bool c_is_zero = false) {
+                          bool c_is_zero = false, bool accumulate = false, bool mirror = true) {
   // sym_row0 >= 0: rows sym_row0 .. of C are X^T X (symmetric, Nc x Nc, sym_row0 a multiple of the
   // tile size): only its upper tiles are computed, the rest is mirrored
   if (deterministic && A == B && lda == ldb && M == Nc && M <= 512 && K <= 4096 && sym_row0 < 0) {
@@ -888,6 +914,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
       // other counts between 5 and 15 do not.  The cause was not isolated (chunk count a multiple of the
       // XCD count in both winners); applied only in that multi-round regime.
       if (real > 24 && K / 64 >= 384) per_xcd = 8;
+      if (c->gemm_per_xcd > 0) per_xcd = c->gemm_per_xcd;
       splits = 8 * per_xcd;
     } else {
       splits = (512 + tiles - 1) / tiles;
@@ -896,12 +923,13 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     if (splits > maxs) splits = maxs;
     if (splits > 1) splits = ((splits + 7) / 8) * 8;
   }
+  if (accumulate && splits < 8) splits = 8;  // the atomic epilogue needs the split decode (8 chunks, one per XCD)
   const int split = splits > 1;
   i64 kps = K;
   if (split) {
     kps = (K + splits - 1) / splits;
     kps = ((kps + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-    if (!c_is_zero) HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
+    if (!c_is_zero && !accumulate) HIP_TRY(hipMemsetAsync(C, 0, (size_t)M * ldc * sizeof(double), c->stream));
   }
   const unsigned grid = (unsigned)(tiles * (split ? splits : 1));
   SpanGuard g(c, KID_GEMM);
@@ -911,7 +939,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     gemm_tn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   else
     gemm_tn_f64<false><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
-  if (sym_row0 >= 0)
+  if (sym_row0 >= 0 && mirror)
     mirror_lower_kernel<<<cdiv((i64)Nc * Nc, 256), 256, 0, c->stream>>>(C + (size_t)sym_row0 * ldc, Nc, ldc, T);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1190,7 +1218,7 @@ static unsigned level_grid(const evoamd_ctx *c, int level, int tag, i64 total, u
   if (tag == 0 && c->conservative_levels) tag = 1;  // counts describe the previous K^n: size it like its children
   // candidates / final K^n can exceed a level if a resident state exceeds the level below
   const int src = (tag == 0) ? level : (level > 0 ? level - 1 : 0);
-  double expect = c->res_cnt[src] * ((tag == 0) ? 1.0 : 1.0 + (double)c->Cmax / (double)c->S);
+  double expect = c->grid_scale * c->res_cnt[src] * ((tag == 0) ? 1.0 : 1.0 + (double)c->Cmax / (double)c->S);
   if (tag != 0 && level == 0) expect = (double)total;  // unknown: children of k = 2 parents
   unsigned want = (unsigned)(2.0 * expect / per_block) + 4;
   return want < g ? want : g;
@@ -1741,11 +1769,13 @@ static int join_fork(evoamd_ctx *c) {
 // timed on the main stream.
 static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
-  const bool gemm_timed = c->timing && (c->timing_mask & ((1u << KID_GEMM) | (1u << KID_MSTEP) | (1u << KID_MISC)));
-  // measured (tools/ab.sh, MI355X): ES3C H = 512 gains 3-4 % of the iteration (N = 12.5k and 100k); ES3C
-  // H = 128 and EBSC (H = 256, 1024) lose ~1 %: their contraction fills every CU with long split-K
-  // workgroups, the chain's small kernels wait for slots, and the fork/join events cost ~10 us
-  bool pays = c->model == EVOAMD_MODEL_SSSC && 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H >= 8e9;
+  const bool gemm_timed = c->timing && (c->timing_mask & ((1u << KID_GEMM) | (1u << KID_MSTEP) | (1u << KID_MISC) |
+                                                          (1u << KID_STATS) | (1u << KID_STATS_OVF)));
+  // the K = N contraction is worth a second stream when it is big (measured, tools/ab.sh, MI355X: ES3C H = 512 gains;
+  // ES3C H = 128 and the EBSC shapes at N <= 50k lose ~1 %: the fork / join events cost ~10 us)
+  const double gemm_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H
+                                                          : 2.0 * (double)c->N * c->D * c->H;
+  bool pays = c->model == EVOAMD_MODEL_SSSC && gemm_flops >= 8e9;
   if (c->comm && c->model == EVOAMD_MODEL_SSSC) {
     // np.array_split shards differ by one row, so a shard size next to the threshold would make some ranks
     // issue three all-reduces and others one: agree once per geometry (max over ranks), same call on every rank
@@ -1757,30 +1787,21 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     }
     pays = c->pays_agreed == 1;
   }
+  // fork_gemm: the contraction is still running when this function returns (beside the H x H inverses); the caller
+  // joins.  With a communicator only ES3C does that (its accumulator is all-reduced in pieces).
   fork_gemm = fork_gemm && (c->overlap_gemm == 2 || (c->overlap_gemm == 1 && pays)) &&
               (!c->comm || c->model == EVOAMD_MODEL_SSSC) && !gemm_timed && !c->mask_infr;
   {
     int rj = join_fork(c);  // a previous call that failed between fork and join must not race with the memset below
     if (rj) return rj;
   }
-  hipStream_t main_stream = c->stream;
-#define FORK_BEGIN()                                              \
-  if (fork_gemm) {                                                \
-    HIP_TRY(hipEventRecord(c->ev_fork, main_stream));             \
-    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));       \
-    c->stream = c->stream2;                                       \
-  }
-#define FORK_END()                                                \
-  if (fork_gemm) {                                                \
-    c->stream = main_stream;                                      \
-    HIP_TRY(hipEventRecord(c->ev_join, c->stream2));              \
-    c->gemm_forked = true;                                        \
-  }
   HIP_TRY(hipSetDevice(c->device));
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
   const int H = c->H, D = c->D;
+  const bool masked = c->mask_infr != nullptr;
   HIP_TRY(hipMemsetAsync(c->acc_base, 0, (size_t)(c->ovf_n + c->acc_n) * sizeof(double), c->stream));
+  HIP_TRY(hipMemsetAsync(c->census, 0, 4 * sizeof(double), c->stream));
   c->yhat_valid = c->stats_rows_valid = false;
   int r = ensure_B(c);
   if (r) return r;
@@ -1788,67 +1809,36 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     r = row_lse(c, c->lpj, N, c->L, c->rowmax, c->rowsum, c->dpar + DP_FS);
     if (r) return r;
   }
-  // column-sum partials: at most ~128 of them (the finish kernels add them serially per column)
-  const i64 rpb = std::max<i64>(256, cdiv(N, 128));
+  // column-sum partials: at most ~128 of them (the finish kernels add them serially per column); a multiple of
+  // four rows so that a block boundary is a workgroup boundary of the EBSC kernel (four datapoints each)
+  const i64 rpb = ((std::max<i64>(256, cdiv(N, 128)) + 3) / 4) * 4;
   const int nblk = (int)cdiv(N, rpb);
+  // Blocks of datapoints: the scatter kernels of block i + 1 (bound by the f64 atomic rate, executed at the memory
+  // side) run beside the MFMA contraction of block i on the second stream.  Same kernels, same sums; the
+  // contraction accumulates with its atomic epilogue.  Not while the classes involved are being timed one by one.
+  int nchunks = 1;
+  if (!masked && !gemm_timed && c->overlap_gemm != 0 && c->stats_chunks > 1 && gemm_flops >= 8e9)
+    nchunks = std::min<int>(c->stats_chunks, nblk);
+  const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
+  nchunks = (int)cdiv(N, rows_per_chunk);
+  const bool second_stream = fork_gemm || nchunks > 1;
+  hipStream_t main_stream = c->stream;
   int skipped = 0;
   // the whole statistics pass (everything that reads K^n + lpj and leaves the M-step sums, the GEMM aside)
   std::unique_ptr<SpanGuard> pass(new SpanGuard(c, KID_STATS_PASS));
-  if (c->model == EVOAMD_MODEL_BSC) {
-    {
-      SpanGuard g(c, KID_STATS);
-#define BSC_STATS(HWT)                                                                                   \
-  bsc_stats_kernel<HWT><<<cdiv(N, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                 \
-      c->states, c->lpj, c->rowmax, c->rowsum, c->yy, N, c->S, c->S_perm, H, c->HW, c->dpar, c->Es,      \
-      c->acc + a.Wq, c->partial2, dig_for(c, c->states))
-      switch (c->HW) {
-        case 1: BSC_STATS(1); break;
-        case 2: BSC_STATS(2); break;
-        case 4: BSC_STATS(4); break;
-        case 8: BSC_STATS(8); break;
-        case 16: BSC_STATS(16); break;
-        default: BSC_STATS(0); break;
-      }
-#undef BSC_STATS
-      HIP_TRY(hipGetLastError());
-      DBG_SYNC(c, "bsc stats");
-    }
-    {
-      SpanGuard g(c, KID_MISC);
-      r = ensure_colpart(c, (size_t)nblk * H);
-      if (r) return r;
-      colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk), 256, 0, c->stream>>>(c->Es, H, N, H, rpb, c->colpart);
-      bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
-                                                                       c->partial2, cdiv(N, 4), c->acc + a.sigma);
-      HIP_TRY(hipGetLastError());
-    }
-    pass.reset();
-    const double *Ywp = c->Y;
-    int ldwp = c->ldY;
-    if (c->mask_infr) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211)
-      if (c->rec_in_stats) {
-        r = compute_reconstruction(c);  // y_hat = Es W^T under the Theta of this E-step (_models.py:193-194)
-        if (r) return r;
-        select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
-        HIP_TRY(hipGetLastError());
-        c->yrec_valid = true;
-        c->rec_in_stats = false;
-      }
-      REQUIRE(c->yrec_valid, "incomplete data: the M-step needs y_reconstructed (bsc.py:186); reconstruct or upload it");
-      Ywp = c->Yrec;
-      ldwp = D;
-    }
-    FORK_BEGIN();
-    r = launch_gemm_tn(c, c->Es, H, Ywp, ldwp, c->acc + a.Wp, D, H, D, N, false, -1,
-                       /*c_is_zero=*/true);  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
-    FORK_END();
-    if (r) return r;
-  } else {
-    double *Es = c->Y + D, *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed]
+  const int cols = c->model == EVOAMD_MODEL_BSC ? H : 3 * H;
+  r = ensure_colpart(c, (size_t)nblk * cols);
+  if (r) return r;
+  // ---- ES3C: argument block shared by the scatter kernels
+  double *Es = c->model == EVOAMD_MODEL_SSSC ? c->Y + D : c->Es;
+  double *Ez = c->Y + D + H, *Ed = c->Y + D + 2 * H;  // columns of [Y | Es | Ez | Ed] (ES3C)
+  SsscArgs sa = {};
+  bool need[3] = {true, true, true};
+  int cap = 0;
+  if (c->model == EVOAMD_MODEL_SSSC) {
     Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, N, c->S, 0, nullptr, c->L, c->S_perm, c->flags, KID_STATS, 0};
     b.mask = c->mask_infr;
-    const bool masked = c->mask_infr != nullptr;
-    SsscArgs sa = sssc_args(c, b);
+    sa = sssc_args(c, b);
     sa.lpj_in = c->lpj;
     sa.rowmax = c->rowmax;
     sa.rowsum = c->rowsum;
@@ -1860,28 +1850,97 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     sa.xszsz = c->acc + a.xszsz;
     sa.xss_o = c->acc_base;
     sa.xszsz_o = c->acc_base + (size_t)H * H;
-    const i64 total = N * (i64)c->S;
-    const int cap = (int)list_cap(total);
+    cap = (int)list_cap(N * (i64)c->S);
     // the final K^n is made of resident states and accepted candidates: same levels as the candidates
-    bool need[3];
     levels_for(c, 1, need);
     r = zero_lists(c);
     if (r) return r;
-    const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
-                  o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
-    const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
-    if (masked) {
+  }
+  const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
+                o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
+  const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
+  const ListOut none_out = {nullptr, nullptr, 0};
+  const double *Ywp = c->Y;  // EBSC: what the Wp contraction reads
+  int ldwp = c->ldY;
+
+  for (int ci = 0; ci < nchunks; ci++) {
+    const i64 n0 = (i64)ci * rows_per_chunk;
+    const i64 nc = std::min<i64>(rows_per_chunk, N - n0);
+    const int blk0 = (int)(n0 / rpb), nblk_c = (int)cdiv(nc, rpb);
+    c->grid_scale = (double)nc / (double)N;
+    if (c->model == EVOAMD_MODEL_BSC) {
+      {
+        SpanGuard g(c, KID_STATS);
+#define BSC_STATS(HWT)                                                                                              \
+  bsc_stats_kernel<HWT><<<cdiv(nc, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                           \
+      c->states + (size_t)n0 * c->S * c->HW, c->lpj + (size_t)n0 * c->L, c->rowmax + n0, c->rowsum + n0, c->yy + n0, nc, \
+      c->S, c->S_perm, H, c->HW, c->dpar, c->Es + (size_t)n0 * H, c->acc + a.Wq, c->partial2 + n0 / 4,             \
+      dig_for(c, c->states) ? dig_for(c, c->states) + (size_t)n0 * c->S : nullptr)
+        switch (c->HW) {
+          case 1: BSC_STATS(1); break;
+          case 2: BSC_STATS(2); break;
+          case 4: BSC_STATS(4); break;
+          case 8: BSC_STATS(8); break;
+          case 16: BSC_STATS(16); break;
+          default: BSC_STATS(0); break;
+        }
+#undef BSC_STATS
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "bsc stats");
+      }
+      {
+        SpanGuard g(c, KID_MISC);
+        colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Es + (size_t)n0 * H, H, nc, H, rpb,
+                                                                                c->colpart + (size_t)blk0 * H);
+        HIP_TRY(hipGetLastError());
+      }
+      if (masked) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211); one block only
+        if (c->rec_in_stats) {
+          r = compute_reconstruction(c);  // y_hat = Es W^T under the Theta of this E-step (_models.py:193-194)
+          if (r) return r;
+          select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
+          HIP_TRY(hipGetLastError());
+          c->yrec_valid = true;
+          c->rec_in_stats = false;
+        }
+        REQUIRE(c->yrec_valid, "incomplete data: the M-step needs y_reconstructed (bsc.py:186); reconstruct or upload it");
+        Ywp = c->Yrec;
+        ldwp = D;
+      }
+    } else if (masked) {
       // incomplete data (sssc.py:276: W[this_x_infr, :]): the state terms belong to the datapoint, so every
       // state goes through the wavefront kernel, which forms W_obs^T W_obs itself and ADDS its moments to
       // the rows (they start from zero here)
+      const i64 total = N * (i64)c->S;
       HIP_TRY(hipMemset2DAsync(Es, (size_t)c->ldY * sizeof(double), 0, (size_t)3 * H * sizeof(double), (size_t)N, c->stream));
       const ListIn nat = {nullptr, nullptr, 0};
-      const ListOut none_out = {nullptr, nullptr, 0};
-      SpanGuard g(c, KID_STATS);
-      sssc_big_kernel<1><<<(int)std::min<i64>(total, 65536), 64, big_lds(8), c->stream>>>(sa, nat, o3, 8);
-      sssc_big_kernel<1><<<1024, 64, big_lds(SSSC_KCAP), c->stream>>>(sa, i3, none_out, SSSC_KCAP);
+      {
+        SpanGuard g(c, KID_STATS);
+        sssc_big_kernel<1><<<(int)std::min<i64>(total, 65536), 64, big_lds(8), c->stream>>>(sa, nat, o3, 8);
+        sssc_big_kernel<1><<<1024, 64, big_lds(SSSC_KCAP), c->stream>>>(sa, i3, none_out, SSSC_KCAP);
+        HIP_TRY(hipGetLastError());
+      }
+      SpanGuard g(c, KID_MISC);
+      colsum_partial_kernel<<<dim3(cdiv(3 * H, 64), nblk), 256, 0, c->stream>>>(Es, c->ldY, N, 3 * H, rpb, c->colpart);
       HIP_TRY(hipGetLastError());
     } else {
+      SsscArgs sc = sa;  // this block's rows
+      sc.states = sa.states + (size_t)n0 * c->S * c->HW;
+      if (sa.dig) sc.dig = sa.dig + (size_t)n0 * c->S;
+      sc.Bm = sa.Bm + (size_t)n0 * H;
+      sc.yy = sa.yy + n0;
+      sc.lpj_in = sa.lpj_in + (size_t)n0 * sa.ldo;
+      sc.rowmax = sa.rowmax + n0;
+      sc.rowsum = sa.rowsum + n0;
+      sc.Es = sa.Es + (size_t)n0 * sa.ldE;
+      sc.Ez = sa.Ez + (size_t)n0 * sa.ldE;
+      sc.Ed = sa.Ed + (size_t)n0 * sa.ldE;
+      sc.N = nc;
+      const i64 total = nc * (i64)c->S;
+      if (ci > 0) {  // the previous block's overflow census joins the running sum; fresh lists for this block
+        census_lists_kernel<<<1, 256, 0, c->stream>>>(c->list_n, LIST_SHARDS, skip_mask(need), c->err, c->census);
+        HIP_TRY(hipGetLastError());
+      }
       {
         // workgroups own whole datapoints; rows of Es / Ez / Ed staged in LDS (<= 64 KiB)
         int npb = 256 / c->S;
@@ -1890,14 +1949,14 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         if (npb > lim) npb = lim < 1 ? 1 : lim;
         const size_t lds = (size_t)npb * 3 * H * sizeof(double);
         SpanGuard g(c, KID_STATS);
-        const int sgrid = (int)cdiv(N, npb);
+        const int sgrid = (int)cdiv(nc, npb);
         switch (c->HW) {
-          case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-          case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-          case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-          case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-          case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
-          default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sa, npb, o1); break;
+          case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+          case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+          case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+          case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+          case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+          default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
         }
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats main");
@@ -1906,68 +1965,92 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         SpanGuard g(c, KID_STATS_OVF);
         const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
         if (need[0])
-          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sa, i1, o2);
-        const ListOut none_out = {nullptr, nullptr, 0};
+          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sc, i1, o2);
         if (use_k8_kernel(c, tg)) {
           if (need[1])
-            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sa, i2, o3);
+            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sc, i2, o3);
         } else if (need[1]) {
-          sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sa, i2, o3, 8);
+          sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sc, i2, o3, 8);
         }
         if (need[2])
           sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-              sa, i3, none_out, SSSC_KCAP);
+              sc, i3, none_out, SSSC_KCAP);
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats overflow levels");
       }
-      // a skipped level must have found its input list empty (checked by tail_kernel).  When K=4 is
-      // skipped nothing feeds the deeper lists either, so only the first skipped level matters.
+      // a skipped level must have found its input list empty (census_lists_kernel / tail_kernel check)
       skipped = skip_mask(need);
-    }
-    {
       SpanGuard g(c, KID_MISC);
-      r = ensure_colpart(c, (size_t)nblk * 3 * H);
-      if (r) return r;
-      colsum_partial_kernel<<<dim3(cdiv(3 * H, 64), nblk), 256, 0, c->stream>>>(Es, c->ldY, N, 3 * H, rpb, c->colpart);
+      colsum_partial_kernel<<<dim3(cdiv(3 * H, 64), nblk_c), 256, 0, c->stream>>>(sc.Es, c->ldY, nc, 3 * H, rpb,
+                                                                                    c->colpart + (size_t)blk0 * 3 * H);
+      HIP_TRY(hipGetLastError());
+    }
+    c->grid_scale = 1.0;
+    // ---- this block's part of the K = N contraction
+    if (c->model == EVOAMD_MODEL_SSSC && masked) continue;  // two products from the reconstructed rows, below
+    if (second_stream) {
+      HIP_TRY(hipEventRecord(c->ev_chunk[ci], main_stream));
+      HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_chunk[ci], 0));
+      c->stream = c->stream2;
+    }
+    const bool acc_mode = nchunks > 1, last = ci == nchunks - 1;
+    if (c->model == EVOAMD_MODEL_BSC)  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
+      r = launch_gemm_tn(c, c->Es + (size_t)n0 * H, H, Ywp + (size_t)n0 * ldwp, ldwp, c->acc + a.Wp, D, H, D, nc, false, -1,
+                         /*c_is_zero=*/true, acc_mode, last);
+    else
+      // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
+      // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned;
+      // launch_gemm_tn drops the hint if its tile does not divide it)
+      r = launch_gemm_tn(c, c->Y + (size_t)n0 * c->ldY, c->ldY, Ez + (size_t)n0 * c->ldY, c->ldY, c->acc + a.sWp, H,
+                         D + 2 * H, H, nc, false, ((D + H) % GEMM_BM) == 0 ? D + H : -1, /*c_is_zero=*/true, acc_mode, last);
+    c->stream = main_stream;
+    if (r) return r;
+  }
+  // ---- the sums of the scattered moments are complete: mirror / diagonals / column sums
+  {
+    SpanGuard g(c, KID_MISC);
+    if (c->model == EVOAMD_MODEL_BSC) {
+      bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
+                                                                       c->partial2, cdiv(N, 4), c->acc + a.sigma);
+    } else {
       const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
       sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
                                                                  c->acc + a.xsz, c->colpart, nblk, H, c->y2sum,
                                                                  c->acc + a.y2, D, sa.xss_o, sa.xszsz_o,
                                                                  masked ? nullptr : c->PT);
-      HIP_TRY(hipGetLastError());
-      DBG_SYNC(c, "sssc colsum + finish");
     }
-    pass.reset();
-    // [Y | Es | Ez]^T Ez  ->  Wp (D,H) | sum_n xpt_s (x) xpt_sz (H,H) | sum_n xpt_sz (x) xpt_sz (H,H)
-    // (the last block is Ez^T Ez: symmetric, upper tiles only when its first row is tile-aligned)
-    if (masked) {
-      // y_hat = Ez W^T with the Theta of this E-step: the reconstruction (sssc.py:613-627), the rows the Wp
-      // contraction reads (:631) and, squared over the reliable entries, the trace term of sigma2 (:640-645,751)
-      r = compute_reconstruction(c);
-      if (r) return r;
-      REQUIRE(c->rec_in_stats, "ES3C on incomplete data needs do_reconstruction in every step (sssc.py:630-633)");
-      select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
-      HIP_TRY(hipGetLastError());
-      c->yrec_valid = true;
-      c->rec_in_stats = false;
-      r = launch_gemm_tn(c, Es, c->ldY, Ez, c->ldY, c->acc + a.sWp + (size_t)D * H, H, 2 * H, H, N, false,
-                         (H % GEMM_BM) == 0 ? H : -1, /*c_is_zero=*/true);
-      if (r) return r;
-      r = launch_gemm_tn(c, c->Yrec, D, Ez, c->ldY, c->acc + a.sWp, H, D, H, N, false, -1, /*c_is_zero=*/true);
-      if (r) return r;
-    } else {
-      FORK_BEGIN();
-      r = launch_gemm_tn(c, c->Y, c->ldY, Ez, c->ldY, c->acc + a.sWp, H, D + 2 * H, H, N, false,
-                         ((D + H) % GEMM_BM) == 0 ? D + H : -1,  // launch_gemm_tn drops the hint if its tile does not divide it
-                         /*c_is_zero=*/true);                    // acc was cleared at the top of stats_compute
-      FORK_END();
-      if (r) return r;
-    }
+    HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "colsum + finish");
+  }
+  pass.reset();
+  if (c->model == EVOAMD_MODEL_SSSC && masked) {
+    // y_hat = Ez W^T with the Theta of this E-step: the reconstruction (sssc.py:613-627), the rows the Wp
+    // contraction reads (:631) and, squared over the reliable entries, the trace term of sigma2 (:640-645,751)
+    r = compute_reconstruction(c);
+    if (r) return r;
+    REQUIRE(c->rec_in_stats, "ES3C on incomplete data needs do_reconstruction in every step (sssc.py:630-633)");
+    select_rec_kernel<<<cdiv(N, 4), 256, 0, c->stream>>>(c->Y, c->ldY, c->mask_x, c->mask_infr, c->yhat, N, D, c->Yrec);
+    HIP_TRY(hipGetLastError());
+    c->yrec_valid = true;
+    c->rec_in_stats = false;
+    r = launch_gemm_tn(c, Es, c->ldY, Ez, c->ldY, c->acc + a.sWp + (size_t)D * H, H, 2 * H, H, N, false,
+                       (H % GEMM_BM) == 0 ? H : -1, /*c_is_zero=*/true);
+    if (r) return r;
+    r = launch_gemm_tn(c, c->Yrec, D, Ez, c->ldY, c->acc + a.sWp, H, D, H, N, false, -1, /*c_is_zero=*/true);
+    if (r) return r;
+  }
+  if (second_stream) {
+    HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+    if (fork_gemm)
+      c->gemm_forked = true;  // the caller joins (after the H x H inverses)
+    else
+      HIP_TRY(hipStreamWaitEvent(main_stream, c->ev_join, 0));
   }
   {
     SpanGuard g(c, KID_MISC);
     tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
-                                          c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped);
+                                          c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped,
+                                          c->census);
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "stats contraction + tail");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
@@ -1987,8 +2070,6 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   }
   c->stats_rows_valid = true;
   return 0;
-#undef FORK_BEGIN
-#undef FORK_END
 }
 
 // After the accumulator + scalar block reached the host: remember which overflow levels K^n needs.

@@ -16,6 +16,25 @@ __device__ __forceinline__ void clear_lists_checked(int *__restrict__ list_n, in
   }
 }
 
+// Between two chunks of a chunked statistics pass: add the overflow census of the chunk that just ended to
+// census[0..2] (states above 2 / 4 / 8 active latents), check its skipped levels, clear the counters.
+__global__ __launch_bounds__(256) void census_lists_kernel(int *__restrict__ list_n, int nshards, int skipped_mask,
+                                                           int *__restrict__ err, double *__restrict__ census) {
+  __shared__ int lvl[3];
+  if (threadIdx.x < 3) lvl[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * nshards; i += 256) {
+    const int v = list_n[i];
+    if (v) atomicAdd(&lvl[i / nshards], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    if (lvl[threadIdx.x] != 0 && ((skipped_mask >> threadIdx.x) & 1)) atomicOr(err, 4);
+    census[threadIdx.x] += (double)lvl[threadIdx.x];
+  }
+  for (int i = threadIdx.x; i < 4 * nshards; i += 256) list_n[i] = 0;
+}
+
 // the same check on its own (paths where a memset clears the counters)
 __global__ void check_lists_kernel(int *__restrict__ list_n, int n_list, int skipped_mask, int *__restrict__ err) {
   clear_lists_checked(list_n, n_list, skipped_mask, err);
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *__res
 __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, double N, double *__restrict__ dpar,
                                                    unsigned *__restrict__ flags, i64 nflags3, i64 nper,
                                                    int *__restrict__ err, int *__restrict__ list_n, int nshards,
-                                                   int skipped_mask) {
+                                                   int skipped_mask, const double *__restrict__ census) {
   __shared__ int cnt[3];
   __shared__ int lvl[3];
   const int t = threadIdx.x;
@@ -252,9 +271,10 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
     dpar[DP_ECNT0] = 0.0;
     dpar[DP_ECNT1] = 0.0;
     if (list_n) {
-      dpar[DP_NGT2] = (double)lvl[0];
-      dpar[DP_NGT4] = (double)lvl[1];
-      dpar[DP_NGT8] = (double)lvl[2];
+      // census: what the earlier chunks of a chunked statistics pass counted (census_lists_kernel)
+      dpar[DP_NGT2] = (double)lvl[0] + (census ? census[0] : 0.0);
+      dpar[DP_NGT4] = (double)lvl[1] + (census ? census[1] : 0.0);
+      dpar[DP_NGT8] = (double)lvl[2] + (census ? census[2] : 0.0);
       // level j+1 consumes list j; if it was skipped its list must be empty
       int lost = 0;
       for (int j = 0; j < 3; j++)

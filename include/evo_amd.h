@@ -81,7 +81,12 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * 0 = 32 from n = 256 on (32 x 32 pivot block inverted in registers through its Schur complement), else 16.
  * "prefetch_lpj" (0/1, default 1): evoamd_mstep_device enqueues the next iteration's evoamd_lpj_resident
  * pass behind its mailbox kernel (the GPU works while the host turns the iteration around); the next
- * evoamd_lpj_resident call returns at once unless Theta, K^n, the data or an option changed in between. */
+ * evoamd_lpj_resident call returns at once unless Theta, K^n, the data or an option changed in between.
+ * "stats_chunks" (1 .. 16, default 1; measured slower than one block at the north-star shape, kept for A/B): the statistics pass of large shards (contraction >= 8 GFLOP) runs in that many
+ * blocks of datapoints; the MFMA contraction of block i runs on the second stream beside the scatter kernels of block
+ * i + 1 (those are bound by the f64 atomic rate, the contraction by the matrix cores); 1 = one block.  "overlap_gemm" = 0
+ * switches this off as well.  "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
+ * (measurement aid: tools/gemm_sweep.sh). */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */
