@@ -179,6 +179,53 @@ def _init_chunk(args):
     return np.packbits(suff["ss"], axis=-1)
 
 
+def _bernoulli_rows_packed(rs, n_rows, H, p):
+    """(n_rows, ceil(H/8)) uint8: iid Bernoulli(p) bits in np.packbits layout, drawn through the gaps between
+    successive ones (geometric), i.e. ~n_rows H p random numbers instead of n_rows H."""
+    PB = (H + 7) // 8
+    total = n_rows * H
+    out = np.zeros(n_rows * PB, dtype=np.uint8)
+    pos = -1
+    while pos < total:
+        m = int(1.2 * (total - pos) * p) + 64
+        where = pos + np.cumsum(rs.geometric(p, size=m))
+        pos = int(where[-1])
+        where = where[where < total]
+        r, h = np.divmod(where, H)
+        np.bitwise_or.at(out, r * PB + (h >> 3), (0x80 >> (h & 7)).astype(np.uint8))
+    return out.reshape(n_rows, PB)
+
+
+def init_states_inprocess(cfg, n_rows, seed, dense=False, chunk=1000):
+    """init_states' construction (variational/utils.py:100-138: S Bernoulli(p) rows, sorted-unique; while fewer than S,
+    S more rows whose new unique ones are appended in sorted order; first S kept) from a private generator IN THIS
+    PROCESS, bits drawn sparsely: for runs under rocprofv3, where starting worker processes is not an option.
+    Same law as init_states, not the same np.random stream."""
+    H, S = cfg["H"], cfg["S"]
+    p = (8.0 / H) if dense else 1.0 / H
+    rs = np.random.RandomState(seed)
+    PB = (H + 7) // 8
+    void = np.dtype((np.void, PB))
+    R = 6  # rounds of S rows drawn ahead per datapoint
+    for n0 in range(0, n_rows, chunk):
+        n = min(chunk, n_rows - n0)
+        pool = _bernoulli_rows_packed(rs, n * R * S, H, p).reshape(n, R * S, PB)
+        out = np.zeros((n, S, PB), dtype=np.uint8)
+        for i in range(n):
+            first_rows = np.ascontiguousarray(pool[i, :S])
+            _, first = np.unique(first_rows.view(void), return_index=True)
+            have = first_rows[first]
+            r = 1
+            while have.shape[0] < S:
+                more = pool[i, r * S:(r + 1) * S] if r < R else _bernoulli_rows_packed(rs, S, H, p)
+                conc = np.ascontiguousarray(np.concatenate((have, more)))
+                _, first = np.unique(conc.view(void), return_index=True)
+                have = np.concatenate((have, conc[first[first >= have.shape[0]]]))
+                r += 1
+            out[i] = have[:S]
+        yield n0, out
+
+
 def init_states_packed(cfg, n_rows, seed, workers, dense=False, chunk=2000):
     """Yields (n0, packed uint8 (n, S, ceil(H/8))): the reference's init_states run chunk by chunk in a process
     pool (the bool form of the north-star K^n would be 10 GB, and one core needs minutes for 100k datapoints)."""
@@ -346,6 +393,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--dense-states", action="store_true",
                     help="SURVEY 8d stress variant: K^n initialised with p_init_Kn = 8/H (mean |s| = 8)")
+    ap.add_argument("--inprocess-init", action="store_true",
+                    help="draw K^n(0) in this process instead of a worker pool (runs under rocprofv3)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="evoamd_set_option before the run (A/B of a kernel path, e.g. overlap_gemm=0)")
     args = ap.parse_args()
@@ -379,7 +428,10 @@ def main():
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
     workers = max(1, host_cores() // world)
     log("data ready (%d x %d); init_states for %d datapoints on %d workers ..." % (n_loc, cfg["D"], n_loc, workers))
-    chunks = list(init_states_packed(cfg, n_loc, 4321 + 100003 * rank, workers, dense=args.dense_states))
+    if args.inprocess_init:
+        chunks = list(init_states_inprocess(cfg, n_loc, 4321 + 100003 * rank, dense=args.dense_states))
+    else:
+        chunks = list(init_states_packed(cfg, n_loc, 4321 + 100003 * rank, workers, dense=args.dense_states))
     log("K^n(0) ready")
 
     from evo_amd.engine import Engine

@@ -148,6 +148,13 @@ struct evoamd_ctx {
                          // 5.61, 4 blocks 5.68-5.88, 8 blocks 5.99 -- both kernels live on the memory-side f64 atomic
                          // units (the contraction's split-K epilogue issues 36 M of them) and they time-slice the CUs
                          // instead of overlapping; off by default
+  // ES3C pair bins (kernels_sssc.hpp: PairBins): option "pair_bins" 0 never / 1 when the flush is a small part of
+  // the contributions / 2 always
+  int n_cu = 256;  // compute units of the device (persistent grids)
+  int stats_stage = 1;  // option "stats_stage" (measurement): 0 = no LDS staging of B rows / singleton table
+  int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
+  PairBins pbins = {};
+  int pair_bins = 1;
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
   double *census = nullptr;  // 4 doubles: overflow census of the earlier blocks of a chunked statistics pass
@@ -381,6 +388,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                 prop.gcnArchName);
   evoamd_ctx *c = new evoamd_ctx();
   c->device = device;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -397,6 +405,14 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
+  {
+    const void *wk[] = {(const void *)sssc_stats_wave_kernel<0, 4>,  (const void *)sssc_stats_wave_kernel<1, 4>,
+                        (const void *)sssc_stats_wave_kernel<2, 4>,  (const void *)sssc_stats_wave_kernel<4, 4>,
+                        (const void *)sssc_stats_wave_kernel<8, 4>,  (const void *)sssc_stats_wave_kernel<16, 4>,
+                        (const void *)sssc_stats_wave_kernel<0, 1>,  (const void *)sssc_stats_wave_kernel<0, 8>,
+                        (const void *)sssc_stats_wave_kernel<0, 16>};
+    for (const void *f : wk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+  }
   *out = c;
   return 0;
 }
@@ -407,7 +423,8 @@ static void free_all(evoamd_ctx *c) {
                   c->Wt,     c->G,      c->Psi,     c->Bm,      c->mus,      c->pilbar_v,  c->GP,      c->DG,    c->D1,    c->PT,   c->yhat,  c->tmpWt,  c->mask_infr,  c->mask_x,  c->Yrec,
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
-                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start};
+                  c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
+                  c->pbins.keys, c->pbins.qv, c->pbins.gcnt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -466,6 +483,18 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "overlap_gemm") == 0) {
     c->overlap_gemm = value;
+    return 0;
+  }
+  if (strcmp(name, "stats_stage") == 0) {
+    c->stats_stage = value;
+    return 0;
+  }
+  if (strcmp(name, "stats_waves") == 0) {
+    c->stats_waves = value;
+    return 0;
+  }
+  if (strcmp(name, "pair_bins") == 0) {
+    c->pair_bins = value;
     return 0;
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
@@ -618,6 +647,27 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     int rl = ensure_lists(c, (i64)N * SC);
     if (rl) return rl;
     ALLOC(c->list_n, 4 * LIST_SHARDS);
+    // pair bins of the statistics pass: 2 rf folded rows x H columns per LDS tile
+    if (c->pbins.keys) (void)hipFree(c->pbins.keys);
+    if (c->pbins.qv) (void)hipFree(c->pbins.qv);
+    if (c->pbins.gcnt) (void)hipFree(c->pbins.gcnt);
+    c->pbins = PairBins{};
+    if (H >= 2 && H <= 1024) {
+      PairBins pb = {};
+      pb.rf = std::max(1, PB_TILE / (2 * H));
+      const int nfold = (H - 1 + 1) / 2;
+      pb.nb = (int)cdiv(nfold, pb.rf);
+      // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
+      // of its states being pairs spread evenly over the bins x 2
+      pb.nwg = 2048;
+      pb.cap = (int)std::max<i64>(64, 2 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
+      const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
+      ALLOC(pb.keys, ne);
+      ALLOC(pb.qv, ne);
+      ALLOC(pb.gcnt, (size_t)pb.nb * pb.nwg);
+      HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
+      c->pbins = pb;
+    }
   }
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
@@ -1817,7 +1867,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // side) run beside the MFMA contraction of block i on the second stream.  Same kernels, same sums; the
   // contraction accumulates with its atomic epilogue.  Not while the classes involved are being timed one by one.
   int nchunks = 1;
-  if (!masked && !gemm_timed && c->overlap_gemm != 0 && c->stats_chunks > 1 && gemm_flops >= 8e9)
+  if (!masked && !gemm_timed && c->overlap_gemm != 0 && c->stats_chunks > 1 && (gemm_flops >= 8e9 || c->overlap_gemm == 2))
     nchunks = std::min<int>(c->stats_chunks, nblk);
   const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
   nchunks = (int)cdiv(N, rows_per_chunk);
@@ -1850,6 +1900,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     sa.xszsz = c->acc + a.xszsz;
     sa.xss_o = c->acc_base;
     sa.xszsz_o = c->acc_base + (size_t)H * H;
+    if (!masked) {  // the kernels sum the columns of [Es | Ez] and the diagonal second moments themselves
+      sa.cs_s = c->acc + a.xs;
+      sa.cs_z = c->acc + a.xsz;
+      sa.cs_d = c->diag;
+      HIP_TRY(hipMemsetAsync(c->diag, 0, (size_t)H * sizeof(double), c->stream));
+    }
     cap = (int)list_cap(N * (i64)c->S);
     // the final K^n is made of resident states and accepted candidates: same levels as the candidates
     levels_for(c, 1, need);
@@ -1942,24 +1998,55 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         HIP_TRY(hipGetLastError());
       }
       {
-        // workgroups own whole datapoints; rows of Es / Ez / Ed staged in LDS (<= 64 KiB)
-        int npb = 256 / c->S;
-        if (npb < 1) npb = 1;
-        const int lim = (int)(65536 / ((size_t)24 * H));
-        if (npb > lim) npb = lim < 1 ? 1 : lim;
-        const size_t lds = (size_t)npb * 3 * H * sizeof(double);
+        // one wave per datapoint, persistent workgroups: W x 2 H doubles of rows + 3 H of column accumulators in LDS
+        int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) + 2048 <= 159 * 1024 ? 4 : 1;
+        if (c->stats_waves == 8 || c->stats_waves == 16) Wv = c->stats_waves;  // measurement option (digest path only)
+        size_t lds = (size_t)(Wv * 2 + 3) * H * sizeof(double);
+        REQUIRE(lds + 2048 <= 159 * 1024, "ES3C statistics: H too large for the LDS rows (H <= 4000)");
+        // B row of each wave's datapoint + the singleton table in LDS too when that still leaves two workgroups per CU
+        const size_t lds_staged = lds + (size_t)(Wv + 4) * H * sizeof(double);
+        const int stage = (H % 2) == 0 && 2 * (lds_staged + 2048) <= 160 * 1024 && c->stats_stage != 0;
+        if (stage) lds = lds_staged;
+        int per_cu = (int)((160 * 1024) / (lds + 2048));
+        const int wave_lim = 32 / Wv;  // 32 waves per CU
+        if (per_cu > wave_lim) per_cu = wave_lim;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
         SpanGuard g(c, KID_STATS);
-        const int sgrid = (int)cdiv(nc, npb);
-        switch (c->HW) {
-          case 1: sssc_stats_kernel<1><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
-          case 2: sssc_stats_kernel<2><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
-          case 4: sssc_stats_kernel<4><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
-          case 8: sssc_stats_kernel<8><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
-          case 16: sssc_stats_kernel<16><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
-          default: sssc_stats_kernel<0><<<sgrid, 256, lds, c->stream>>>(sc, npb, o1); break;
+        int sgrid = (int)std::min<i64>(cdiv(nc, Wv), (i64)c->n_cu * per_cu);
+        // pair bins pay when the tiles' flush is a small part of the contributions they absorb
+        PairBins pb = {};
+        if (c->pbins.keys && (c->pair_bins == 2 ||
+                              (c->pair_bins == 1 && total / 2 >= 6 * (i64)c->pbins.nb * PB_NSH * (PB_TILE / 2)))) {
+          pb = c->pbins;
+          if (sgrid > pb.nwg) sgrid = pb.nwg;  // one private region per producer workgroup and bin
         }
+#define STATS_WAVE(HWT) sssc_stats_wave_kernel<HWT, 4><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage)
+        if (Wv == 1) {
+          sssc_stats_wave_kernel<0, 1><<<sgrid, 64, lds, c->stream>>>(sc, o1, pb, stage);
+        } else if (Wv == 8) {
+          sssc_stats_wave_kernel<0, 8><<<sgrid, 512, lds, c->stream>>>(sc, o1, pb, stage);
+        } else if (Wv == 16) {
+          sssc_stats_wave_kernel<0, 16><<<sgrid, 1024, lds, c->stream>>>(sc, o1, pb, stage);
+        } else {
+          switch (c->HW) {
+            case 1: STATS_WAVE(1); break;
+            case 2: STATS_WAVE(2); break;
+            case 4: STATS_WAVE(4); break;
+            case 8: STATS_WAVE(8); break;
+            case 16: STATS_WAVE(16); break;
+            default: STATS_WAVE(0); break;
+          }
+        }
+#undef STATS_WAVE
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats main");
+        if (pb.keys) {
+          pair_bins_reduce_kernel<<<pb.nb * PB_NSH, 256, (size_t)2 * pb.rf * H * sizeof(double2), c->stream>>>(
+              pb, H, c->acc + a.xss, c->acc + a.xszsz);
+          HIP_TRY(hipGetLastError());
+          DBG_SYNC(c, "pair bins reduce");
+        }
       }
       if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
@@ -1980,10 +2067,6 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
       // a skipped level must have found its input list empty (census_lists_kernel / tail_kernel check)
       skipped = skip_mask(need);
-      SpanGuard g(c, KID_MISC);
-      colsum_partial_kernel<<<dim3(cdiv(3 * H, 64), nblk_c), 256, 0, c->stream>>>(sc.Es, c->ldY, nc, 3 * H, rpb,
-                                                                                    c->colpart + (size_t)blk0 * 3 * H);
-      HIP_TRY(hipGetLastError());
     }
     c->grid_scale = 1.0;
     // ---- this block's part of the K = N contraction
@@ -2014,10 +2097,11 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                                                        c->partial2, cdiv(N, 4), c->acc + a.sigma);
     } else {
       const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
+      // complete data: the kernels left the column sums in xs / xsz / diag (nblk = 0); else per-block partials
       sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
-                                                                 c->acc + a.xsz, c->colpart, nblk, H, c->y2sum,
-                                                                 c->acc + a.y2, D, sa.xss_o, sa.xszsz_o,
-                                                                 masked ? nullptr : c->PT);
+                                                                 c->acc + a.xsz, masked ? c->colpart : c->diag,
+                                                                 masked ? nblk : 0, H, c->y2sum, c->acc + a.y2, D,
+                                                                 sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT);
     }
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "colsum + finish");

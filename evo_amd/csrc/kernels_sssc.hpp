@@ -61,6 +61,9 @@ struct SsscArgs {
   const double *rowmax, *rowsum;
   double *Es, *Ez, *Ed;   // (N, ldE) rows per datapoint: xpt_s, xpt_sz and the DIAGONAL of xpt_szsz
   int ldE;
+  // column sums over the datapoints, accumulated by the kernels themselves (H each, zero-initialised): sum_n xpt_s,
+  // sum_n xpt_sz, diagonal of sum_n xpt_szsz.  nullptr: the Ed rows + a separate column-sum pass (incomplete data).
+  double *cs_s, *cs_z, *cs_d;
   double *xss, *xszsz;    // (H,H) zero-initialised: strict UPPER triangle sums of the states with 2 active latents
   double *xss_o, *xszsz_o;  // (H,H) zero-initialised: what the overflow kernels (> 2 active latents) add, xszsz_o both triangles
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
@@ -424,7 +427,13 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
         if (i < k) {
           unsafeAtomicAdd(&a.Es[n * a.ldE + idx[i]], qn);
           unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[i]], qn * kap[i]);
-          unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
+          if (a.cs_s) {  // the main kernel summed its columns already: add this state's share
+            unsafeAtomicAdd(&a.cs_s[idx[i]], qn);
+            unsafeAtomicAdd(&a.cs_z[idx[i]], qn * kap[i]);
+            unsafeAtomicAdd(&a.cs_d[idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
+          } else {
+            unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
+          }
         }
       }
       sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
@@ -649,100 +658,271 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
 }
 
-// Main statistics pass over the resident K^n (sssc.py:553-611): workgroups own whole datapoints
-// (npb = max(1, 256 / S) per workgroup), so the first moments xpt_s / xpt_sz of a datapoint are
-// accumulated in LDS and written as complete rows of Es / Ez with plain coalesced stores -- no
-// memset, no global atomics; only the H x H second moments use global f64 atomics.  States with
-// more than 2 active latents go to list_out and are added by the overflow kernels afterwards
-// (stream order guarantees their atomics land after the row stores).  kappa and Lam of the states
-// with |A| <= 2 come from the same tables as the lpj pass (no elimination per pair), the state
-// words are read with 16-byte loads, and the overflow reservation overlaps with the arithmetic.
-template <int HWT>
-__global__ __launch_bounds__(256) void sssc_stats_kernel(SsscArgs a, int npb, ListOut lo) {
+// ---------------------------------------------------------------------------------------
+// Pair bins.  The second moments of the states with two active latents are sums over ALL datapoints of
+// (q, q (Lam_01 + kappa_0 kappa_1)) into element (i, j), i < j, of two H x H matrices: ~N S / 2 contributions on
+// H^2 / 2 addresses.  As global f64 atomics they run at the memory-side atomic rate (23.6 G/s measured,
+// tools/probes/atom_scope_probe.hip, whatever the scope) and were all this pass waited for.  Instead every
+// contribution is APPENDED (plain stores) to the bin of its row i -- every producer workgroup owns a private region
+// per bin and counts in LDS, so an append costs no global atomic at all (a first version that reserved slots with
+// one returning atomic per workgroup and bin was slower than the direct atomics) --; a second kernel reduces each
+// bin in an LDS tile and adds the tile to the matrices once.  Rows are folded (i with H-2-i: H partners per folded row) so that the
+// bins of the upper triangle fill evenly.  A bin region that is full falls back to the direct atomics.
+// ---------------------------------------------------------------------------------------
+#define PB_TILE 4096  // pair slots per LDS tile (x 16 bytes = 64 KiB)
+#define PB_MAX_BINS 256
+#define PB_NSH 8      // reduce workgroups per bin
+struct PairBins {
+  unsigned *keys;  // nb x nwg private regions of `cap` entries: (tile row << 16) | j
+  double2 *qv;     // {q, q (Lam_01 + kappa_0 kappa_1)}
+  int *gcnt;       // nb x nwg: entries each producer workgroup left in each bin (the reduce kernel zeroes them)
+  int cap, nb, rf, nwg;  // rf folded rows per bin: the tile holds 2 rf rows x H columns; nwg producer workgroups
+};
+__device__ __forceinline__ int pb_fold(int i, int H) { return i < H - 2 - i ? i : H - 2 - i; }
+
+// Workgroup (bin, s) reduces the regions that the producer workgroups w = s, s + PB_NSH, ... left in `bin`: LDS tile
+// <- their entries (ds_add_f64), then the non-zero slots once to the matrices.  One wave per region at a time.
+// 2 rf H <= PB_TILE.
+__global__ __launch_bounds__(256) void pair_bins_reduce_kernel(PairBins pb, int H, double *__restrict__ xss,
+                                                               double *__restrict__ xszsz) {
+  extern __shared__ double2 pb_tile[];
+  const int bin = blockIdx.x / PB_NSH, sh = blockIdx.x - bin * PB_NSH;
+  const int slots = 2 * pb.rf * H;
+  for (int i = threadIdx.x; i < slots; i += 256) pb_tile[i] = make_double2(0.0, 0.0);
+  lds_barrier();
+  const int lane = lane_id(), wave = wave_id_uniform();
+  for (int w = sh + PB_NSH * wave; w < pb.nwg; w += PB_NSH * 4) {
+    const size_t reg = (size_t)bin * pb.nwg + w;
+    int n = pb.gcnt[reg];
+    if (n > pb.cap) n = pb.cap;
+    if (n == 0) continue;  // wave-uniform
+    if (lane == 0) pb.gcnt[reg] = 0;  // ready for the next pass
+    const unsigned *keys = pb.keys + reg * pb.cap;
+    const double2 *qv = pb.qv + reg * pb.cap;
+    for (int e0 = 0; e0 < n; e0 += 128) {  // two entries in flight per lane
+      const int ea = e0 + lane, eb = e0 + 64 + lane;
+      const unsigned ka = ea < n ? keys[ea] : 0xFFFFFFFFu, kb = eb < n ? keys[eb] : 0xFFFFFFFFu;
+      const double2 va = ea < n ? qv[ea] : make_double2(0.0, 0.0), vb = eb < n ? qv[eb] : make_double2(0.0, 0.0);
+      if (ka != 0xFFFFFFFFu) {
+        double2 *t = &pb_tile[(int)(ka >> 16) * H + (int)(ka & 0xFFFFu)];
+        unsafeAtomicAdd(&t->x, va.x);
+        unsafeAtomicAdd(&t->y, va.y);
+      }
+      if (kb != 0xFFFFFFFFu) {
+        double2 *t = &pb_tile[(int)(kb >> 16) * H + (int)(kb & 0xFFFFu)];
+        unsafeAtomicAdd(&t->x, vb.x);
+        unsafeAtomicAdd(&t->y, vb.y);
+      }
+    }
+  }
+  lds_barrier();
+  for (int idx = threadIdx.x; idx < slots; idx += 256) {
+    const double2 v = pb_tile[idx];
+    if (v.x != 0.0 || v.y != 0.0) {
+      const int r = idx / H, j = idx - r * H;
+      const int f = bin * pb.rf + (r >> 1);
+      const int i = (r & 1) ? H - 2 - f : f;
+      const i64 o = (i64)i * H + j;
+      unsafeAtomicAdd(&xss[o], v.x);
+      unsafeAtomicAdd(&xszsz[o], v.y);
+    }
+  }
+}
+
+// Main statistics pass over the resident K^n (sssc.py:553-611), states with |A| <= 2 (the others go to the
+// overflow list and are added by the overflow kernels afterwards): ONE WAVE per datapoint, persistent
+// workgroups of W waves.  kappa and Lam come from the same tables as the lpj pass (no elimination per state).
+// The round-1 kernel gave a 256-thread workgroup to every datapoint, issued two global f64 atomics per pair state and
+// wrote three dense rows per datapoint that a second kernel read again for the column sums; measured at the
+// north-star shape it was bound first by the atomic rate (1.2-1.3 ms), then -- with the pair bins -- by
+// (datapoints in flight per CU) / (latency of one datapoint): 8 datapoints, each a chain of ~5 dependent memory
+// round trips and three workgroup barriers (0.86 ms).  Here a datapoint's rounds of 64 states need no barrier at
+// all (a wave's LDS operations execute in order) and three whole passes over memory are gone:
+//   * no Ed rows: the diagonal second moments go straight into a workgroup accumulator;
+//   * no column-sum kernel: each wave adds the rows it writes out to workgroup accumulators (LDS), which reach
+//     the global sums xs / xsz / diag with 3 H atomics per WORKGROUP at the end;
+//   * pair second moments through the pair bins (no global atomics).
+// The counters of that version (profiles/r02_c4_stats_wave_pmc.txt) showed the vector L1 as the limit: 2 070 cache
+// accesses per datapoint, six of every seven of them single-lane gathers (D1[idx], B[n][idx] twice per pair
+// state): so the singleton table (H x 32 B, once per workgroup) and the datapoint's B row (H doubles, one
+// coalesced load per wave and datapoint) are staged in LDS when `stage` is set and the gathers become LDS reads.
+// Dynamic LDS: W x 2 H doubles (Es / Ez row of each wave's datapoint) + 3 H doubles (accumulators)
+//              [+ W x H doubles (B rows) + H double4 (D1) when stage].
+template <int HWT, int W>
+__global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage) {
   a.s2inv = a.dpar[DP_S2INV];
-  extern __shared__ double rows[];  // npb x 3 x H : xpt_s | xpt_sz | diag(xpt_szsz)
-  __shared__ int ovf_buf[256];
-  __shared__ int ovf_ctl[2];
-  const i64 n0 = (i64)blockIdx.x * npb;
-  const int nrows = (int)((n0 + npb <= a.N) ? npb : (a.N - n0));
-  for (int i = threadIdx.x; i < nrows * 3 * a.H; i += 256) rows[i] = 0.0;
-  const int work = nrows * a.C;
+  extern __shared__ double wrows[];
+  __shared__ int bcnt[PB_MAX_BINS];
+  const int H = a.H, lane = lane_id(), wave = wave_id_uniform();
+  double *rowS = wrows + (size_t)wave * 2 * H, *rowZ = rowS + H;
+  double *accS = wrows + (size_t)W * 2 * H, *accZ = accS + H, *accD = accZ + H;
+  double *rowB = accD + H + (size_t)wave * H;                 // stage only
+  double4 *d1s = (double4 *)(accD + H + (size_t)W * H);       // stage only (32-byte aligned: all offsets are multiples of H doubles, H even)
+  const bool binned = pb.keys != nullptr;
+  for (int i = threadIdx.x; i < 3 * H; i += 64 * W) accS[i] = 0.0;
+  if (stage)
+    for (int i = threadIdx.x; i < H; i += 64 * W) d1s[i] = a.D1[i];
+  if (binned)
+    for (int i = threadIdx.x; i < pb.nb; i += 64 * W) bcnt[i] = 0;
+  __syncthreads();
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
-  for (int t0 = 0; t0 < work; t0 += 256) {
-    const int t = t0 + threadIdx.x;
-    const bool live = t < work;
-    int r = 0, c = 0, k = 0, idx0 = 0, idx1 = 0;
-    i64 n = n0;
-    double l = 0.0, rmax = 0.0, rsum = 1.0;
-    if (live) {
-      r = (int)(((float)t + 0.5f) * (1.0f / (float)a.C));  // t < 2^20: float quotient, then exact
-      if (r * a.C > t) r--;
-      if ((r + 1) * a.C <= t) r++;
-      c = t - r * a.C;
-      n = n0 + r;
-      if (a.dig) {
-        const u64 d = a.dig[n * (i64)a.C + c];
-        k = dig_k(d);
-        idx0 = dig_idx(d, 0);
-        idx1 = dig_idx(d, 1);
-      } else {
-        load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k, idx0, idx1);
-      }
-      l = a.lpj_in[n * a.ldo + a.col0 + c];
-      rmax = a.rowmax[n];
-      rsum = a.rowsum[n];
+  const double s = a.s2inv;
+  for (i64 n = (i64)blockIdx.x * W + wave; n < a.N; n += (i64)gridDim.x * W) {
+    for (int h = lane; h < 2 * H; h += 64) rowS[h] = 0.0;
+    const double rmax = a.rowmax[n], rsum = a.rowsum[n] + EVO_F64_TINY;
+    const double *Bn = a.Bm + n * H;
+    if (stage) {
+      for (int h = lane; h < H; h += 64) rowB[h] = Bn[h];
+      Bn = rowB;
     }
-    const bool over = live && k > 2;
-    append_begin<256>(lo, shard, (int)(n * a.C + c), over, ovf_buf, ovf_ctl);  // first barrier also covers the row zeroing
-    if (live && !over) {
-      const double q = exp(l + (0.0 - rmax));
-      if (q != 0.0 && k > 0) {
-        const double qn = q / (rsum + EVO_F64_TINY);
-        const double *Bn = a.Bm + n * a.H;
-        double4 d0 = a.D1[idx0], d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
-        double b0 = Bn[idx0], b1 = 0.0, g01 = 0.0, l00 = d0.w, l01 = 0.0, l10 = 0.0, l11 = 0.0;
-        if (k == 2) {
-          d1 = a.D1[idx1];
-          b1 = Bn[idx1];
-          const PairEntry pe = a.PT[(i64)idx0 * a.H + idx1];
-          g01 = pe.g01;
-          l00 = pe.l00;
-          l01 = pe.l01;
-          l10 = pe.l10;
-          l11 = pe.l11;
-          if (pe.singular != 0.0) atomicOr(a.err, 2);
+    const double4 *D1t = stage ? d1s : a.D1;
+    const double *lp = a.lpj_in + n * a.ldo + a.col0;
+    lds_wave_fence();
+    // Rounds of 64 states, four rounds per group, written as straight-line phases over the group so that the
+    // loads of all four rounds are in flight together: a wave's time per datapoint is its chain of dependent
+    // memory round trips (digest / lpj -> table and B gathers -> arithmetic), not its instruction count.
+    for (int c0 = 0; c0 < a.C; c0 += 4 * 64) {
+      constexpr int RG = 4;
+      bool live[RG];
+      int k[RG], idx0[RG], idx1[RG];
+      double l[RG];
+#pragma unroll
+      for (int u = 0; u < RG; u++) {  // phase A: the states and their lpj
+        const int c = c0 + 64 * u + lane;
+        live[u] = c < a.C;
+        k[u] = idx0[u] = idx1[u] = 0;
+        l[u] = 0.0;
+        if (a.dig) {
+          const u64 d = a.dig[n * (i64)a.C + (live[u] ? c : 0)];
+          k[u] = live[u] ? dig_k(d) : 0;
+          idx0[u] = dig_idx(d, 0);
+          idx1[u] = dig_idx(d, 1);
+        } else if (live[u]) {
+          load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k[u], idx0[u], idx1[u]);
         }
-        const double s = a.s2inv;
-        const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
-        const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
-        const double k0 = s * (l00 * v0 + l01 * v1) + d0.x;  // kappa = Lam v / sigma2 + mu  (sssc.py:574-575)
-        const double k1 = s * (l10 * v0 + l11 * v1) + d1.x;
-        double *es = rows + (size_t)r * 3 * a.H, *ez = es + a.H, *ed = ez + a.H;
-        unsafeAtomicAdd(&es[idx0], qn);
-        unsafeAtomicAdd(&ez[idx0], qn * k0);
-        unsafeAtomicAdd(&ed[idx0], qn * (l00 + k0 * k0));
-        if (k == 2) {
-          unsafeAtomicAdd(&es[idx1], qn);
-          unsafeAtomicAdd(&ez[idx1], qn * k1);
-          unsafeAtomicAdd(&ed[idx1], qn * (l11 + k1 * k1));
-          // Global f64 atomics are what bounds this kernel (~16 G/s, executed memory-side), so a pair
-          // state issues two, not three: the (idx1, idx0) element differs from the (idx0, idx1) one by
-          // qn (l10 - l01), a per-PAIR constant times sum(qn) = xss[o01]; sssc_finish_kernel adds it.
-          const i64 o01 = (i64)idx0 * a.H + idx1;
-          unsafeAtomicAdd(&a.xss[o01], qn);
-          unsafeAtomicAdd(&a.xszsz[o01], qn * (l01 + k0 * k1));
+        l[u] = lp[live[u] ? c : 0];
+      }
+      // states with more than two active latents: to the overflow list, one returning atomic per group that has
+      // any (issued now, its result is only needed after the arithmetic)
+      bool over[RG];
+      int n_over = 0, my_off[RG];
+#pragma unroll
+      for (int u = 0; u < RG; u++) {
+        over[u] = live[u] && k[u] > 2;
+        const u64 om = __ballot(over[u]);
+        my_off[u] = n_over + __popcll(om & ((1ull << lane) - 1ull));
+        n_over += __popcll(om);
+      }
+      int obase = 0;
+      if (n_over) {  // uniform
+        if (lane == 0) obase = atomicAdd(&lo.counts[shard], n_over);
+        obase = __shfl(obase, 0, 64);
+      }
+      // phase B: table entries and B values of every state of the group (harmless index 0 where unused)
+      bool act[RG], pair[RG];
+      double4 d0[RG], d1[RG];
+      double b0[RG], b1[RG];
+      PairEntry pe[RG];
+#pragma unroll
+      for (int u = 0; u < RG; u++) {
+        act[u] = live[u] && !over[u] && k[u] > 0;
+        pair[u] = act[u] && k[u] == 2;
+        const int i0 = act[u] ? idx0[u] : 0, i1 = pair[u] ? idx1[u] : 0;
+        d0[u] = D1t[i0];
+        b0[u] = Bn[i0];
+        d1[u] = D1t[i1];
+        b1[u] = Bn[i1];
+        pe[u] = a.PT[pair[u] ? (i64)i0 * H + i1 : 0];
+      }
+      // phase C: arithmetic, row moments (LDS), pair moments (bins)
+#pragma unroll
+      for (int u = 0; u < RG; u++) {
+        const double q = act[u] ? exp(l[u] + (0.0 - rmax)) : 0.0;
+        if (q != 0.0) {
+          const double qn = q / rsum;
+          double g01 = 0.0, l00 = d0[u].w, l01 = 0.0, l10 = 0.0, l11 = 0.0, mu1 = 0.0, g11 = 0.0, bb1 = 0.0;
+          if (pair[u]) {
+            g01 = pe[u].g01;
+            l00 = pe[u].l00;
+            l01 = pe[u].l01;
+            l10 = pe[u].l10;
+            l11 = pe[u].l11;
+            mu1 = d1[u].x;
+            g11 = d1[u].z;
+            bb1 = b1[u];
+            if (pe[u].singular != 0.0) atomicOr(a.err, 2);
+          }
+          const double mu0 = d0[u].x;
+          const double v0 = b0[u] - d0[u].z * mu0 - g01 * mu1;
+          const double v1 = bb1 - g01 * mu0 - g11 * mu1;
+          const double k0 = s * (l00 * v0 + l01 * v1) + mu0;  // kappa = Lam v / sigma2 + mu  (sssc.py:574-575)
+          const double k1 = s * (l10 * v0 + l11 * v1) + mu1;
+          unsafeAtomicAdd(&rowS[idx0[u]], qn);
+          unsafeAtomicAdd(&rowZ[idx0[u]], qn * k0);
+          unsafeAtomicAdd(&accD[idx0[u]], qn * (l00 + k0 * k0));
+          if (pair[u]) {
+            unsafeAtomicAdd(&rowS[idx1[u]], qn);
+            unsafeAtomicAdd(&rowZ[idx1[u]], qn * k1);
+            unsafeAtomicAdd(&accD[idx1[u]], qn * (l11 + k1 * k1));
+            // element (idx0, idx1) of the two H x H sums; the (idx1, idx0) element of xszsz differs by
+            // qn (l10 - l01), a per-PAIR constant times xss[o01]: sssc_finish_kernel adds it
+            const double pq = qn, pv = qn * (l01 + k0 * k1);
+            bool direct = !binned;
+            if (binned) {
+              const int f = pb_fold(idx0[u], H);
+              const int bin = f / pb.rf;
+              const int pos = atomicAdd(&bcnt[bin], 1);  // LDS: the workgroup's running count for this bin
+              if (pos < pb.cap) {
+                const int r = 2 * (f - bin * pb.rf) + (idx0[u] != f ? 1 : 0);
+                const size_t at = ((size_t)bin * pb.nwg + blockIdx.x) * pb.cap + pos;
+                pb.keys[at] = ((unsigned)r << 16) | (unsigned)idx1[u];
+                pb.qv[at] = make_double2(pq, pv);
+              } else {
+                direct = true;  // region full
+              }
+            }
+            if (direct) {
+              const i64 o01 = (i64)idx0[u] * H + idx1[u];
+              unsafeAtomicAdd(&a.xss[o01], pq);
+              unsafeAtomicAdd(&a.xszsz[o01], pv);
+            }
+          }
         }
       }
+#pragma unroll
+      for (int u = 0; u < RG; u++)
+        if (over[u]) {
+          const int pos = obase + my_off[u];
+          if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = (int)(n * a.C + c0 + 64 * u + lane);
+        }
     }
-    append_end<256>(lo, shard, ovf_buf, ovf_ctl);
-    lds_barrier();  // ovf_ctl / ovf_buf are reused by the next chunk (LDS only: do not wait for the global atomics)
+    lds_wave_fence();
+    // the datapoint's rows: out to [Y | Es | Ez] for the contraction, and into the workgroup's column sums
+    double *es = a.Es + n * a.ldE, *ez = a.Ez + n * a.ldE;
+    for (int h = lane; h < H; h += 64) {
+      const double vs = rowS[h], vz = rowZ[h];
+      es[h] = vs;
+      ez[h] = vz;
+      if (vs != 0.0) {
+        unsafeAtomicAdd(&accS[h], vs);
+        unsafeAtomicAdd(&accZ[h], vz);
+      }
+    }
+    lds_wave_fence();
   }
-  for (int i = threadIdx.x; i < nrows * a.H; i += 256) {
-    const int r = i / a.H, h = i - r * a.H;
-    a.Es[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + h];
-    a.Ez[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + a.H + h];
-    a.Ed[(n0 + r) * a.ldE + h] = rows[(size_t)r * 3 * a.H + 2 * a.H + h];
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += 64 * W) {
+    if (accS[h] != 0.0) {
+      unsafeAtomicAdd(&a.cs_s[h], accS[h]);
+      unsafeAtomicAdd(&a.cs_z[h], accZ[h]);
+    }
+    if (accD[h] != 0.0) unsafeAtomicAdd(&a.cs_d[h], accD[h]);
   }
+  if (binned)
+    for (int i = threadIdx.x; i < pb.nb; i += 64 * W) {
+      const int cnt = bcnt[i];
+      pb.gcnt[(size_t)i * pb.nwg + blockIdx.x] = cnt < pb.cap ? cnt : pb.cap;
+    }
 }
 
 // xpt_ss: mirror the strict upper triangle and put xpt_s on the diagonal.
@@ -970,7 +1150,13 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
         fv[lane] = kap;
         unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
         unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
-        unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
+        if (a.cs_s) {
+          unsafeAtomicAdd(&a.cs_s[idx[lane]], qn);
+          unsafeAtomicAdd(&a.cs_z[idx[lane]], qn * kap);
+          unsafeAtomicAdd(&a.cs_d[idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
+        } else {
+          unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
+        }
       }
       lds_barrier();
       for (int q = lane; q < k * k; q += 64) {
@@ -1001,14 +1187,22 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
   // the three column sums of latent i are taken by three different threads of row i (the diagonal one
   // and its two right-hand neighbours, cyclically): each is a chain of nblk dependent additions
   const bool wide = H >= 3;
-  if (i == j) {
-    const double s = ordered_strided_sum(part + i, 3 * (i64)H, nblk);
-    xs[i] = s;
-    xss[t] = s;
+  if (nblk == 0) {
+    // the statistics kernels accumulated the column sums themselves: xs / xsz are final, `part` is the diagonal of xszsz
+    if (i == j) {
+      xss[t] = xs[i];
+      xszsz[t] = part[i];
+    }
+  } else {
+    if (i == j) {
+      const double s = ordered_strided_sum(part + i, 3 * (i64)H, nblk);
+      xs[i] = s;
+      xss[t] = s;
+    }
+    if (wide ? (j == (i + 1 == H ? 0 : i + 1)) : (i == j)) xsz[i] = ordered_strided_sum(part + H + i, 3 * (i64)H, nblk);
+    if (wide ? (j == (i + 2 >= H ? i + 2 - H : i + 2)) : (i == j))
+      xszsz[(i64)i * H + i] = ordered_strided_sum(part + 2 * H + i, 3 * (i64)H, nblk);
   }
-  if (wide ? (j == (i + 1 == H ? 0 : i + 1)) : (i == j)) xsz[i] = ordered_strided_sum(part + H + i, 3 * (i64)H, nblk);
-  if (wide ? (j == (i + 2 >= H ? i + 2 - H : i + 2)) : (i == j))
-    xszsz[(i64)i * H + i] = ordered_strided_sum(part + 2 * H + i, 3 * (i64)H, nblk);
   if (i < j) {
     // this thread owns both (i,j) and (j,i).  xss / xszsz hold the upper-triangle sums of the pair
     // states (sssc_stats_kernel), xss_o / xszsz_o what the overflow kernels added (any k).

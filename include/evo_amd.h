@@ -85,7 +85,12 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "stats_chunks" (1 .. 16, default 1; measured slower than one block at the north-star shape, kept for A/B): the statistics pass of large shards (contraction >= 8 GFLOP) runs in that many
  * blocks of datapoints; the MFMA contraction of block i runs on the second stream beside the scatter kernels of block
  * i + 1 (those are bound by the f64 atomic rate, the contraction by the matrix cores); 1 = one block.  "overlap_gemm" = 0
- * switches this off as well.  "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
+ * switches this off as well.  "pair_bins" (0 / 1 / 2, default 1): the ES3C statistics pass appends the second-moment
+ * contributions of the states with two active latents to row bins and reduces each bin in an LDS tile instead of
+ * issuing two global f64 atomics per state: never / when the tiles' flush is a small part of the contributions
+ * (large N S) / always.  "stats_stage" (0/1, default 1): that kernel stages the B row of each datapoint and the singleton table
+ * in LDS when two workgroups per CU still fit.  "stats_waves" (0 / 8 / 16, measurement aid): waves per workgroup of the
+ * ES3C statistics kernel (0 = 4).  "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh). */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 

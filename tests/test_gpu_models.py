@@ -50,6 +50,20 @@ def test_trajectory_bsc_direct_form(engine, name):
         engine.set_option("bsc_direct", 0)
 
 
+@pytest.mark.parametrize("name", ["es3c_bars", "es3c_mid", "es3c_dense", "es3c_cross", "es3c_perm"])
+def test_trajectory_es3c_pair_bins(engine, name):
+    """Same trajectories with the pair second moments going through the row bins + LDS tiles (the path large
+    shards take by themselves: option pair_bins = 2 forces it at any size), and at a BASELINE shape."""
+    try:
+        engine.set_option("pair_bins", 2)
+        test_trajectory_reference_rng(engine, name)
+        if name == "es3c_mid":
+            test_shape_trajectory(engine, "c2_small", False)
+            test_shape_trajectory(engine, "c4_small", False)
+    finally:
+        engine.set_option("pair_bins", 1)
+
+
 @pytest.mark.parametrize("name", STEP_FIXTURES)
 def test_trajectory_reference_rng(engine, name):
     """Theta and K^n are carried from step to step (not reloaded), so errors would compound:
@@ -291,8 +305,11 @@ def test_overlap_gemm_option(engine, algo):
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
     cls = BSC if algo == "ebsc" else SSSC
     out = []
-    for ov in (2, 0):  # 2 = always (1 = only for the shapes where it was measured to pay)
+    for ov, chunks in ((2, 1), (0, 1), (2, 3)):  # 2 = always (1 = only for the shapes where it was measured to pay)
+        # chunks = 3: the statistics pass in three blocks of datapoints, each block's contraction accumulating on
+        # the second stream beside the next block's scatter kernels (overflow census summed over the blocks)
         engine.set_option("overlap_gemm", ov)
+        engine.set_option("stats_chunks", chunks)
         try:
             np.random.seed(3)
             model = cls(D, H, S, rng="device", sync_host=True, engine=engine, seed=5)
@@ -305,9 +322,11 @@ def test_overlap_gemm_option(engine, algo):
             out.append((np.array(Fs), {k: np.array(v) for k, v in theta.items()}))
         finally:
             engine.set_option("overlap_gemm", 1)
-    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9)
-    for k in out[0][1]:
-        np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-7, atol=1e-10)
+            engine.set_option("stats_chunks", 1)
+    for other in (1, 2):
+        np.testing.assert_allclose(out[0][0], out[other][0], rtol=1e-9)
+        for k in out[0][1]:
+            np.testing.assert_allclose(out[0][1][k], out[other][1][k], rtol=1e-7, atol=1e-10)
 
 
 @pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense", "ebsc_perm", "es3c_perm"])
