@@ -155,6 +155,7 @@ struct evoamd_ctx {
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
   int pair_bins = 1;
+  int gemm_streamk = 1;  // option "gemm_streamk": long-K 128-tile contraction as one resident-sized stream-K grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
   double *census = nullptr;  // 4 doubles: overflow census of the earlier blocks of a chunked statistics pass
@@ -405,6 +406,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
+  HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_sk_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM128_LDS_BYTES));
   {
     const void *wk[] = {(const void *)sssc_stats_wave_kernel<0, 4>,  (const void *)sssc_stats_wave_kernel<1, 4>,
                         (const void *)sssc_stats_wave_kernel<2, 4>,  (const void *)sssc_stats_wave_kernel<4, 4>,
@@ -412,6 +415,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                         (const void *)sssc_stats_wave_kernel<0, 1>,  (const void *)sssc_stats_wave_kernel<0, 8>,
                         (const void *)sssc_stats_wave_kernel<0, 16>};
     for (const void *f : wk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<4, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<8, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   }
   *out = c;
   return 0;
@@ -495,6 +500,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "pair_bins") == 0) {
     c->pair_bins = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_streamk") == 0) {
+    c->gemm_streamk = value;
     return 0;
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
@@ -983,7 +992,18 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
   }
   const unsigned grid = (unsigned)(tiles * (split ? splits : 1));
   SpanGuard g(c, KID_GEMM);
-  if (big)
+  if (big && split && c->gemm_streamk) {
+    // stream-K: one resident-sized grid, every XCD owns an eighth of K (option "gemm_streamk")
+    i64 real = tiles;
+    if (sym_row0 >= 0) {
+      const i64 ts = cdiv(Nc, T);
+      real -= ts * (ts - 1) / 2;
+    }
+    const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
+    gemm_tn128_sk_f64<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0,
+                                                                       (int)real);
+  } else if (big)
     gemm_tn128_f64<<<grid, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   else if (vec)
     gemm_tn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
@@ -2051,11 +2071,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
         const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
+        const size_t cs_lds = sc.cs_s ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
         if (need[0])
-          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, 0, c->stream>>>(sc, i1, o2);
+          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2);
         if (use_k8_kernel(c, tg)) {
           if (need[1])
-            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, 0, c->stream>>>(sc, i2, o3);
+            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3);
         } else if (need[1]) {
           sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sc, i2, o3, 8);
         }

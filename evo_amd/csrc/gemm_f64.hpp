@@ -181,21 +181,12 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
 #define GEMM_T 128
 #define GEMM_LDS2 144
 #define GEMM128_LDS_BYTES (2 * 2 * GEMM_BK * GEMM_LDS2 * sizeof(double))
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_f64(const double *__restrict__ A, int lda,
-                                                      const double *__restrict__ B, int ldb,
-                                                      double *__restrict__ C, int ldc, int M, int Nc, i64 K,
-                                                      i64 k_per_split, int gx, int gy, int split, int sym_row0) {
-  extern __shared__ double lds128[];
-  double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
-  double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
-  const int tiles = gx * gy;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int zc = split ? xcd + 8 * (jj / tiles) : 0;
-  const int tile = split ? jj % tiles : (int)blockIdx.x;
-  const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
-  if (sym_row0 >= 0 && m0 >= sym_row0 && m0 - sym_row0 > n0) return;  // uniform
-  const i64 kbeg = (i64)zc * k_per_split;
-  const i64 kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+// One K range [kbeg, kend) of one 128 x 128 output tile at (m0, n0): the body both 128-tile kernels share.
+// atomic: add the tile to C with f64 atomics (split K / stream-K), else store it.
+__device__ __forceinline__ void gemm_tn128_segment(const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
+                                                   double *__restrict__ C, int ldc, int M, int Nc, int m0, int n0, i64 kbeg,
+                                                   i64 kend, bool atomic, double (*As)[GEMM_BK][GEMM_LDS2],
+                                                   double (*Bs)[GEMM_BK][GEMM_LDS2]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   v4f64 acc[4][4];
@@ -276,12 +267,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
         const int col = n0 + wn * 64 + j * 16 + (lane & 15);
         if (row < M && col < Nc) {
-          if (split)
+          if (atomic)
             unsafeAtomicAdd(&C[(i64)row * ldc + col], acc[i][j][r]);
           else
             C[(i64)row * ldc + col] = acc[i][j][r];
         }
       }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_f64(const double *__restrict__ A, int lda,
+                                                      const double *__restrict__ B, int ldb,
+                                                      double *__restrict__ C, int ldc, int M, int Nc, i64 K,
+                                                      i64 k_per_split, int gx, int gy, int split, int sym_row0) {
+  extern __shared__ double lds128[];
+  double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
+  double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int tiles = gx * gy;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int zc = split ? xcd + 8 * (jj / tiles) : 0;
+  const int tile = split ? jj % tiles : (int)blockIdx.x;
+  const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+  if (sym_row0 >= 0 && m0 >= sym_row0 && m0 - sym_row0 > n0) return;  // uniform
+  const i64 kbeg = (i64)zc * k_per_split;
+  const i64 kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, split != 0, As, Bs);
+}
+
+// Stream-K form of the same contraction: exactly as many workgroups as the chip holds at once (wpx per XCD, 2 per
+// CU).  XCD x owns the K range [x Kx, (x + 1) Kx) of EVERY tile (that slice of A and B stays in one L2); its
+// wpx workgroups cut the (real tile, K slab) units of that range into wpx equal runs, so a workgroup works through
+// one or two tile segments back to back and everybody finishes together.  Against the split-K grid above (tiles x
+// 64 chunks = 4.25 rounds of resident workgroups at the north-star shape) there is no ramp per round, no
+// partial last round, and a third of the atomic epilogues (~ (tiles + wpx) per XCD instead of 8 tiles).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_sk_f64(
+    const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M,
+    int Nc, i64 K, i64 Kx, int gx, int gy, int sym_row0, int n_real) {
+  extern __shared__ double lds128[];
+  double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
+  double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const i64 kx0 = (i64)xcd * Kx;
+  const i64 kx1 = (kx0 + Kx < K) ? kx0 + Kx : K;
+  if (kx1 <= kx0) return;
+  const i64 slabs = (kx1 - kx0 + GEMM_BK - 1) / GEMM_BK;
+  const i64 U = (i64)n_real * slabs;
+  i64 u = U * w / wpx;
+  const i64 u1 = U * (w + 1) / wpx;
+  while (u < u1) {  // uniform
+    const int rt = (int)(u / slabs);
+    const i64 sb = u - (i64)rt * slabs;
+    i64 se = sb + (u1 - u);
+    if (se > slabs) se = slabs;
+    // the rt-th real tile in row-major order (strictly lower tiles of the symmetric block do not exist)
+    int tile = 0, seen = -1;
+    for (int tt = 0; tt < gx * gy; tt++) {
+      const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
+      if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
+      if (++seen == rt) {
+        tile = tt;
+        break;
+      }
+    }
+    const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+    const i64 kbeg = kx0 + sb * GEMM_BK;
+    i64 kend = kx0 + se * GEMM_BK;
+    if (kend > kx1) kend = kx1;
+    gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs);
+    u += se - sb;
+  }
 }
 
 // C (M x Nc) = A B with A: M x K (lda) row-major, B: K x Nc (ldb).  No K split (K = D or H is small).

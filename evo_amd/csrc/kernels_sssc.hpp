@@ -366,6 +366,14 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int ovf_buf[BS];
   __shared__ int ovf_ctl[2];
+  // statistics with in-kernel column sums (a.cs_s): 3 H doubles of dynamic LDS collect this workgroup's share of
+  // sum_n xpt_s / xpt_sz / diag(xpt_szsz); as global atomics they were 9-12 per state on 3 H addresses (+150 us)
+  extern __shared__ double cs_acc[];
+  const bool cs_lds = MODE == 1 && a.cs_s != nullptr;
+  if (cs_lds) {
+    for (int i = threadIdx.x; i < 3 * a.H; i += BS) cs_acc[i] = 0.0;
+    __syncthreads();
+  }
   const i64 total = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
   i64 round = blockIdx.x;
   for (i64 base = (i64)blockIdx.x * BS; base < total; base += (i64)gridDim.x * BS, round += gridDim.x) {
@@ -428,15 +436,25 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
           unsafeAtomicAdd(&a.Es[n * a.ldE + idx[i]], qn);
           unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[i]], qn * kap[i]);
           if (a.cs_s) {  // the main kernel summed its columns already: add this state's share
-            unsafeAtomicAdd(&a.cs_s[idx[i]], qn);
-            unsafeAtomicAdd(&a.cs_z[idx[i]], qn * kap[i]);
-            unsafeAtomicAdd(&a.cs_d[idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
+            unsafeAtomicAdd(&cs_acc[idx[i]], qn);
+            unsafeAtomicAdd(&cs_acc[a.H + idx[i]], qn * kap[i]);
+            unsafeAtomicAdd(&cs_acc[2 * a.H + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
           } else {
             unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
           }
         }
       }
       sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
+    }
+  }
+  if (cs_lds) {
+    __syncthreads();
+    for (int h = threadIdx.x; h < a.H; h += BS) {
+      if (cs_acc[h] != 0.0) {
+        unsafeAtomicAdd(&a.cs_s[h], cs_acc[h]);
+        unsafeAtomicAdd(&a.cs_z[h], cs_acc[a.H + h]);
+        unsafeAtomicAdd(&a.cs_d[h], cs_acc[2 * a.H + h]);
+      }
     }
   }
 }
