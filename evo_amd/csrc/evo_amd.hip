@@ -158,7 +158,8 @@ struct evoamd_ctx {
   int gemm_streamk = 1;  // option "gemm_streamk": long-K 128-tile contraction as one resident-sized stream-K grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
-  double *census = nullptr;  // 4 doubles: overflow census of the earlier blocks of a chunked statistics pass
+  double *census = nullptr;  // 4 doubles at the head of acc_base: overflow census of the earlier blocks of a chunked statistics pass
+  i64 pre_n = 4;
   hipEvent_t ev_chunk[16] = {};
   bool configured = false, have_data = false, have_params = false, have_cand = false, B_valid = false;
   // which ES3C overflow levels (K=4, K=8, LDS) the next pass over K^n needs; exact, from the
@@ -395,7 +396,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
-  HIP_TRY(hipMalloc((void **)&c->census, 4 * sizeof(double)));
+
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -457,7 +458,7 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 16; i++)
     if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
-  if (c->census) (void)hipFree(c->census);
+
   delete c;
 }
 
@@ -632,8 +633,12 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     c->Es = nullptr;  // lives inside c->Y for SSSC
   }
   c->acc_n = acc_len(c);
-  c->ovf_n = (model == EVOAMD_MODEL_SSSC) ? 2 * (i64)H * H : 0;
-  ALLOC(c->acc_base, (size_t)c->ovf_n + c->acc_n + DP_COUNT);  // [overflow H x H pair |] packed accumulator, then the scalar block (one D2H)
+  // in front of the packed accumulator, cleared by the same memset: [overflow census (4) | CS_SLICES column-sum
+  // slices of 3 H | overflow H x H pair] (ES3C)
+  c->pre_n = (model == EVOAMD_MODEL_SSSC) ? 4 + (i64)CS_SLICES * 3 * H : 4;
+  c->ovf_n = c->pre_n + ((model == EVOAMD_MODEL_SSSC) ? 2 * (i64)H * H : 0);
+  ALLOC(c->acc_base, (size_t)c->ovf_n + c->acc_n + DP_COUNT);  // [... |] packed accumulator, then the scalar block (one D2H)
+  c->census = c->acc_base;
   c->acc = c->acc_base + c->ovf_n;
   c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 4);
@@ -1306,6 +1311,15 @@ static bool use_k8_kernel(const evoamd_ctx *c, int tag) {
   return expect > 8192.0;
 }
 
+// Few enough states above 4 active latents (known from the last statistics pass) that the two wavefront levels
+// (k <= 8, then k <= KCAP) are better served by one launch at full capacity.
+static bool few_dense_states(const evoamd_ctx *c, int tag) {
+  if (!c->need_known || tag == 2) return false;
+  if (tag == 0 && c->conservative_levels) tag = 1;
+  const double expect = c->grid_scale * (tag == 0 ? c->res_cnt[1] : c->res_cnt[1] + c->res_cnt[0] * (double)c->Cmax / (double)c->S);
+  return expect <= 1024.0;
+}
+
 static int zero_lists(evoamd_ctx *c) {
   if (!c->lists_clean) {
     if (c->pending_skip)  // no clearing kernel ran since the last chain: check its skipped levels here
@@ -1375,6 +1389,7 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     SpanGuard g(c, KID_LPJ_OVF);
     // the levels carry the pass's TAG in their names, so a kernel trace separates the pass over K^n from the
     // candidate batch level by level
+    bool merged23 = false;
     if (need[0])
       sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
     DBG_SYNC(c, "sssc lpj K=4 level");
@@ -1382,13 +1397,19 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     if (use_k8_kernel(c, TAG)) {
       if (need[1])
         sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
+    } else if (need[1] && few_dense_states(c, TAG)) {
+      // a handful of states above 4 active latents: ONE launch of the wavefront kernel at full capacity serves list 2
+      // (a launch costs ~8 us however little it does; the k <= 8 sizing only pays for thousands of states)
+      sssc_big_kernel<0, TAG><<<level_grid(c, 1, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+          a, i2, none_out, SSSC_KCAP);
+      merged23 = true;
     } else if (need[1]) {
       // a few thousand states above 4 active latents: the wavefront-per-state kernel, sized for k <= 8
       // (1.9 KiB of LDS, many workgroups per CU); anything denser moves on to list 3
       sssc_big_kernel<0, TAG><<<level_grid(c, 1, TAG, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(a, i2, o3, 8);
     }
     DBG_SYNC(c, "sssc lpj K=8 level");
-    if (need[2])
+    if (need[2] && !merged23)
       sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
           a, i3, none_out, SSSC_KCAP);
     HIP_TRY(hipGetLastError());
@@ -1871,7 +1892,6 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const int H = c->H, D = c->D;
   const bool masked = c->mask_infr != nullptr;
   HIP_TRY(hipMemsetAsync(c->acc_base, 0, (size_t)(c->ovf_n + c->acc_n) * sizeof(double), c->stream));
-  HIP_TRY(hipMemsetAsync(c->census, 0, 4 * sizeof(double), c->stream));
   c->yhat_valid = c->stats_rows_valid = false;
   int r = ensure_B(c);
   if (r) return r;
@@ -1918,14 +1938,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     sa.ldE = c->ldY;
     sa.xss = c->acc + a.xss;
     sa.xszsz = c->acc + a.xszsz;
-    sa.xss_o = c->acc_base;
-    sa.xszsz_o = c->acc_base + (size_t)H * H;
-    if (!masked) {  // the kernels sum the columns of [Es | Ez] and the diagonal second moments themselves
-      sa.cs_s = c->acc + a.xs;
-      sa.cs_z = c->acc + a.xsz;
-      sa.cs_d = c->diag;
-      HIP_TRY(hipMemsetAsync(c->diag, 0, (size_t)H * sizeof(double), c->stream));
-    }
+    sa.xss_o = c->acc_base + c->pre_n;
+    sa.xszsz_o = c->acc_base + c->pre_n + (size_t)H * H;
+    if (!masked) sa.cs = c->acc_base + 4;  // the kernels sum the columns of [Es | Ez] and the diagonal second moments themselves
     cap = (int)list_cap(N * (i64)c->S);
     // the final K^n is made of resident states and accepted candidates: same levels as the candidates
     levels_for(c, 1, need);
@@ -2020,7 +2035,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       {
         // one wave per datapoint, persistent workgroups: W x 2 H doubles of rows + 3 H of column accumulators in LDS
         int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) + 2048 <= 159 * 1024 ? 4 : 1;
-        if (c->stats_waves == 8 || c->stats_waves == 16) Wv = c->stats_waves;  // measurement option (digest path only)
+        // (8 / 16 waves per workgroup were measured: c4 8 waves -4 %, 16 waves 2x slower; c2 16 waves 112 vs 74 us)
+        if (c->stats_waves == 4 || c->stats_waves == 8 || c->stats_waves == 16) Wv = c->stats_waves;  // measurement option
         size_t lds = (size_t)(Wv * 2 + 3) * H * sizeof(double);
         REQUIRE(lds + 2048 <= 159 * 1024, "ES3C statistics: H too large for the LDS rows (H <= 4000)");
         // B row of each wave's datapoint + the singleton table in LDS too when that still leaves two workgroups per CU
@@ -2033,7 +2049,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
         SpanGuard g(c, KID_STATS);
-        int sgrid = (int)std::min<i64>(cdiv(nc, Wv), (i64)c->n_cu * per_cu);
+        // a wave per datapoint while that is at most a few rounds of resident workgroups (a second datapoint per wave
+        // doubles the kernel's critical path at small N), a persistent grid-stride loop beyond
+        int sgrid = (int)std::min<i64>(cdiv(nc, Wv), (i64)c->n_cu * per_cu * 4);
         // pair bins pay when the tiles' flush is a small part of the contributions they absorb
         PairBins pb = {};
         if (c->pbins.keys && (c->pair_bins == 2 ||
@@ -2071,16 +2089,21 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
         const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
-        const size_t cs_lds = sc.cs_s ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
+        const size_t cs_lds = sc.cs ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
+        bool merged23 = false;
         if (need[0])
           sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2);
         if (use_k8_kernel(c, tg)) {
           if (need[1])
             sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3);
+        } else if (need[1] && few_dense_states(c, tg)) {
+          sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+              sc, i2, none_out, SSSC_KCAP);  // one launch for both wavefront levels (see launch_sssc_lpj)
+          merged23 = true;
         } else if (need[1]) {
           sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sc, i2, o3, 8);
         }
-        if (need[2])
+        if (need[2] && !merged23)
           sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
               sc, i3, none_out, SSSC_KCAP);
         HIP_TRY(hipGetLastError());
@@ -2090,6 +2113,27 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       skipped = skip_mask(need);
     }
     c->grid_scale = 1.0;
+    if (ci == nchunks - 1) {
+      // (before this block's contraction is enqueued: on one stream the span of the statistics pass must not cover it)
+      // ---- the sums of the scattered moments are complete: mirror / diagonals / column sums
+      {
+        SpanGuard g(c, KID_MISC);
+        if (c->model == EVOAMD_MODEL_BSC) {
+          bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
+                                                                           c->partial2, cdiv(N, 4), c->acc + a.sigma);
+        } else {
+          const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
+          // complete data: the kernels left the column sums in CS_SLICES slices; else per-block partials of the rows
+          sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
+                                                                     c->acc + a.xsz, masked ? c->colpart : sa.cs,
+                                                                     masked ? nblk : CS_SLICES, H, c->y2sum, c->acc + a.y2, D,
+                                                                     sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT);
+        }
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "colsum + finish");
+      }
+      pass.reset();
+    }
     // ---- this block's part of the K = N contraction
     if (c->model == EVOAMD_MODEL_SSSC && masked) continue;  // two products from the reconstructed rows, below
     if (second_stream) {
@@ -2110,24 +2154,6 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     c->stream = main_stream;
     if (r) return r;
   }
-  // ---- the sums of the scattered moments are complete: mirror / diagonals / column sums
-  {
-    SpanGuard g(c, KID_MISC);
-    if (c->model == EVOAMD_MODEL_BSC) {
-      bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
-                                                                       c->partial2, cdiv(N, 4), c->acc + a.sigma);
-    } else {
-      const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
-      // complete data: the kernels left the column sums in xs / xsz / diag (nblk = 0); else per-block partials
-      sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
-                                                                 c->acc + a.xsz, masked ? c->colpart : c->diag,
-                                                                 masked ? nblk : 0, H, c->y2sum, c->acc + a.y2, D,
-                                                                 sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT);
-    }
-    HIP_TRY(hipGetLastError());
-    DBG_SYNC(c, "colsum + finish");
-  }
-  pass.reset();
   if (c->model == EVOAMD_MODEL_SSSC && masked) {
     // y_hat = Ez W^T with the Theta of this E-step: the reconstruction (sssc.py:613-627), the rows the Wp
     // contraction reads (:631) and, squared over the reliable entries, the trace term of sigma2 (:640-645,751)

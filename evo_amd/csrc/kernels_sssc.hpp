@@ -34,6 +34,7 @@ struct PairEntry {
   double pad;
 };
 
+#define CS_SLICES 16
 struct SsscArgs {
   const u64 *states;     // (shared ? 1 : N) x C x HW
   const u64 *dig;        // (N x C) state digests or nullptr (common.hpp)
@@ -61,9 +62,11 @@ struct SsscArgs {
   const double *rowmax, *rowsum;
   double *Es, *Ez, *Ed;   // (N, ldE) rows per datapoint: xpt_s, xpt_sz and the DIAGONAL of xpt_szsz
   int ldE;
-  // column sums over the datapoints, accumulated by the kernels themselves (H each, zero-initialised): sum_n xpt_s,
-  // sum_n xpt_sz, diagonal of sum_n xpt_szsz.  nullptr: the Ed rows + a separate column-sum pass (incomplete data).
-  double *cs_s, *cs_z, *cs_d;
+  // column sums over the datapoints, accumulated by the kernels themselves: CS_SLICES slices of 3 H doubles
+  // (sum_n xpt_s | sum_n xpt_sz | diagonal of sum_n xpt_szsz), zero-initialised; a workgroup adds its LDS sums to slice
+  // blockIdx % CS_SLICES (3 H atomics per workgroup, contention spread over the slices) and sssc_finish_kernel adds
+  // the slices.  nullptr: the Ed rows + a separate column-sum pass (incomplete data).
+  double *cs;
   double *xss, *xszsz;    // (H,H) zero-initialised: strict UPPER triangle sums of the states with 2 active latents
   double *xss_o, *xszsz_o;  // (H,H) zero-initialised: what the overflow kernels (> 2 active latents) add, xszsz_o both triangles
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
   // statistics with in-kernel column sums (a.cs_s): 3 H doubles of dynamic LDS collect this workgroup's share of
   // sum_n xpt_s / xpt_sz / diag(xpt_szsz); as global atomics they were 9-12 per state on 3 H addresses (+150 us)
   extern __shared__ double cs_acc[];
-  const bool cs_lds = MODE == 1 && a.cs_s != nullptr;
+  const bool cs_lds = MODE == 1 && a.cs != nullptr;
   if (cs_lds) {
     for (int i = threadIdx.x; i < 3 * a.H; i += BS) cs_acc[i] = 0.0;
     __syncthreads();
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
         if (i < k) {
           unsafeAtomicAdd(&a.Es[n * a.ldE + idx[i]], qn);
           unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[i]], qn * kap[i]);
-          if (a.cs_s) {  // the main kernel summed its columns already: add this state's share
+          if (a.cs) {  // the main kernel summed its columns already: add this state's share
             unsafeAtomicAdd(&cs_acc[idx[i]], qn);
             unsafeAtomicAdd(&cs_acc[a.H + idx[i]], qn * kap[i]);
             unsafeAtomicAdd(&cs_acc[2 * a.H + idx[i]], qn * (P[i][i] + kap[i] * kap[i]));
@@ -449,11 +452,12 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
   }
   if (cs_lds) {
     __syncthreads();
+    double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * a.H;
     for (int h = threadIdx.x; h < a.H; h += BS) {
       if (cs_acc[h] != 0.0) {
-        unsafeAtomicAdd(&a.cs_s[h], cs_acc[h]);
-        unsafeAtomicAdd(&a.cs_z[h], cs_acc[a.H + h]);
-        unsafeAtomicAdd(&a.cs_d[h], cs_acc[2 * a.H + h]);
+        unsafeAtomicAdd(&sl[h], cs_acc[h]);
+        unsafeAtomicAdd(&sl[a.H + h], cs_acc[a.H + h]);
+        unsafeAtomicAdd(&sl[2 * a.H + h], cs_acc[2 * a.H + h]);
       }
     }
   }
@@ -929,12 +933,13 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
     lds_wave_fence();
   }
   __syncthreads();
+  double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * H;
   for (int h = threadIdx.x; h < H; h += 64 * W) {
     if (accS[h] != 0.0) {
-      unsafeAtomicAdd(&a.cs_s[h], accS[h]);
-      unsafeAtomicAdd(&a.cs_z[h], accZ[h]);
+      unsafeAtomicAdd(&sl[h], accS[h]);
+      unsafeAtomicAdd(&sl[H + h], accZ[h]);
     }
-    if (accD[h] != 0.0) unsafeAtomicAdd(&a.cs_d[h], accD[h]);
+    if (accD[h] != 0.0) unsafeAtomicAdd(&sl[2 * H + h], accD[h]);
   }
   if (binned)
     for (int i = threadIdx.x; i < pb.nb; i += 64 * W) {
@@ -1168,10 +1173,11 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
         fv[lane] = kap;
         unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
         unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
-        if (a.cs_s) {
-          unsafeAtomicAdd(&a.cs_s[idx[lane]], qn);
-          unsafeAtomicAdd(&a.cs_z[idx[lane]], qn * kap);
-          unsafeAtomicAdd(&a.cs_d[idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
+        if (a.cs) {  // (few states reach this kernel: straight to a slice)
+          double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * a.H;
+          unsafeAtomicAdd(&sl[idx[lane]], qn);
+          unsafeAtomicAdd(&sl[a.H + idx[lane]], qn * kap);
+          unsafeAtomicAdd(&sl[2 * a.H + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
         } else {
           unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
         }
@@ -1205,22 +1211,14 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
   // the three column sums of latent i are taken by three different threads of row i (the diagonal one
   // and its two right-hand neighbours, cyclically): each is a chain of nblk dependent additions
   const bool wide = H >= 3;
-  if (nblk == 0) {
-    // the statistics kernels accumulated the column sums themselves: xs / xsz are final, `part` is the diagonal of xszsz
-    if (i == j) {
-      xss[t] = xs[i];
-      xszsz[t] = part[i];
-    }
-  } else {
-    if (i == j) {
-      const double s = ordered_strided_sum(part + i, 3 * (i64)H, nblk);
-      xs[i] = s;
-      xss[t] = s;
-    }
-    if (wide ? (j == (i + 1 == H ? 0 : i + 1)) : (i == j)) xsz[i] = ordered_strided_sum(part + H + i, 3 * (i64)H, nblk);
-    if (wide ? (j == (i + 2 >= H ? i + 2 - H : i + 2)) : (i == j))
-      xszsz[(i64)i * H + i] = ordered_strided_sum(part + 2 * H + i, 3 * (i64)H, nblk);
+  if (i == j) {
+    const double s = ordered_strided_sum(part + i, 3 * (i64)H, nblk);
+    xs[i] = s;
+    xss[t] = s;
   }
+  if (wide ? (j == (i + 1 == H ? 0 : i + 1)) : (i == j)) xsz[i] = ordered_strided_sum(part + H + i, 3 * (i64)H, nblk);
+  if (wide ? (j == (i + 2 >= H ? i + 2 - H : i + 2)) : (i == j))
+    xszsz[(i64)i * H + i] = ordered_strided_sum(part + 2 * H + i, 3 * (i64)H, nblk);
   if (i < j) {
     // this thread owns both (i,j) and (j,i).  xss / xszsz hold the upper-triangle sums of the pair
     // states (sssc_stats_kernel), xss_o / xszsz_o what the overflow kernels added (any k).
