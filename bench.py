@@ -120,29 +120,36 @@ def stats_kernels(cfg):
     hw = (cfg["H"] + 63) // 64
     hwt = hw if hw in (1, 2, 4, 8, 16) else 0
     if cfg["algo"] == "es3c":
-        return ["void sssc_stats_kernel<%d>" % hwt, "void sssc_small_kernel<4, 1, 2, 256>",
-                "void sssc_small_kernel<8, 1, 2, 256>", "void sssc_big_kernel<1, 2>", "colsum_partial_kernel",
-                "sssc_finish_kernel"]
+        return ["void sssc_stats_wave_kernel<%d, 4>" % hwt, "pair_bins_reduce_kernel", "void sssc_small_kernel<4, 1, 2, 256>",
+                "void sssc_small_kernel<8, 1, 2, 256>", "void sssc_big_kernel<1, 2>", "sssc_finish_kernel"]
     return ["void bsc_stats_kernel<%d>" % hwt, "colsum_partial_kernel", "bsc_finish_kernel"]
 
 
 def pmc_traffic(config, kernels):
-    """HBM bytes per pass = sum over `kernels` of bytes per launch from the committed rocprofv3 counter passes
-    (profiles/r02_<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs, read side corrected as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    """HBM bytes per pass = sum over `kernels` of (bytes per launch x launches per pass) from the committed
+    rocprofv3 counter passes (profiles/r02_<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  A pass is
+    one launch of the first kernel of the list; the conditional overflow levels count with their own launch
+    frequency.  None if the file is absent."""
     path = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % config)
     try:
         with open(path) as f:
             d = json.load(f)
     except Exception:
         return None
-    total, seen = 0.0, False
+
+    def find(k):
+        return [rec for name, rec in d.items() if name.startswith(k)]
+
+    main = find(kernels[0])
+    if not main:
+        return None
+    passes = float(main[0].get("launches", 1)) or 1.0
+    total = 0.0
     for k in kernels:
-        for name, rec in d.items():
-            if name.startswith(k):
-                total += float(rec["traffic_bytes_2xfetch_plus_write"]) * float(rec.get("launches_per_pass", 1.0))
-                seen = True
-    return total if seen else None
+        for rec in find(k):
+            total += float(rec["traffic_bytes_2xfetch_plus_write"]) * float(rec.get("launches", passes)) / passes
+    return total
 
 
 def algorithmic_bytes_pass(cfg, N):

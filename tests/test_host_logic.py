@@ -336,3 +336,36 @@ def test_standard_init_incomplete_data_matches_reference():
     th = model.check_params(model.standard_init({"y": g["Y"], "x_infr": g["x_infr"]}))
     for k in ("W", "pi", "sigma"):
         np.testing.assert_allclose(th[k], g["t0_in_%s" % k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_datalog_routes_like_the_reference(tmp_path, capsys):
+    """DataLog / TextPrinter / StoreToTxt / StoreToH5 (evo/utils/datalog.py:137-274, autotable.py:93-173): per-table
+    routing incl. the '*' wildcard, append_all handing every handler its own sub-dict, ignored(), one row per append.
+    PyTables is not in this image, so the table file is the NumPy container (same rows); with PyTables it is HDF5."""
+    from evo_amd.utils import autotable
+    from evo_amd.utils.datalog import DataLog, StoreToH5, StoreToTxt, TextPrinter
+    log = DataLog()
+    store = log.set_handler("*", StoreToH5, str(tmp_path / "training.h5"))
+    log.set_handler(("F", "S_nunique"), TextPrinter)
+    txt = log.set_handler("F", StoreToTxt, str(tmp_path / "f.txt"))
+    assert log.ignored("nothing") is False and DataLog().ignored("F")
+    W = np.arange(6.0).reshape(2, 3)
+    for e in range(3):
+        log.append_all({"F": -10.0 + e, "S_nunique": 3.5, "W": W + e})
+    log.append("note", "hello")
+    out = capsys.readouterr().out
+    assert out.count("F = ") == 3 and out.count("S_nunique = ") == 3 and "W =" not in out
+    log.remove_handler(txt)
+    assert (tmp_path / "f.txt").read_text().splitlines() == ["F = -10.0", "F = -9.0", "F = -8.0"]
+    with pytest.raises(TypeError):
+        store.append("W", np.zeros((3, 3)))  # rows of one table share a shape (autotable.py:124-127)
+    log.close()
+    if autotable._tables is None:
+        d = np.load(tmp_path / "training.npz")
+        np.testing.assert_array_equal(d["F"], [-10.0, -9.0, -8.0])
+        assert d["W"].shape == (3, 2, 3) and np.array_equal(d["W"][2], W + 2) and d["note"][0] == "hello"
+    else:
+        import tables
+        with tables.open_file(str(tmp_path / "training.h5")) as h5:
+            np.testing.assert_array_equal(h5.root.F[:], [-10.0, -9.0, -8.0])
+            assert h5.root.W.shape == (3, 2, 3)

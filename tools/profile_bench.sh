@@ -7,14 +7,14 @@
 # it spawns worker processes, which must not happen once the profiler has initialised the GPU.
 set -e
 CFG=${1:-c2}
-TAG=${2:-r01}
+TAG=${2:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_${TAG}_${CFG}
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --steps 20 --warmup 3 --no-cpu-baseline --inprocess-init > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --inprocess-init > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --inprocess-init > $OUT/bench_write.json 2> $OUT/write.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --steps 4 --warmup 1 --em-per-step 5 --no-cpu-baseline --inprocess-init > $OUT/bench_trace.json 2> $OUT/trace.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --em-per-step 3 --no-cpu-baseline --inprocess-init > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --em-per-step 3 --no-cpu-baseline --inprocess-init > $OUT/bench_write.json 2> $OUT/write.log
 python3 $R/tools/summarize_prof.py $OUT > $OUT/summary.md
 cat $OUT/summary.md

@@ -70,7 +70,8 @@ def main(out):
             w = pmc.get("WRITE_SIZE", {}).get(n, [0.0, 0])
             fl = f[0] / f[1] if f[1] else 0.0
             wl = w[0] / w[1] if w[1] else 0.0
-            js[n] = {"fetch_kib": fl, "write_kib": wl, "traffic_bytes_2xfetch_plus_write": (2 * fl + wl) * 1024}
+            js[n] = {"fetch_kib": fl, "write_kib": wl, "traffic_bytes_2xfetch_plus_write": (2 * fl + wl) * 1024,
+                     "launches": max(f[1], w[1])}
         json.dump(js, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for nm in ("bench_trace.json",):
         p = os.path.join(out, nm)
