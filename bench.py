@@ -49,6 +49,9 @@ CONFIGS = {  # BASELINE.json "configs": the whole job (N_total is split over the
     "c4shard": dict(algo="es3c", D=256, H=512, S=200, N=12500, name="ES3C D=256 H=512 S=200 N=12.5k (one eighth of c4) f64"),
     "c5": dict(algo="ebsc", D=256, H=1024, S=256, N=200000, name="EBSC D=256 H=1024 S=256 N=200k (f64; the reference has no f32)"),
     "c5shard": dict(algo="ebsc", D=256, H=1024, S=256, N=25000, name="EBSC D=256 H=1024 S=256 N=25k (one eighth of c5) f64"),
+    "c5f32": dict(algo="ebsc", D=256, H=1024, S=256, N=200000, f32=True,
+                  name="EBSC D=256 H=1024 S=256 N=200k float32 mode (data / B / E_q[s] rows and the long contractions in f32; "
+                       "lpj arithmetic, sums, Theta f64)"),
 }
 CONFIGS["c4full"] = CONFIGS["c4"]  # round-1 name
 EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
@@ -154,14 +157,15 @@ def pmc_traffic(config, kernels):
 
 def algorithmic_bytes_pass(cfg, N):
     """lpj pass and statistics pass alike, per datapoint D*w + C*(ceil(H/8) + w) with w = 8, C = S."""
-    return N * (cfg["D"] * 8 + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
+    w_y = 4 if cfg.get("f32") else 8  # float32 mode: y_n is float, lpj stays double
+    return N * (cfg["D"] * w_y + cfg["S"] * ((cfg["H"] + 7) // 8 + 8))
 
 
 def layout_bytes_lpj(cfg, N):
     """Compulsory bytes of the lpj pass in THIS implementation's HBM layout: per datapoint the row of
     B = Y W (H doubles, replaces y_n in the Gram form) and per state one 8-byte digest (count + first
     active latents, replaces the ceil(H/8) bit words) plus the 8-byte lpj written."""
-    return N * (cfg["H"] * 8 + cfg["S"] * (8 + 8))
+    return N * (cfg["H"] * (4 if cfg.get("f32") else 8) + cfg["S"] * (8 + 8))
 
 
 def gemm_flops_per_iteration(cfg, N):
@@ -450,8 +454,9 @@ def main():
         eng.set_option(name, int(val))
     comm = parallel.init_rccl_from_env(eng)
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
+    kw = {"dtype": np.float32} if cfg.get("f32") else {}
     model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17,
-                device_mstep=not args.host_mstep)
+                device_mstep=not args.host_mstep, **kw)
     np.random.seed(99)
     theta = model.check_params(model.standard_init(my_data))  # data moments all-reduced, W noise broadcast from rank 0
     suff = ea_suff(cfg)
@@ -537,7 +542,8 @@ def main():
             "metric": "E-step candidate-state evals/sec (NxS), full EM iteration", "value": evals / dt,
             "unit": "state evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 data + contractions, f64 lpj / sums" if cfg.get("f32") else "f64",
+            "data": "synthetic",
             "config": {"workload": cfg["name"], "algo": cfg["algo"], "N_total": cfg["N"], "N_rank0": n_loc,
                        "D": cfg["D"], "H": cfg["H"], "S": cfg["S"],
                        "step": "%d full EM iterations" % iters, "em_iterations_per_step": iters,

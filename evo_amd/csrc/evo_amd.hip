@@ -177,6 +177,12 @@ struct evoamd_ctx {
   int k8_mode = -1;  // ES3C states with 5..8 active latents: 1 = K=8 register kernel, 0 = LDS wavefront
                      // kernel, -1 = choose per launch from the counts of the last statistics pass
   bool bsc_direct = false;  // EBSC batches: direct residual kernel instead of the Gram-form one
+  // EBSC float32 mode (option "ebsc_f32", read by evoamd_configure): the data, B = Y W and the Es rows live in
+  // float and the two K- / N-long contractions run on v_mfma_f32_16x16x4_f32; lpj arithmetic, Theta and every
+  // accumulator stay double.  Yf (N,D), Ytf = Y^T (D, ldYt), Wf (D,H), Bf (N,H), Esf (N,H)
+  bool f32_opt = false, f32 = false;
+  float *Yf = nullptr, *Ytf = nullptr, *Wf = nullptr, *Bf = nullptr, *Esf = nullptr;
+  i64 ldYt = 0;
   uint8_t *mask_infr = nullptr, *mask_x = nullptr;  // EBSC incomplete data: reliable entries / entries that keep their value
   double *Yrec = nullptr;       // y_reconstructed (N x D): what the M-step's Wp contraction reads then
   bool yrec_valid = false, rec_in_stats = false;
@@ -409,6 +415,10 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                               (int)GEMM128_LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_sk_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
+  HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_sk_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM128_LDS_BYTES));
+  HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_store_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM128_LDS_BYTES));
   {
     const void *wk[] = {(const void *)sssc_stats_wave_kernel<0, 4>,  (const void *)sssc_stats_wave_kernel<1, 4>,
                         (const void *)sssc_stats_wave_kernel<2, 4>,  (const void *)sssc_stats_wave_kernel<4, 4>,
@@ -430,7 +440,7 @@ static void free_all(evoamd_ctx *c) {
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
-                  c->pbins.keys, c->pbins.qv, c->pbins.gcnt};
+                  c->pbins.keys, c->pbins.qv, c->pbins.gcnt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -467,6 +477,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   c->gen++;  // an option can change which kernel form evaluates K^n: drop a prefetched pass
   if (strcmp(name, "sssc_k8") == 0) {
     c->k8_mode = value < 0 ? -1 : (value != 0);
+    return 0;
+  }
+  if (strcmp(name, "ebsc_f32") == 0) {
+    c->f32_opt = value != 0;  // takes effect at the next evoamd_configure
     return 0;
   }
   if (strcmp(name, "bsc_direct") == 0) {
@@ -627,7 +641,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   // H > 1024: colp | rowp | perm in the same place) | SPD path: Pinv (2 x 2 x 256), diag (2 x H)
   ALLOC(c->gjwork, (size_t)2 * H * H + (size_t)132 * H + 1040 + 4 * GJS32 * GJS32);  // + pivot inverses of the 32-column path
   if (model == EVOAMD_MODEL_BSC) {
-    ALLOC(c->Es, (size_t)N * H);
+    ALLOC(c->Es, (model == EVOAMD_MODEL_BSC && c->f32_opt) ? 1 : (size_t)N * H);
   } else {
     if (c->Es) { (void)hipFree(c->Es); }
     c->Es = nullptr;  // lives inside c->Y for SSSC
@@ -642,10 +656,25 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->acc = c->acc_base + c->ovf_n;
   c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 4);
+  for (float **fp : {&c->Yf, &c->Ytf, &c->Wf, &c->Bf, &c->Esf}) {
+    if (*fp) (void)hipFree(*fp);
+    *fp = nullptr;
+  }
+  c->f32 = model == EVOAMD_MODEL_BSC && c->f32_opt;
+  if (c->f32) REQUIRE((H % 4) == 0 && (D % 4) == 0, "float32 mode needs H and D to be multiples of 4 (16-byte rows)");
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Wt, (size_t)H * D);
     ALLOC(c->G, (size_t)H * H);
-    ALLOC(c->Bm, (size_t)N * H);
+    ALLOC(c->Bm, c->f32 ? 1 : (size_t)N * H);
+    if (c->f32) {
+      c->ldYt = ((N + 3) / 4) * 4;
+      ALLOC(c->Yf, (size_t)N * D);
+      ALLOC(c->Ytf, (size_t)D * c->ldYt);
+      ALLOC(c->Wf, (size_t)D * H);
+      ALLOC(c->Bf, (size_t)N * H);
+      ALLOC(c->Esf, (size_t)N * H);
+      HIP_TRY(hipMemsetAsync(c->Ytf, 0, (size_t)D * c->ldYt * sizeof(float), c->stream));
+    }
   } else {
     ALLOC(c->G, (size_t)H * H);
     ALLOC(c->Psi, (size_t)H * H);
@@ -742,6 +771,11 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
   {
     launch_colsum<true>(c, c->Y, c->ldY, c->N, c->D, c->y2sum);
   }
+  if (c->f32) {  // float copies for the two long contractions: Y (N,D) and Y^T (D,N)
+    to_f32_kernel<<<cdiv(c->N * (i64)c->D, 256), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->Yf, c->D);
+    transpose_to_f32_kernel<<<dim3(cdiv(c->N, 32), cdiv(c->D, 32)), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->Ytf,
+                                                                                       c->ldYt);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->have_data = true;
@@ -752,6 +786,7 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
 
 extern "C" int evoamd_upload_masks(evoamd_ctx *c, const uint8_t *x_infr, const uint8_t *x) {
   REQUIRE(c && c->configured && c->have_data, "configure and upload_data first");
+  REQUIRE(!(c->f32 && x_infr), "incomplete data is not available in the float32 mode");
   HIP_TRY(hipSetDevice(c->device));
   if (!x_infr) {  // back to complete data (upload_data again restores entries that were zeroed)
     if (c->mask_infr) (void)hipFree(c->mask_infr);
@@ -1031,9 +1066,12 @@ static int launch_gemm_nn(evoamd_ctx *c, const double *A, int lda, const double 
 // ---------------------------------------------------------------------------------------
 // parameters
 // ---------------------------------------------------------------------------------------
+static int launch_B_f32(evoamd_ctx *c);
+
 extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, double sigma, double *ljc) {
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC, "context is not configured for BSC");
   REQUIRE(W, "W is NULL");
+  REQUIRE(!(c->f32 && c->bsc_direct), "the direct residual kernel is not available in the float32 mode");
   HIP_TRY(hipSetDevice(c->device));
   // bsc.py:111-121; incomplete data: the normaliser counts the reliable entries (bsc.py:113-118)
   c->ljc = c->H * log(1.0 - pi) - (c->rel_frac >= 0.0 ? c->rel_frac : (double)c->D) / 2.0 * log(2 * M_PI * sigma * sigma);
@@ -1060,7 +1098,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
     int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D);  // G = W^T W
     if (r) return r;
     if (c->have_data) {
-      r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);  // B = Y W
+      r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);  // B = Y W
       if (r) return r;
       c->B_valid = true;
     }
@@ -1144,10 +1182,43 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   return 0;
 }
 
+// float32 mode: C (M x Nc double, zeroed by the caller) += A^T B with float A (K x M), B (K x Nc): the stream-K grid on
+// v_mfma_f32_16x16x4_f32 with the f64 atomic epilogue; small outputs by the one-thread-per-element kernel.
+static int launch_gemm_tn_f32(evoamd_ctx *c, const float *A, int lda, const float *B, int ldb, double *C, int ldc, int M, int Nc,
+                              i64 K) {
+  SpanGuard g(c, KID_GEMM);
+  if (M >= 128 && Nc >= 128 && K >= 2048 && (M % 4) == 0 && (Nc % 4) == 0) {
+    const int gx = (int)cdiv(Nc, GEMM_T), gy = (int)cdiv(M, GEMM_T);
+    const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
+    gemm_tn128_sk_f32<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, gx * gy);
+  } else {
+    gemm_tn_naive_f32<<<cdiv((i64)M * Nc, 256), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// float32 mode: Wf <- W, then Bf = Y W as (Y^T)^T Wf on the f32 matrix cores (whole K = D per 128 x 128 tile)
+static int launch_B_f32(evoamd_ctx *c) {
+  SpanGuard g(c, KID_GEMM);
+  to_f32_kernel<<<cdiv((i64)c->D * c->H, 256), 256, 0, c->stream>>>(c->W, c->H, c->D, c->H, c->Wf, c->H);
+  if (c->H >= 128 && c->N >= 128) {
+    const int gx = (int)cdiv(c->H, GEMM_T), gy = (int)cdiv(c->N, GEMM_T);
+    gemm_tn128_store_f32<<<(unsigned)gx * gy, 256, GEMM128_LDS_BYTES, c->stream>>>(c->Ytf, (int)c->ldYt, c->Wf, c->H, c->Bf,
+                                                                                  c->H, (int)c->N, c->H, c->D, gx);
+  } else {
+    gemm_nn_naive_f32<<<cdiv(c->N * (i64)c->H, 256), 256, 0, c->stream>>>(c->Yf, c->D, c->Wf, c->H, c->Bf, c->H, c->N, c->H,
+                                                                           c->D);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // B = Y W depends on both the data and Theta; recompute it if either arrived later.
 static int ensure_B(evoamd_ctx *c) {
   if (c->B_valid || (c->model == EVOAMD_MODEL_BSC && c->bsc_direct)) return 0;
-  int r = launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
+  int r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
   if (r) return r;
   DBG_SYNC(c, "B = Y W");
   c->B_valid = true;
@@ -1183,6 +1254,9 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
   if (!c->bsc_direct && b.tag != 2 && !b.mask) {  // masked data: per-datapoint Gram matrices -> direct form
     const i64 total = b.N * (i64)b.C;
     unsigned grid = cdiv(total, 256);
+    // float32 mode: the batches over the resident data read the float B (per-datapoint calls bring their own double row)
+    const int bf32 = (c->f32 && b.Bm == c->Bm) ? 1 : 0;
+    const void *bmat = bf32 ? (const void *)c->Bf : (const void *)b.Bm;
     SpanGuard g(c, b.kid);
     // second-generation kernel (register state words, B rows in LDS) when the shape allows it
     const int rows_cap = 512 / b.C + 2;
@@ -1192,8 +1266,8 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     if (!b.shared && (hw_ok || dg) && (c->H % 2) == 0 && lds <= 40 * 1024) {
       const unsigned g2 = cdiv(total, 512);
 #define GRAM2(TAG, HWT)                                                                                      \
-  bsc_lpj_gram2_kernel<TAG, HWT><<<g2, 512, lds, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, c->H, \
-                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg)
+  bsc_lpj_gram2_kernel<TAG, HWT><<<g2, 512, lds, c->stream>>>(b.states, b.counts, bmat, b.yy, c->G, b.N, b.C, c->H, \
+                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32)
 #define GRAM2_HW(TAG)                    \
   switch (c->HW) {                       \
     case 1: GRAM2(TAG, 1); break;        \
@@ -1213,8 +1287,8 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
       return 0;
     }
 #define GRAM_LAUNCH(TAG)                                                                                       \
-  bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, b.Bm, b.yy, c->G, b.N, b.C, b.shared, \
-                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg)
+  bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, bmat, b.yy, c->G, b.N, b.C, b.shared, \
+                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32)
     if (b.tag == 0)
       GRAM_LAUNCH(0);
     else
@@ -1965,8 +2039,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
 #define BSC_STATS(HWT)                                                                                              \
   bsc_stats_kernel<HWT><<<cdiv(nc, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                           \
       c->states + (size_t)n0 * c->S * c->HW, c->lpj + (size_t)n0 * c->L, c->rowmax + n0, c->rowsum + n0, c->yy + n0, nc, \
-      c->S, c->S_perm, H, c->HW, c->dpar, c->Es + (size_t)n0 * H, c->acc + a.Wq, c->partial2 + n0 / 4,             \
-      dig_for(c, c->states) ? dig_for(c, c->states) + (size_t)n0 * c->S : nullptr)
+      c->S, c->S_perm, H, c->HW, c->dpar,                                                                           \
+      c->f32 ? (void *)(c->Esf + (size_t)n0 * H) : (void *)(c->Es + (size_t)n0 * H), c->acc + a.Wq, c->partial2 + n0 / 4, \
+      dig_for(c, c->states) ? dig_for(c, c->states) + (size_t)n0 * c->S : nullptr, c->f32 ? 1 : 0)
         switch (c->HW) {
           case 1: BSC_STATS(1); break;
           case 2: BSC_STATS(2); break;
@@ -1981,8 +2056,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
       {
         SpanGuard g(c, KID_MISC);
-        colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Es + (size_t)n0 * H, H, nc, H, rpb,
-                                                                                c->colpart + (size_t)blk0 * H);
+        if (c->f32)
+          colsum_partial_f32_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Esf + (size_t)n0 * H, H, nc, H, rpb,
+                                                                                      c->colpart + (size_t)blk0 * H);
+        else
+          colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Es + (size_t)n0 * H, H, nc, H, rpb,
+                                                                                  c->colpart + (size_t)blk0 * H);
         HIP_TRY(hipGetLastError());
       }
       if (masked) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211); one block only
@@ -2142,7 +2221,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       c->stream = c->stream2;
     }
     const bool acc_mode = nchunks > 1, last = ci == nchunks - 1;
-    if (c->model == EVOAMD_MODEL_BSC)  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
+    if (c->model == EVOAMD_MODEL_BSC && c->f32)
+      r = launch_gemm_tn_f32(c, c->Esf + (size_t)n0 * H, H, c->Yf + (size_t)n0 * D, D, c->acc + a.Wp, D, H, D, nc);
+    else if (c->model == EVOAMD_MODEL_BSC)  // Wp = Es^T Y  (H,D); acc was cleared at the top of stats_compute
       r = launch_gemm_tn(c, c->Es + (size_t)n0 * H, H, Ywp + (size_t)n0 * ldwp, ldwp, c->acc + a.Wp, D, H, D, nc, false, -1,
                          /*c_is_zero=*/true, acc_mode, last);
     else
@@ -2344,7 +2425,7 @@ static int refresh_after_update(evoamd_ctx *c) {
   } else if (!c->bsc_direct) {
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
     if (r) return r;
-    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
     if (r) return r;
     c->B_valid = true;
   }
@@ -2414,6 +2495,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
 
 // y_hat = E W^T with E = Es (EBSC) / Ez (ES3C) rows of the last statistics pass (see evoamd_reconstruct)
 static int compute_reconstruction(evoamd_ctx *c) {
+  REQUIRE(!c->f32, "reconstruction is not available in the float32 mode");
   const size_t need = (size_t)c->N * c->D;
   if (need > c->yhat_n) {
     ALLOC(c->yhat, need);

@@ -181,51 +181,82 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
 #define GEMM_T 128
 #define GEMM_LDS2 144
 #define GEMM128_LDS_BYTES (2 * 2 * GEMM_BK * GEMM_LDS2 * sizeof(double))
-// One K range [kbeg, kend) of one 128 x 128 output tile at (m0, n0): the body both 128-tile kernels share.
-// atomic: add the tile to C with f64 atomics (split K / stream-K), else store it.
-__device__ __forceinline__ void gemm_tn128_segment(const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-                                                   double *__restrict__ C, int ldc, int M, int Nc, int m0, int n0, i64 kbeg,
-                                                   i64 kend, bool atomic, double (*As)[GEMM_BK][GEMM_LDS2],
-                                                   double (*Bs)[GEMM_BK][GEMM_LDS2]) {
+// One K range [kbeg, kend) of one 128 x 128 output tile at (m0, n0): the body the 128-tile kernels share.
+// T = element type of A and B (double: v_mfma_f64_16x16x4_f64; float: v_mfma_f32_16x16x4_f32, the EBSC float32
+// mode), TO = element type of C.  atomic: add the tile to C (double) with f64 atomics (split K / stream-K), else store.
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<double> {
+  typedef v4f64 acc_t;
+  typedef double2 piece_t;  // 16-byte load
+  static constexpr int EPP = 2;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }  // f64: the exception
+  static __device__ __forceinline__ piece_t zero() { return make_double2(0.0, 0.0); }
+};
+template <>
+struct Mfma16<float> {
+  typedef v4f32 acc_t;
+  typedef float4 piece_t;
+  static constexpr int EPP = 4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }  // the standard C/D map
+  static __device__ __forceinline__ piece_t zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+
+template <typename T, typename TO>
+__device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb,
+                                                   TO *__restrict__ C, int ldc, int M, int Nc, int m0, int n0, i64 kbeg,
+                                                   i64 kend, bool atomic, T (*As)[GEMM_BK][GEMM_LDS2],
+                                                   T (*Bs)[GEMM_BK][GEMM_LDS2]) {
+  typedef Mfma16<T> MM;
+  typedef typename MM::piece_t piece_t;
+  constexpr int EPP = MM::EPP;             // elements per 16-byte piece
+  constexpr int PPR = GEMM_T / EPP;        // pieces per slab row (128 columns)
+  constexpr int NP = GEMM_BK * PPR / 256;  // pieces per thread and operand (double 4, float 2)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  v4f64 acc[4][4];
+  typename MM::acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  // loader: the 16 x 64 grid of 16-byte pieces of a slab (16 rows x 128 columns), pieces p = t + 256 i
-  double2 ra[2][4], rb[2][4];  // two slabs ahead (a slab is 4096 matrix-core cycles per wave here)
-  auto fetch = [&](double2(&qa)[4], double2(&qb)[4], i64 k0) {
+    for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+      for (int r = 0; r < 4; r++) acc[i][j][r] = (T)0;
+  // loader: the 16 x PPR grid of 16-byte pieces of a slab (16 rows x 128 columns), pieces p = t + 256 i
+  piece_t ra[2][NP], rb[2][NP];  // two slabs ahead (a slab is 4096 matrix-core cycles per wave in f64)
+  auto fetch = [&](piece_t(&qa)[NP], piece_t(&qb)[NP], i64 k0) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
       const int p = t + 256 * i;
-      const i64 kr = k0 + (p >> 6);
-      const int cc = (p & 63) * 2;
+      const i64 kr = k0 + (p / PPR);
+      const int cc = (p % PPR) * EPP;
       const bool kin = kr < kend;
       const i64 krc = kin ? kr : kend - 1;
       const int ma = m0 + cc, nb = n0 + cc;
-      double2 va = *(const double2 *)(A + krc * lda + (ma < M ? ma : M - 2));
-      double2 vb = *(const double2 *)(B + krc * ldb + (nb < Nc ? nb : Nc - 2));
-      if (!(kin && ma < M)) va = make_double2(0.0, 0.0);
-      if (!(kin && nb < Nc)) vb = make_double2(0.0, 0.0);
+      piece_t va = *(const piece_t *)(A + krc * lda + (ma < M ? ma : M - EPP));
+      piece_t vb = *(const piece_t *)(B + krc * ldb + (nb < Nc ? nb : Nc - EPP));
+      if (!(kin && ma < M)) va = MM::zero();
+      if (!(kin && nb < Nc)) vb = MM::zero();
       qa[i] = va;
       qb[i] = vb;
     }
   };
-  auto stash = [&](const double2(&qa)[4], const double2(&qb)[4], int buf) {
+  auto stash = [&](const piece_t(&qa)[NP], const piece_t(&qb)[NP], int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int p = t + 256 * i, r = p >> 6, cc = (p & 63) * 2;
-      *(double2 *)&As[buf][r][cc] = qa[i];
-      *(double2 *)&Bs[buf][r][cc] = qb[i];
+    for (int i = 0; i < NP; i++) {
+      const int p = t + 256 * i, r = p / PPR, cc = (p % PPR) * EPP;
+      *(piece_t *)&As[buf][r][cc] = qa[i];
+      *(piece_t *)&Bs[buf][r][cc] = qb[i];
     }
   };
   auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
       const int kl = kk * 4 + (lane >> 4);
-      double a[4], b[4];
+      T a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) a[i] = As[buf][kl][wm * 64 + i * 16 + (lane & 15)];
 #pragma unroll
@@ -233,8 +264,7 @@ __device__ __forceinline__ void gemm_tn128_segment(const double *__restrict__ A,
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = MM::mma(a[i], b[j], acc[i][j]);
     }
   };
   const i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
@@ -264,13 +294,13 @@ __device__ __forceinline__ void gemm_tn128_segment(const double *__restrict__ A,
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r;
+        const int row = m0 + wm * 64 + i * 16 + MM::row(lane, r);
         const int col = n0 + wn * 64 + j * 16 + (lane & 15);
         if (row < M && col < Nc) {
           if (atomic)
-            unsafeAtomicAdd(&C[(i64)row * ldc + col], acc[i][j][r]);
+            unsafeAtomicAdd((double *)&C[(i64)row * ldc + col], (double)acc[i][j][r]);  // TO is double on this path
           else
-            C[(i64)row * ldc + col] = acc[i][j][r];
+            C[(i64)row * ldc + col] = (TO)acc[i][j][r];
         }
       }
 }
@@ -335,6 +365,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs);
     u += se - sb;
   }
+}
+
+// ---- float32 forms (EBSC float32 mode: data, B = Y W and the Es rows in float, sums in double) --------------------
+// Stream-K contraction of float operands into a double C (atomic epilogue): Wp = Es^T Y.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_sk_f32(
+    const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M,
+    int Nc, i64 K, i64 Kx, int gx, int gy, int n_real) {
+  extern __shared__ double lds128[];
+  float(*As)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])lds128;
+  float(*Bs)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])((float *)lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const i64 kx0 = (i64)xcd * Kx;
+  const i64 kx1 = (kx0 + Kx < K) ? kx0 + Kx : K;
+  if (kx1 <= kx0) return;
+  const i64 slabs = (kx1 - kx0 + GEMM_BK - 1) / GEMM_BK;
+  const i64 U = (i64)n_real * slabs;
+  i64 u = U * w / wpx;
+  const i64 u1 = U * (w + 1) / wpx;
+  while (u < u1) {  // uniform
+    const int tile = (int)(u / slabs);
+    const i64 sb = u - (i64)tile * slabs;
+    i64 se = sb + (u1 - u);
+    if (se > slabs) se = slabs;
+    const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+    const i64 kbeg = kx0 + sb * GEMM_BK;
+    i64 kend = kx0 + se * GEMM_BK;
+    if (kend > kx1) kend = kx1;
+    gemm_tn128_segment<float, double>(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs);
+    u += se - sb;
+  }
+}
+
+// C (M x Nc, float) = A^T B, whole K per tile, plain stores: B = Y W as (Y^T)^T W with the transposed float copy of Y.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_store_f32(
+    const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int M,
+    int Nc, i64 K, int gx) {
+  extern __shared__ double lds128[];
+  float(*As)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])lds128;
+  float(*Bs)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])((float *)lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int tile = blockIdx.x;
+  const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+  gemm_tn128_segment<float, float>(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, 0, K, false, As, Bs);
 }
 
 // C (M x Nc) = A B with A: M x K (lda) row-major, B: K x Nc (ldb).  No K split (K = D or H is small).

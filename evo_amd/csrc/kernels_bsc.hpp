@@ -105,6 +105,18 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
 
 // Gram-form lpj, one THREAD per (datapoint, state):
 //   ||y - W s||^2 = yy_n - 2 sum_{h in s} b_nh + sum_{h in s} G_hh + 2 sum_{h<h' in s} G_hh'
+// A row of B = Y W that is either double or (float32 mode) float in memory.
+struct BRow {
+  const void *p;
+  int f32;
+  __device__ __forceinline__ BRow row(i64 n, int H) const {
+    return BRow{f32 ? (const void *)((const float *)p + n * H) : (const void *)((const double *)p + n * H), f32};
+  }
+  __device__ __forceinline__ double operator[](int h) const {
+    return f32 ? (double)((const float *)p)[h] : ((const double *)p)[h];
+  }
+};
+
 // with b_n = W^T y_n (rows of Bm = Y W) and G = W^T W from the f64 MFMA precompute (SURVEY 8a
 // "restatements").  Work per state is O(k^2) gathers from L2-resident G instead of the direct
 // kernel's O(k D) row reads plus a 64-lane reduction, and all 64 lanes of a wave evaluate
@@ -115,19 +127,21 @@ __global__ __launch_bounds__(256) void bsc_lpj_kernel(
 // single-datapoint operator) as the cancellation-free form.
 template <int TAG>
 __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
-    const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
+    const u64 *__restrict__ states, const int *__restrict__ counts, const void *__restrict__ Bm_,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int shared, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err, const u64 *__restrict__ dig) {
+    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
+  // float32 mode: B = Y W is stored in float (b_f32); the arithmetic stays double
+  const BRow Bm = {Bm_, b_f32};
   for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < total; t += (i64)gridDim.x * 256) {
     const unsigned tu = (unsigned)t;  // N*C < 2^31
     const i64 n = (i64)(tu / (unsigned)C);
     const int c = (int)(tu - (unsigned)n * (unsigned)C);
     if (counts && c >= counts[n]) continue;
     const u64 *sp = states + ((shared ? 0 : n * (i64)C) + c) * HW;
-    const double *Bn = Bm + n * H;
+    const BRow Bn = Bm.row(n, H);
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
     bool done = false;
@@ -191,10 +205,10 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
 #define BSC_KR 4
 template <int TAG, int HWT>
 __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
-    const u64 *__restrict__ states, const int *__restrict__ counts, const double *__restrict__ Bm,
+    const u64 *__restrict__ states, const int *__restrict__ counts, const void *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err, const u64 *__restrict__ dig) {
+    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32) {
   extern __shared__ double Bs[];
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
@@ -251,10 +265,18 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
     }
   }
   {
-    const double2 *src = (const double2 *)(Bm + n_first * H);  // H is even (host)
     double2 *dst = (double2 *)Bs;
     const int n2 = rows * H / 2;
-    for (int i = threadIdx.x; i < n2; i += 512) dst[i] = src[i];
+    if (b_f32) {  // float32 mode: rows of B are float in memory, double in LDS
+      const float2 *src = (const float2 *)((const float *)Bm + n_first * H);
+      for (int i = threadIdx.x; i < n2; i += 512) {
+        const float2 v = src[i];
+        dst[i] = make_double2((double)v.x, (double)v.y);
+      }
+    } else {
+      const double2 *src = (const double2 *)((const double *)Bm + n_first * H);  // H is even (host)
+      for (int i = threadIdx.x; i < n2; i += 512) dst[i] = src[i];
+    }
   }
   const double yyn = live ? yy[n] : 0.0;
   __syncthreads();
@@ -395,8 +417,8 @@ template <int HWT>
 __global__ __launch_bounds__(256) void bsc_stats_kernel(
     const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
     const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H,
-    int HW, const double *__restrict__ dpar, double *__restrict__ Es, double *__restrict__ Wq,
-    double *__restrict__ sig_partial, const u64 *__restrict__ dig) {
+    int HW, const double *__restrict__ dpar, void *__restrict__ Es_, double *__restrict__ Wq,
+    double *__restrict__ sig_partial, const u64 *__restrict__ dig, int es_f32) {
   extern __shared__ double es_lds[];  // 4 waves x H
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   __shared__ double wsig[4];
@@ -494,7 +516,13 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
       sig += q * ((l - pil_bar * (double)k) / pre1);
     }
     lds_wave_fence();  // not __threadfence_block(): that would wait for this wave's global Wq atomics
-    for (int h = lane; h < H; h += 64) Es[n * H + h] = es[h] * inv;
+    if (es_f32) {  // float32 mode: the rows the Wp contraction reads are float
+      float *Es = (float *)Es_;
+      for (int h = lane; h < H; h += 64) Es[n * H + h] = (float)(es[h] * inv);
+    } else {
+      double *Es = (double *)Es_;
+      for (int h = lane; h < H; h += 64) Es[n * H + h] = es[h] * inv;
+    }
     sig = wave_sum(sig) * inv;
   }
   if (lane == 0) wsig[wave] = (n < N) ? sig : 0.0;

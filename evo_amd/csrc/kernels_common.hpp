@@ -214,6 +214,66 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const double *__res
   if (rl == 0 && c < Cn) part[(i64)blockIdx.y * Cn + c] = ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
 }
 
+// ---- float32 mode helpers (EBSC): float copies of Y (row-major and transposed), of W, float column sums ----------
+__global__ __launch_bounds__(256) void colsum_partial_f32_kernel(const float *__restrict__ X, int ldx, i64 R, int Cn,
+                                                                 i64 rows_per_block, double *__restrict__ part) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const i64 r0 = (i64)blockIdx.y * rows_per_block;
+  const i64 r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  double s = 0.0;
+  if (c < Cn)
+    for (i64 r = r0 + rl; r < r1; r += 4) s += (double)X[r * ldx + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < Cn) part[(i64)blockIdx.y * Cn + c] = ((sh[0][cl] + sh[1][cl]) + sh[2][cl]) + sh[3][cl];
+}
+// dst (R x C float, ld ldd) = (float) src (R x C double, ld lds)
+__global__ __launch_bounds__(256) void to_f32_kernel(const double *__restrict__ src, int lds_, i64 R, int C,
+                                                     float *__restrict__ dst, int ldd) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= R * C) return;
+  const i64 r = t / C;
+  const int c = (int)(t - r * C);
+  dst[r * ldd + c] = (float)src[r * lds_ + c];
+}
+// dst (C x R float, ld ldd) = transpose of src (R x C double, ld lds): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_to_f32_kernel(const double *__restrict__ src, int lds_, i64 R, int C,
+                                                               float *__restrict__ dst, i64 ldd) {
+  __shared__ float tile[32][33];
+  const i64 r0 = (i64)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    tile[j][tx] = (r0 + j < R && c0 + tx < C) ? (float)src[(r0 + j) * lds_ + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < C && r0 + tx < R) dst[(i64)(c0 + j) * ldd + r0 + tx] = tile[tx][j];
+}
+// Small shapes of the float32 mode (the 128-tile kernels need outputs >= 256 wide): one thread per output element.
+// C (M x Nc double) = A^T B, A (K x M float), B (K x Nc float), double accumulation.
+__global__ __launch_bounds__(256) void gemm_tn_naive_f32(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                         int ldb, double *__restrict__ C, int ldc, int M, int Nc, i64 K) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)M * Nc) return;
+  const int m = (int)(t / Nc), n = (int)(t - (i64)m * Nc);
+  double s = 0.0;
+  for (i64 k = 0; k < K; k++) s += (double)A[k * lda + m] * (double)B[k * ldb + n];
+  C[(i64)m * ldc + n] = s;
+}
+// C (M x Nc float) = A B, A (M x K float), B (K x Nc float)
+__global__ __launch_bounds__(256) void gemm_nn_naive_f32(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                         int ldb, float *__restrict__ C, int ldc, i64 M, int Nc, int K) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * Nc) return;
+  const i64 m = t / Nc;
+  const int n = (int)(t - m * Nc);
+  float s = 0.f;
+  for (int k = 0; k < K; k++) s = fmaf(A[m * lda + k], B[(i64)k * ldb + n], s);
+  C[m * ldc + n] = s;
+}
+
 // Accumulator tail + bookkeeping in one single-workgroup launch (was 6 launches):
 //   tail = { Fs, sum_nunique, sum_sub, N, reset counters[3], 0 } from the device scalar block;
 //   the E-step counters are consumed (zeroed); clamp flags are counted with the reference's

@@ -40,6 +40,7 @@ class Engine:
         self.N = self.D = self.H = self.S = self.S_perm = self.Cmax = 0
         self.ljc = None
         self.has_masks = False
+        self.f32 = False  # EBSC float32 mode of the configured geometry (option "ebsc_f32")
         self.world = 1
         self.rank = 0
 

@@ -74,7 +74,7 @@ class Model:
     model_name = None  # "bsc" | "sssc"
 
     def __init__(self, D, H, S, to_learn=("W", "pi", "sigma"), comm=None, rng="reference", sync_host=True,
-                 device=None, engine=None, seed=0, device_mstep=False):
+                 device=None, engine=None, seed=0, device_mstep=False, dtype=np.float64):
         """``D, H, S, to_learn, comm`` as in the reference (_models.py:20-56).  ``comm`` may be an
         mpi4py communicator or one of evo_amd.utils.parallel; None means one rank."""
         if rng not in ("reference", "device"):
@@ -90,6 +90,14 @@ class Model:
         # use Gauss-Jordan instead of LAPACK, so Theta agrees with the host formulas to ~1e-12 but
         # not bit for bit -- keep it off for rng="reference" parity runs.
         self.device_mstep = bool(device_mstep)
+        # dtype=np.float32 (EBSC only): the data, B = Y W and the E_q[s] rows are kept in float and the two long
+        # contractions run on the f32 matrix cores; lpj arithmetic, selection, sums and Theta stay float64.  The reference
+        # is float64-only -- this is BASELINE.json configs[4]'s "float32"; agreement with the float64 path ~1e-6 in lpj / F.
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("dtype must be float64 or float32")
+        if self.dtype == np.float32 and self.model_name != "bsc":
+            raise NotImplementedError("float32 mode exists for EBSC (BSC) only")
         self._dev_theta = None   # the dict whose values mirror the parameters resident on the device
         tol = 1e-5
         self.noise_policy = {  # _models.py:47-52
@@ -167,8 +175,11 @@ class Model:
             raise NotImplementedError("permanent background unit is outside the accelerated path")
         cmax = self._cmax(my_suff_stat) if "n_parents" in my_suff_stat else 1
         eng = self.engine
-        if not eng.same_geometry(self.model_name, N, D, self.H, self.S, S_perm, cmax):
+        f32 = self.dtype == np.float32
+        if not eng.same_geometry(self.model_name, N, D, self.H, self.S, S_perm, cmax) or eng.f32 != f32:
+            eng.set_option("ebsc_f32", 1 if f32 else 0)  # read by configure
             eng.configure(self.model_name, N, D, self.H, self.S, S_perm, cmax)
+            eng.f32 = f32
             self._y_token = None
             self._resident = False
         if not self._same_objects(self._y_token, Y):
@@ -415,6 +426,8 @@ class Model:
         which reads the derived keys it stores)."""
         eng = self.engine
         if not self._engine_matches():
+            eng.set_option("ebsc_f32", 0)
+            eng.f32 = False
             eng.configure(self.model_name, 1, self.D, self.H, self.S, 0, 1)
             self._y_token = None
             self._resident = False

@@ -180,4 +180,3 @@ class DataLog:
                 closed.append(handler)
 
 
-dlog = DataLog()  # the module-level instance the reference's examples import (datalog.py end)

@@ -62,7 +62,12 @@ int evoamd_device_count(int *count);
 int evoamd_ctx_create(int device, evoamd_ctx **out);
 void evoamd_ctx_destroy(evoamd_ctx *ctx);
 int evoamd_synchronize(evoamd_ctx *ctx);
-/* Options: "bsc_direct" (0/1, default 0): evaluate EBSC batches with the direct residual kernel
+/* Options: "ebsc_f32" (0/1, default 0; read by the next evoamd_configure of an EBSC geometry): float32 mode -- the data,
+ * B = Y W and the per-datapoint E_q[s] rows are stored in float and the two long contractions (B = Y W, Wp = Es^T Y) run
+ * on v_mfma_f32_16x16x4_f32; lpj arithmetic, selection, every accumulator and Theta stay float64 (the reference has no
+ * float32 at all: BASELINE.json configs[4] asks for it).  Parity with the float64 path: lpj / F to ~1e-6 relative,
+ * Theta to ~1e-5, K^n not bit-identical.  No incomplete data, reconstruction or bsc_direct in this mode.
+ * "bsc_direct" (0/1, default 0): evaluate EBSC batches with the direct residual kernel
  * (the reference's arithmetic, bsc.py:91-93) instead of the Gram-form kernel.  Takes effect at the
  * next evoamd_set_params_bsc.  "sssc_k8" (1 / 0 / -1, default -1): serve ES3C states with 5..8 active
  * latents with the K=8 register kernel / the LDS wavefront kernel / whichever the counts of the last

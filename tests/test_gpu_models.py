@@ -782,3 +782,72 @@ def test_new_array_same_shape_is_uploaded(engine):
     model.invalidate()
     Fc = model.free_energy(my_data, theta, suff, full=False)
     assert abs(Fc - Fa) > 1e-3 * abs(Fa)
+
+
+def test_ebsc_float32_mode_against_reference(engine):
+    """BASELINE.json configs[4] asks for float32; the reference is float64-only, so the float32 mode
+    (data, B = Y W, E_q[s] rows and the two long contractions in float; lpj arithmetic, sums, Theta in double) is
+    held against the reference's float64 fixture at a STATED tolerance: lpj 2e-5, F 1e-6, Theta 1e-4 relative;
+    selection is not claimed bit-exact in this mode (>= 99 % of the K^n rows agree on this fixture)."""
+    from evo_amd.models import BSC
+    g = load_golden("step_ebsc_mid.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    Y = g["Y"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    model = BSC(D, H, S, engine=engine, dtype=np.float32)
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in BSC_KEYS}
+    for k in ("pi", "sigma"):
+        theta[k] = np.float64(theta[k])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    np.random.seed(1000 + int(g["seed"]))
+    F, nu, nsub, theta = model.step(theta, suff, my_data)
+    assert engine.f32
+    want = unpack_bits(g["t0_ss_out"], H)
+    same_rows = (suff["ss"] == want).all(axis=2)
+    assert same_rows.mean() >= 0.99, same_rows.mean()
+    m = same_rows.all(axis=1)  # datapoints whose K^n is identical: their lpj rows are comparable entry by entry
+    np.testing.assert_allclose(suff["lpj"][m], g["t0_lpj_out"][m], rtol=2e-5)
+    np.testing.assert_allclose(F, float(g["t0_F"]), rtol=1e-6)
+    for k in BSC_KEYS:
+        ref = g["t0_out_%s" % k]
+        np.testing.assert_allclose(theta[k], ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    with pytest.raises(NotImplementedError):
+        from evo_amd.models import SSSC
+        SSSC(D, H, S, engine=engine, dtype=np.float32)
+    # the next float64 model on the same engine gets a float64 geometry back
+    test_trajectory_reference_rng(engine, "ebsc_bars")
+    assert not engine.f32
+
+
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_ebsc_float32_matrix_core_paths(engine, device_mstep):
+    """Float32 mode at a shape that takes the f32 MFMA kernels (B = Y W by gemm_tn128_store_f32 on the transposed
+    float copy of Y, Wp = Es^T Y by the stream-K gemm_tn128_sk_f32 with its f64 atomic epilogue): same seeds as a
+    float64 run of the same model; lpj and F agree to 1e-5 / 1e-6, the accumulators and Theta to 1e-4."""
+    from evo_amd.models import BSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(21)
+    D, H, S, N = 128, 256, 24, 4096
+    W0 = rng.normal(size=(D, H))
+    Y = (rng.random_sample((N, H)) < 2.0 / H).astype(float) @ W0.T + 0.5 * rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    out = {}
+    for dt in (np.float64, np.float32):
+        np.random.seed(3)
+        model = BSC(D, H, S, rng="device", sync_host=True, engine=engine, seed=7, dtype=dt, device_mstep=device_mstep)
+        theta = model.check_params(model.standard_init(my_data))
+        suff = init_states(N, S, H, "fit", "randflip", 6, 2, 1)
+        F, nu, nsub, theta = model.step(theta, suff, my_data)
+        out[dt] = (F, suff["lpj"].copy(), suff["ss"].copy(), {k: np.array(theta[k]) for k in BSC_KEYS},
+                   None if device_mstep else dict(engine.acc_views(model.last_acc.copy())))
+    F64, l64, s64, t64, a64 = out[np.float64]
+    F32, l32, s32, t32, a32 = out[np.float32]
+    np.testing.assert_allclose(F32, F64, rtol=1e-6)
+    same = (s32 == s64).all(axis=(1, 2))
+    assert same.mean() > 0.97, same.mean()
+    np.testing.assert_allclose(l32[same], l64[same], rtol=1e-5)
+    for k in BSC_KEYS:
+        np.testing.assert_allclose(t32[k], t64[k], rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(t64[k]).max())), err_msg=k)
+    if a64 is not None:
+        for k in ("Wp", "Wq", "pies", "sigma"):
+            np.testing.assert_allclose(a32[k], a64[k], rtol=1e-4, atol=1e-4 * float(np.abs(a64[k]).max()), err_msg=k)
