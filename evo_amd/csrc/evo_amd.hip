@@ -425,7 +425,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                         (const void *)sssc_stats_wave_kernel<8, 4>,  (const void *)sssc_stats_wave_kernel<16, 4>,
                         (const void *)sssc_stats_wave_kernel<0, 1>,  (const void *)sssc_stats_wave_kernel<0, 8>,
                         (const void *)sssc_stats_wave_kernel<0, 16>};
-    for (const void *f : wk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    for (const void *f : wk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  // + <= 9.2 KiB static
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<4, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<8, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   }
@@ -2113,16 +2113,17 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
       {
         // one wave per datapoint, persistent workgroups: W x 2 H doubles of rows + 3 H of column accumulators in LDS
-        int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) + 2048 <= 159 * 1024 ? 4 : 1;
+        int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) <= 150 * 1024 ? 4 : 1;
         // (8 / 16 waves per workgroup were measured: c4 8 waves -4 %, 16 waves 2x slower; c2 16 waves 112 vs 74 us)
         if (c->stats_waves == 4 || c->stats_waves == 8 || c->stats_waves == 16) Wv = c->stats_waves;  // measurement option
         size_t lds = (size_t)(Wv * 2 + 3) * H * sizeof(double);
-        REQUIRE(lds + 2048 <= 159 * 1024, "ES3C statistics: H too large for the LDS rows (H <= 4000)");
+        const size_t lds_static = 1024 + (size_t)Wv * 512 + 128;  // the kernel's bin counters and overflow buffers
+        REQUIRE(lds <= 150 * 1024, "ES3C statistics: H too large for the LDS rows (H <= 3800)");
         // B row of each wave's datapoint + the singleton table in LDS too when that still leaves two workgroups per CU
         const size_t lds_staged = lds + (size_t)(Wv + 4) * H * sizeof(double);
-        const int stage = (H % 2) == 0 && 2 * (lds_staged + 2048) <= 160 * 1024 && c->stats_stage != 0;
+        const int stage = (H % 2) == 0 && 2 * (lds_staged + lds_static) <= 160 * 1024 && c->stats_stage != 0;
         if (stage) lds = lds_staged;
-        int per_cu = (int)((160 * 1024) / (lds + 2048));
+        int per_cu = (int)((160 * 1024) / (lds + lds_static));
         const int wave_lim = 32 / Wv;  // 32 waves per CU
         if (per_cu > wave_lim) per_cu = wave_lim;
         if (per_cu > 8) per_cu = 8;
@@ -2145,8 +2146,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           sssc_stats_wave_kernel<0, 8><<<sgrid, 512, lds, c->stream>>>(sc, o1, pb, stage);
         } else if (Wv == 16) {
           sssc_stats_wave_kernel<0, 16><<<sgrid, 1024, lds, c->stream>>>(sc, o1, pb, stage);
+        } else if (!stage || !sc.dig) {
+          STATS_WAVE(0);
         } else {
-          switch (c->HW) {
+          switch (c->HW) {  // digests + staging: the instantiations that prefetch the next datapoint
             case 1: STATS_WAVE(1); break;
             case 2: STATS_WAVE(2); break;
             case 4: STATS_WAVE(4); break;

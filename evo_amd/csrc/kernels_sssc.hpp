@@ -771,10 +771,12 @@ __global__ __launch_bounds__(256) void pair_bins_reduce_kernel(PairBins pb, int 
 // Dynamic LDS: W x 2 H doubles (Es / Ez row of each wave's datapoint) + 3 H doubles (accumulators)
 //              [+ W x H doubles (B rows) + H double4 (D1) when stage].
 template <int HWT, int W>
-__global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage) {
+__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double wrows[];
   __shared__ int bcnt[PB_MAX_BINS];
+  constexpr int OVB = 64;  // overflow entries a wave collects before it appends them to the list
+  __shared__ int obuf[W][2 * OVB];
   const int H = a.H, lane = lane_id(), wave = wave_id_uniform();
   double *rowS = wrows + (size_t)wave * 2 * H, *rowZ = rowS + H;
   double *accS = wrows + (size_t)W * 2 * H, *accZ = accS + H, *accD = accZ + H;
@@ -782,28 +784,93 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
   double4 *d1s = (double4 *)(accD + H + (size_t)W * H);       // stage only (32-byte aligned: all offsets are multiples of H doubles, H even)
   const bool binned = pb.keys != nullptr;
   for (int i = threadIdx.x; i < 3 * H; i += 64 * W) accS[i] = 0.0;
-  if (stage)
+  if (HWT > 0 || stage)
     for (int i = threadIdx.x; i < H; i += 64 * W) d1s[i] = a.D1[i];
   if (binned)
     for (int i = threadIdx.x; i < pb.nb; i += 64 * W) bcnt[i] = 0;
   __syncthreads();
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
   const double s = a.s2inv;
-  for (i64 n = (i64)blockIdx.x * W + wave; n < a.N; n += (i64)gridDim.x * W) {
-    for (int h = lane; h < 2 * H; h += 64) rowS[h] = 0.0;
-    const double rmax = a.rowmax[n], rsum = a.rowsum[n] + EVO_F64_TINY;
-    const double *Bn = a.Bm + n * H;
-    if (stage) {
-      for (int h = lane; h < H; h += 64) rowB[h] = Bn[h];
-      Bn = rowB;
+  int ocnt = 0;  // wave-uniform: entries waiting in obuf[wave]
+  auto flush_obuf = [&]() {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&lo.counts[shard], ocnt);
+    base = __shfl(base, 0, 64);
+    for (int i = lane; i < ocnt; i += 64) {
+      const int pos = base + i;
+      if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = obuf[wave][i];
     }
-    const double4 *D1t = stage ? d1s : a.D1;
+    ocnt = 0;
+    lds_wave_fence();
+  };
+  // The inputs of a wave's NEXT datapoint (its B row, the digests and lpj of its first 256 states, its row maximum
+  // and sum: 7 KB) are loaded into registers while the current one is processed -- issued right after the current
+  // group's pair-table gathers, so that waiting for those does not wait for these (HWT > 0: the host launches those
+  // instantiations only with digests and staging on).  Without it a wave had one small dependent batch of loads in
+  // flight at a time (B row -> digests -> tables) and, at two workgroups per CU, the whole chip held ~2 MB in
+  // flight: 70 % of the wave cycles were s_waitcnt (profiles/r02_c4_stats_wave_pmc.txt).  Every prefetch load is
+  // unconditional (clamped addresses, the last datapoint prefetches itself again): a load under a branch makes the
+  // compiler wait for vmcnt(0) at the next use of anything loaded earlier.
+  constexpr bool PF = HWT > 0;
+  constexpr int HB = PF ? HWT : 1;
+  struct Pre {
+    double rmax, rsum, B[HB], l[4];
+    u64 d[4];
+  };
+  auto issue = [&](i64 nn, Pre &p) {
+    p.rmax = a.rowmax[nn];
+    p.rsum = a.rowsum[nn];
+    const double *Bnn = a.Bm + nn * H;
+#pragma unroll
+    for (int i = 0; i < HB; i++) {
+      const int h = lane + 64 * i;
+      p.B[i] = Bnn[h < H ? h : H - 1];
+    }
+    const double *lpn = a.lpj_in + nn * a.ldo + a.col0;
+    const u64 *dgn = a.dig + nn * (i64)a.C;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int c = 64 * u + lane, cc = c < a.C ? c : 0;
+      p.d[u] = dgn[cc];
+      p.l[u] = lpn[cc];
+    }
+  };
+  const i64 n_first = (i64)blockIdx.x * W + wave, n_stride = (i64)gridDim.x * W;
+  Pre cur = {};
+  if (PF && n_first < a.N) issue(n_first, cur);
+  for (i64 n = n_first; n < a.N; n += n_stride) {
+    const i64 n_next = n + n_stride < a.N ? n + n_stride : n;
+    for (int h = lane; h < 2 * H; h += 64) rowS[h] = 0.0;
+    double rmax, rsum;
+    const double *Bn = a.Bm + n * H;
+    if (PF) {
+      rmax = cur.rmax;
+      rsum = cur.rsum + EVO_F64_TINY;
+#pragma unroll
+      for (int i = 0; i < HB; i++) {
+        const int h = lane + 64 * i;
+        if (h < H) rowB[h] = cur.B[i];
+      }
+      Bn = rowB;
+    } else {
+      rmax = a.rowmax[n];
+      rsum = a.rowsum[n] + EVO_F64_TINY;
+      if (stage) {
+        for (int h = lane; h < H; h += 64) rowB[h] = Bn[h];
+        Bn = rowB;
+      }
+    }
+    const double4 *D1t = (PF || stage) ? d1s : a.D1;
     const double *lp = a.lpj_in + n * a.ldo + a.col0;
     lds_wave_fence();
     // Rounds of 64 states, four rounds per group, written as straight-line phases over the group so that the
     // loads of all four rounds are in flight together: a wave's time per datapoint is its chain of dependent
-    // memory round trips (digest / lpj -> table and B gathers -> arithmetic), not its instruction count.
-    for (int c0 = 0; c0 < a.C; c0 += 4 * 64) {
+    // memory round trips (digest / lpj -> pair table -> arithmetic), not its instruction count.
+    // (`first`: the datapoint's first group in a prefetching instantiation -- its inputs are in `cur`, and it issues
+    // the next datapoint's loads.  Peeled statically: under a runtime `c0 == 0` the compiler merges the two paths and
+    // waits for everything outstanding at the first use of a table entry.)
+    auto group = [&](const int c0, auto first_tag) {
+      constexpr bool first = decltype(first_tag)::value;
       constexpr int RG = 4;
       bool live[RG];
       int k[RG], idx0[RG], idx1[RG];
@@ -814,18 +881,26 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
         live[u] = c < a.C;
         k[u] = idx0[u] = idx1[u] = 0;
         l[u] = 0.0;
-        if (a.dig) {
-          const u64 d = a.dig[n * (i64)a.C + (live[u] ? c : 0)];
+        if (first) {
+          const u64 d = cur.d[u];
           k[u] = live[u] ? dig_k(d) : 0;
           idx0[u] = dig_idx(d, 0);
           idx1[u] = dig_idx(d, 1);
-        } else if (live[u]) {
-          load_state_k2<HWT>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k[u], idx0[u], idx1[u]);
+          l[u] = cur.l[u];
+        } else {
+          if (a.dig) {
+            const u64 d = a.dig[n * (i64)a.C + (live[u] ? c : 0)];
+            k[u] = live[u] ? dig_k(d) : 0;
+            idx0[u] = dig_idx(d, 0);
+            idx1[u] = dig_idx(d, 1);
+          } else if (live[u]) {
+            load_state_k2<0>(a.states + (n * (i64)a.C + c) * a.HW, a.HW, k[u], idx0[u], idx1[u]);
+          }
+          l[u] = lp[live[u] ? c : 0];
         }
-        l[u] = lp[live[u] ? c : 0];
       }
-      // states with more than two active latents: to the overflow list, one returning atomic per group that has
-      // any (issued now, its result is only needed after the arithmetic)
+      // states with more than two active latents: to the overflow list.  A few of them (the usual case) wait in
+      // the wave's LDS buffer and leave with one returning atomic per ~64 entries; many at once go directly.
       bool over[RG];
       int n_over = 0, my_off[RG];
 #pragma unroll
@@ -835,47 +910,49 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
         my_off[u] = n_over + __popcll(om & ((1ull << lane) - 1ull));
         n_over += __popcll(om);
       }
+      const bool o_direct = n_over > OVB;
       int obase = 0;
-      if (n_over) {  // uniform
+      if (o_direct) {  // uniform
         if (lane == 0) obase = atomicAdd(&lo.counts[shard], n_over);
         obase = __shfl(obase, 0, 64);
       }
-      // phase B: table entries and B values of every state of the group (harmless index 0 where unused)
+      // phase B: the pair-table entries of the group (harmless entry 0 where unused), then the next datapoint
       bool act[RG], pair[RG];
-      double4 d0[RG], d1[RG];
-      double b0[RG], b1[RG];
       PairEntry pe[RG];
 #pragma unroll
       for (int u = 0; u < RG; u++) {
         act[u] = live[u] && !over[u] && k[u] > 0;
         pair[u] = act[u] && k[u] == 2;
-        const int i0 = act[u] ? idx0[u] : 0, i1 = pair[u] ? idx1[u] : 0;
-        d0[u] = D1t[i0];
-        b0[u] = Bn[i0];
-        d1[u] = D1t[i1];
-        b1[u] = Bn[i1];
-        pe[u] = a.PT[pair[u] ? (i64)i0 * H + i1 : 0];
+        pe[u] = a.PT[pair[u] ? (i64)idx0[u] * H + idx1[u] : 0];
       }
-      // phase C: arithmetic, row moments (LDS), pair moments (bins)
+      if (first) {
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch behind the gathers in the memory queue
+        issue(n_next, cur);  // every member of `cur` has been consumed by now: the loads land in the loop-carried registers
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // phase C: singleton terms and B values (LDS when staged), arithmetic, row moments (LDS), pair moments (bins)
 #pragma unroll
       for (int u = 0; u < RG; u++) {
         const double q = act[u] ? exp(l[u] + (0.0 - rmax)) : 0.0;
         if (q != 0.0) {
           const double qn = q / rsum;
-          double g01 = 0.0, l00 = d0[u].w, l01 = 0.0, l10 = 0.0, l11 = 0.0, mu1 = 0.0, g11 = 0.0, bb1 = 0.0;
+          const double4 d0 = D1t[idx0[u]];  // mu, L1, G_hh, Lam
+          const double b0 = Bn[idx0[u]];
+          double g01 = 0.0, l00 = d0.w, l01 = 0.0, l10 = 0.0, l11 = 0.0, mu1 = 0.0, g11 = 0.0, bb1 = 0.0;
           if (pair[u]) {
+            const double4 d1 = D1t[idx1[u]];
             g01 = pe[u].g01;
             l00 = pe[u].l00;
             l01 = pe[u].l01;
             l10 = pe[u].l10;
             l11 = pe[u].l11;
-            mu1 = d1[u].x;
-            g11 = d1[u].z;
-            bb1 = b1[u];
+            mu1 = d1.x;
+            g11 = d1.z;
+            bb1 = Bn[idx1[u]];
             if (pe[u].singular != 0.0) atomicOr(a.err, 2);
           }
-          const double mu0 = d0[u].x;
-          const double v0 = b0[u] - d0[u].z * mu0 - g01 * mu1;
+          const double mu0 = d0.x;
+          const double v0 = b0 - d0.z * mu0 - g01 * mu1;
           const double v1 = bb1 - g01 * mu0 - g11 * mu1;
           const double k0 = s * (l00 * v0 + l01 * v1) + mu0;  // kappa = Lam v / sigma2 + mu  (sssc.py:574-575)
           const double k1 = s * (l10 * v0 + l11 * v1) + mu1;
@@ -911,12 +988,32 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
           }
         }
       }
+      if (n_over) {  // uniform
 #pragma unroll
-      for (int u = 0; u < RG; u++)
-        if (over[u]) {
-          const int pos = obase + my_off[u];
-          if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = (int)(n * a.C + c0 + 64 * u + lane);
+        for (int u = 0; u < RG; u++)
+          if (over[u]) {
+            const int e = (int)(n * a.C + c0 + 64 * u + lane);
+            if (o_direct) {
+              const int pos = obase + my_off[u];
+              if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = e;
+            } else {
+              obuf[wave][ocnt + my_off[u]] = e;
+            }
+          }
+        if (!o_direct) {
+          ocnt += n_over;
+          if (ocnt >= OVB) {
+            lds_wave_fence();
+            flush_obuf();
+          }
         }
+      }
+    };
+    if (PF) {
+      group(0, std::true_type{});
+      for (int c0 = 4 * 64; c0 < a.C; c0 += 4 * 64) group(c0, std::false_type{});
+    } else {
+      for (int c0 = 0; c0 < a.C; c0 += 4 * 64) group(c0, std::false_type{});
     }
     lds_wave_fence();
     // the datapoint's rows: out to [Y | Es | Ez] for the contraction, and into the workgroup's column sums
@@ -932,6 +1029,7 @@ __global__ __launch_bounds__(64 * W) void sssc_stats_wave_kernel(SsscArgs a, Lis
     }
     lds_wave_fence();
   }
+  if (ocnt) flush_obuf();
   __syncthreads();
   double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * H;
   for (int h = threadIdx.x; h < H; h += 64 * W) {
