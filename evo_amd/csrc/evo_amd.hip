@@ -426,6 +426,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                         (const void *)sssc_stats_wave_kernel<0, 1>,  (const void *)sssc_stats_wave_kernel<0, 8>,
                         (const void *)sssc_stats_wave_kernel<0, 16>};
     for (const void *f : wk) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  // + <= 9.2 KiB static
+    HIP_TRY(hipFuncSetAttribute((const void *)pair_bins_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PB_TILE * 8));
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<4, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<8, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   }
@@ -440,7 +441,7 @@ static void free_all(evoamd_ctx *c) {
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
-                  c->pbins.keys, c->pbins.qv, c->pbins.gcnt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
+                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -691,9 +692,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     if (rl) return rl;
     ALLOC(c->list_n, 4 * LIST_SHARDS);
     // pair bins of the statistics pass: 2 rf folded rows x H columns per LDS tile
-    if (c->pbins.keys) (void)hipFree(c->pbins.keys);
-    if (c->pbins.qv) (void)hipFree(c->pbins.qv);
+    if (c->pbins.ent) (void)hipFree(c->pbins.ent);
     if (c->pbins.gcnt) (void)hipFree(c->pbins.gcnt);
+    if (c->pbins.part) (void)hipFree(c->pbins.part);
     c->pbins = PairBins{};
     if (H >= 2 && H <= 1024) {
       PairBins pb = {};
@@ -701,12 +702,12 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       const int nfold = (H - 1 + 1) / 2;
       pb.nb = (int)cdiv(nfold, pb.rf);
       // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
-      // of its states being pairs spread evenly over the bins x 2
+      // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
       pb.nwg = 2048;
-      pb.cap = (int)std::max<i64>(64, 2 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
+      pb.cap = (int)std::max<i64>(64, 3 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
-      ALLOC(pb.keys, ne);
-      ALLOC(pb.qv, ne);
+      ALLOC(pb.ent, ne);
+      ALLOC(pb.part, (size_t)pb.nb * PB_NSH * 3 * 2 * pb.rf * H);
       ALLOC(pb.gcnt, (size_t)pb.nb * pb.nwg);
       HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
       c->pbins = pb;
@@ -1455,7 +1456,7 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
         default: sssc_main_lpj_kernel<TAG, 512, 0, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
       }
     } else
-      sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1);
+      sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1, PairBins{});
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "sssc lpj main");
   }
@@ -1465,12 +1466,12 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     // candidate batch level by level
     bool merged23 = false;
     if (need[0])
-      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2);
+      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{});
     DBG_SYNC(c, "sssc lpj K=4 level");
     const ListOut none_out = {nullptr, nullptr, 0};
     if (use_k8_kernel(c, TAG)) {
       if (need[1])
-        sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3);
+        sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3, PairBins{});
     } else if (need[1] && few_dense_states(c, TAG)) {
       // a handful of states above 4 active latents: ONE launch of the wavefront kernel at full capacity serves list 2
       // (a launch costs ~8 us however little it does; the k <= 8 sizing only pays for thousands of states)
@@ -2027,6 +2028,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const ListOut none_out = {nullptr, nullptr, 0};
   const double *Ywp = c->Y;  // EBSC: what the Wp contraction reads
   int ldwp = c->ldY;
+  // ES3C pair bins (decided once per pass): they pay when the tiles' fixed cost is a small part of the contributions
+  // they absorb
+  PairBins pb = {};
+  if (c->model == EVOAMD_MODEL_SSSC && !masked && c->pbins.ent &&
+      (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S / 2 >= 6 * (i64)c->pbins.nb * PB_NSH * (PB_TILE / 2))))
+    pb = c->pbins;
 
   for (int ci = 0; ci < nchunks; ci++) {
     const i64 n0 = (i64)ci * rows_per_chunk;
@@ -2132,13 +2139,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         // a wave per datapoint while that is at most a few rounds of resident workgroups (a second datapoint per wave
         // doubles the kernel's critical path at small N), a persistent grid-stride loop beyond
         int sgrid = (int)std::min<i64>(cdiv(nc, Wv), (i64)c->n_cu * per_cu * 4);
-        // pair bins pay when the tiles' flush is a small part of the contributions they absorb
-        PairBins pb = {};
-        if (c->pbins.keys && (c->pair_bins == 2 ||
-                              (c->pair_bins == 1 && total / 2 >= 6 * (i64)c->pbins.nb * PB_NSH * (PB_TILE / 2)))) {
-          pb = c->pbins;
-          if (sgrid > pb.nwg) sgrid = pb.nwg;  // one private region per producer workgroup and bin
-        }
+        if (pb.ent && sgrid > pb.nwg) sgrid = pb.nwg;  // one private region per producer workgroup and bin
 #define STATS_WAVE(HWT) sssc_stats_wave_kernel<HWT, 4><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage)
         if (Wv == 1) {
           sssc_stats_wave_kernel<0, 1><<<sgrid, 64, lds, c->stream>>>(sc, o1, pb, stage);
@@ -2161,12 +2162,6 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
 #undef STATS_WAVE
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats main");
-        if (pb.keys) {
-          pair_bins_reduce_kernel<<<pb.nb * PB_NSH, 256, (size_t)2 * pb.rf * H * sizeof(double2), c->stream>>>(
-              pb, H, c->acc + a.xss, c->acc + a.xszsz);
-          HIP_TRY(hipGetLastError());
-          DBG_SYNC(c, "pair bins reduce");
-        }
       }
       if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
@@ -2174,10 +2169,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         const size_t cs_lds = sc.cs ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
         bool merged23 = false;
         if (need[0])
-          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2);
+          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2, pb);
         if (use_k8_kernel(c, tg)) {
           if (need[1])
-            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3);
+            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3, pb);
         } else if (need[1] && few_dense_states(c, tg)) {
           sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
               sc, i2, none_out, SSSC_KCAP);  // one launch for both wavefront levels (see launch_sssc_lpj)
@@ -2190,6 +2185,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
               sc, i3, none_out, SSSC_KCAP);
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats overflow levels");
+      }
+      if (pb.ent) {  // the entries of the main kernel and of the register-kernel levels: one tile pass per block
+        SpanGuard g(c, KID_STATS);
+        pair_bins_reduce_kernel<<<pb.nb * PB_NSH, PB_RTHREADS, (size_t)3 * 2 * pb.rf * H * sizeof(double), c->stream>>>(pb, H, ci > 0);
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "pair bins reduce");
       }
       // a skipped level must have found its input list empty (census_lists_kernel / tail_kernel check)
       skipped = skip_mask(need);
@@ -2209,7 +2210,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
                                                                      c->acc + a.xsz, masked ? c->colpart : sa.cs,
                                                                      masked ? nblk : CS_SLICES, H, c->y2sum, c->acc + a.y2, D,
-                                                                     sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT);
+                                                                     sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT, pb);
         }
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "colsum + finish");

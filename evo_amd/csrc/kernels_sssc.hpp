@@ -26,13 +26,16 @@
 
 // State terms that depend on the active set only (the reference memoises exactly these per state id
 // in `storage`, sssc.py:268-318): for |A| = 2, one 64-byte entry per latent pair.
-struct PairEntry {
+// Three 16-byte loads fetch everything either pass needs.  det T_A == 0 (the reference would take pinv) shows as
+// L == +inf and a non-finite Lam: pair_singular_L / pair_singular_lam.
+struct __attribute__((aligned(64))) PairEntry {
   double g01;                 // G[h0][h1]
   double L;                   // pil_bar_h0 + pil_bar_h1 - log|det T_A| / 2
   double l00, l01, l10, l11;  // Lam_A = T_A^-1 Psi_A  ( = M_s^-1 of sssc.py:300 )
-  double singular;            // != 0: det T_A == 0 (the reference would take pinv)
-  double pad;
+  double pad[2];
 };
+__device__ __forceinline__ bool pair_singular_L(double L) { return L == __builtin_inf(); }
+__device__ __forceinline__ bool pair_singular_lam(double l00) { return !(fabs(l00) <= 1.7976931348623157e308); }
 
 #define CS_SLICES 16
 struct SsscArgs {
@@ -77,6 +80,104 @@ struct SsscArgs {
 };
 
 #define SSSC_KCAP 64
+
+// ---------------------------------------------------------------------------------------
+// Pair bins.  The second moments of the states with two active latents are sums over ALL datapoints of
+// (q, q (Lam_01 + kappa_0 kappa_1)) into element (i, j), i < j, of two H x H matrices: ~N S / 2 contributions on
+// H^2 / 2 addresses.  As global f64 atomics they run at the memory-side atomic rate (23.6 G/s measured,
+// tools/probes/atom_scope_probe.hip, whatever the scope) and were all this pass waited for.  Instead every
+// contribution is APPENDED (plain stores) to the bin of its row i -- every producer workgroup owns a private region
+// per bin and counts in LDS, so an append costs no global atomic at all (a first version that reserved slots with
+// one returning atomic per workgroup and bin was slower than the direct atomics) --; a second kernel reduces each
+// bin in an LDS tile and adds the tile to the matrices once.  Rows are folded (i with H-2-i: H partners per folded row) so that the
+// bins of the upper triangle fill evenly.  A bin region that is full falls back to the direct atomics.
+// ---------------------------------------------------------------------------------------
+#define PB_TILE 4096  // pair slots per LDS tile (x 3 values x 8 bytes = 96 KiB)
+#define PB_MAX_BINS 256
+#define PB_NSH 4      // reduce workgroups per bin
+#define PB_RTHREADS 1024  // threads of a reduce workgroup (the 96 KiB tile leaves one workgroup per CU)
+struct PairBins {
+  // nb x nwg private regions of `cap` 32-byte entries (one aligned sector each): {q, q (Lam_01 + kappa_0 kappa_1),
+  // q (Lam_10 + kappa_1 kappa_0), key} -- what elements (i, j) of xpt_ss / xpt_szsz and (j, i) of xpt_szsz receive, i < j;
+  // key = (tile row << 16) | j in the low bits of the fourth double
+  double4 *ent;
+  int *gcnt;       // nb x nwg: entries each producer workgroup left in each bin (the reduce kernel zeroes them)
+  double *part;    // nb x PB_NSH reduced tiles of 3 planes x (2 rf H) slots, summed by sssc_finish_kernel
+  int cap, nb, rf, nwg;  // rf folded rows per bin: the tile holds 2 rf rows x H columns; nwg producer workgroups
+};
+__device__ __forceinline__ int pb_fold(int i, int H) { return i < H - 2 - i ? i : H - 2 - i; }
+
+// One entry for element (i, j), i < j, into the private region of workgroup `wg`; false: the region is full (the
+// caller adds the three values with global atomics instead).  `bcnt`: the workgroup's LDS counters, one per bin.
+__device__ __forceinline__ bool pb_append(const PairBins &pb, int *bcnt, int wg, int H, int i, int j, double q,
+                                          double vu, double vl) {
+  const int f = pb_fold(i, H);
+  const int bin = f / pb.rf;
+  const int pos = atomicAdd(&bcnt[bin], 1);  // LDS: the workgroup's running count for this bin
+  if (pos >= pb.cap) return false;
+  const int r = 2 * (f - bin * pb.rf) + (i != f ? 1 : 0);
+  const size_t at = ((size_t)bin * pb.nwg + wg) * pb.cap + pos;
+  pb.ent[at] = make_double4(q, vu, vl, __longlong_as_double((long long)(((unsigned)r << 16) | (unsigned)j)));
+  return true;
+}
+
+// Workgroup (bin, s) reduces the regions that the producer workgroups w = s, s + PB_NSH, ... left in `bin`: LDS tile
+// <- their entries (ds_add_f64), then the whole tile with plain stores to its own slab of pb.part (accumulate != 0:
+// added to what an earlier block of datapoints left there).  sssc_finish_kernel adds the PB_NSH slabs of a bin in a
+// fixed order: no global atomic anywhere on this route.  One wave per region at a time.  2 rf H <= PB_TILE.
+__global__ __launch_bounds__(PB_RTHREADS) void pair_bins_reduce_kernel(PairBins pb, int H, int accumulate) {
+  extern __shared__ double pb_tile[];
+  const int bin = blockIdx.x / PB_NSH, sh = blockIdx.x - bin * PB_NSH;
+  const int slots = 2 * pb.rf * H;
+  double *tq = pb_tile, *tu = pb_tile + slots, *tl = pb_tile + 2 * slots;
+  for (int i = threadIdx.x; i < 3 * slots; i += PB_RTHREADS) pb_tile[i] = 0.0;
+  lds_barrier();
+  const int lane = lane_id(), wave = wave_id_uniform();
+  for (int w = sh + PB_NSH * wave; w < pb.nwg; w += PB_NSH * (PB_RTHREADS / 64)) {
+    const size_t reg = (size_t)bin * pb.nwg + w;
+    int n = pb.gcnt[reg];
+    if (n > pb.cap) n = pb.cap;
+    if (n == 0) continue;  // wave-uniform
+    if (lane == 0) pb.gcnt[reg] = 0;  // ready for the next pass
+    const double4 *ent = pb.ent + reg * pb.cap;
+    for (int e0 = 0; e0 < n; e0 += 128) {  // two entries in flight per lane
+      const int ea = e0 + lane, eb = e0 + 64 + lane;
+      const double4 va = ent[ea < n ? ea : 0], vb = ent[eb < n ? eb : 0];
+      if (ea < n) {
+        const unsigned ka = (unsigned)__double_as_longlong(va.w);
+        const int t = (int)(ka >> 16) * H + (int)(ka & 0xFFFFu);
+        unsafeAtomicAdd(&tq[t], va.x);
+        unsafeAtomicAdd(&tu[t], va.y);
+        unsafeAtomicAdd(&tl[t], va.z);
+      }
+      if (eb < n) {
+        const unsigned kb = (unsigned)__double_as_longlong(vb.w);
+        const int t = (int)(kb >> 16) * H + (int)(kb & 0xFFFFu);
+        unsafeAtomicAdd(&tq[t], vb.x);
+        unsafeAtomicAdd(&tu[t], vb.y);
+        unsafeAtomicAdd(&tl[t], vb.z);
+      }
+    }
+  }
+  lds_barrier();
+  double *out = pb.part + (size_t)blockIdx.x * 3 * slots;
+  for (int i = threadIdx.x; i < 3 * slots; i += PB_RTHREADS) out[i] = accumulate ? out[i] + pb_tile[i] : pb_tile[i];
+}
+
+// What the pair bins hold for element t = (i, j), i < j: {sum q, sum for (i, j), sum for (j, i)}.
+__device__ __forceinline__ void pb_collect(const PairBins &pb, int H, int i, int j, double &bq, double &bu, double &bl) {
+  const int f = pb_fold(i, H), bin = f / pb.rf;
+  const int slots = 2 * pb.rf * H;
+  const int slot = (2 * (f - bin * pb.rf) + (i != f ? 1 : 0)) * H + j;
+  const double *p = pb.part + (size_t)bin * PB_NSH * 3 * slots + slot;
+  bq = bu = bl = 0.0;
+  for (int sh = 0; sh < PB_NSH; sh++, p += 3 * slots) {
+    bq += p[0];
+    bu += p[slots];
+    bl += p[2 * slots];
+  }
+}
+
 
 template <int K>
 __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K], double (*P)[K], bool with_P,
@@ -341,16 +442,19 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
 // every off-diagonal entry (Lam is not symmetric once Psi is not).
 template <int K>
 __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&idx)[K], int k, double qn,
-                                                const double (&kap)[K], const double (&P)[K][K]) {
+                                                const double (&kap)[K], const double (&P)[K][K], const PairBins &pb,
+                                                int *bcnt) {
 #pragma unroll
   for (int i = 0; i < K; i++) {
     if (i < k) {
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (j < k) {
-          const i64 o = (i64)idx[i] * a.H + idx[j];
-          if (j > i) unsafeAtomicAdd(&a.xss_o[o], qn);
-          if (j != i) unsafeAtomicAdd(&a.xszsz_o[o], qn * (P[i][j] + kap[i] * kap[j]));
+      for (int j = i + 1; j < K; j++) {
+        if (j < k) {  // idx ascending: (idx[i], idx[j]) is an upper-triangle element
+          const double vu = qn * (P[i][j] + kap[i] * kap[j]), vl = qn * (P[j][i] + kap[j] * kap[i]);
+          if (pb.ent && pb_append(pb, bcnt, blockIdx.x, a.H, idx[i], idx[j], qn, vu, vl)) continue;
+          unsafeAtomicAdd(&a.xss_o[(i64)idx[i] * a.H + idx[j]], qn);
+          unsafeAtomicAdd(&a.xszsz_o[(i64)idx[i] * a.H + idx[j]], vu);
+          unsafeAtomicAdd(&a.xszsz_o[(i64)idx[j] * a.H + idx[i]], vl);
         }
       }
     }
@@ -364,11 +468,19 @@ __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&i
 // that profilers report the pass over K^n (0), over the candidate batch (1) and the list-driven /
 // auxiliary launches (2) under different kernel names.  BS = workgroup size.
 template <int K, int MODE, int TAG, int BS>
-__global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo) {
+__global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo, PairBins pb) {
   a.s2inv = a.dpar[DP_S2INV];
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int ovf_buf[BS];
   __shared__ int ovf_ctl[2];
+  // statistics: the pair moments go to this workgroup's regions of the pair bins, behind what the workgroup of the same
+  // index of an earlier kernel of the pass left there (pb.gcnt); gridDim.x <= pb.nwg (host)
+  __shared__ int bcnt[MODE == 1 ? PB_MAX_BINS : 1];
+  const bool binned = MODE == 1 && pb.ent != nullptr;
+  if (binned) {
+    for (int i = threadIdx.x; i < pb.nb; i += BS) bcnt[i] = pb.gcnt[(size_t)i * pb.nwg + blockIdx.x];
+    __syncthreads();
+  }
   // statistics with in-kernel column sums (a.cs_s): 3 H doubles of dynamic LDS collect this workgroup's share of
   // sum_n xpt_s / xpt_sz / diag(xpt_szsz); as global atomics they were 9-12 per state on 3 H addresses (+150 us)
   extern __shared__ double cs_acc[];
@@ -447,7 +559,14 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
           }
         }
       }
-      sssc_scatter_hh<K>(a, idx, k, qn, kap, P);
+      sssc_scatter_hh<K>(a, idx, k, qn, kap, P, pb, bcnt);
+    }
+  }
+  if (binned) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < pb.nb; i += BS) {
+      const int cnt = bcnt[i];
+      pb.gcnt[(size_t)i * pb.nwg + blockIdx.x] = cnt < pb.cap ? cnt : pb.cap;
     }
   }
   if (cs_lds) {
@@ -661,7 +780,7 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
         l01 = pe.l01;
         l10 = pe.l10;
         l11 = pe.l11;
-        if (pe.singular != 0.0) atomicOr(a.err, 2);
+        if (pair_singular_L(pe.L)) atomicOr(a.err, 2);
       }
       const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
       const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
@@ -678,77 +797,6 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
     }
   }
   append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
-}
-
-// ---------------------------------------------------------------------------------------
-// Pair bins.  The second moments of the states with two active latents are sums over ALL datapoints of
-// (q, q (Lam_01 + kappa_0 kappa_1)) into element (i, j), i < j, of two H x H matrices: ~N S / 2 contributions on
-// H^2 / 2 addresses.  As global f64 atomics they run at the memory-side atomic rate (23.6 G/s measured,
-// tools/probes/atom_scope_probe.hip, whatever the scope) and were all this pass waited for.  Instead every
-// contribution is APPENDED (plain stores) to the bin of its row i -- every producer workgroup owns a private region
-// per bin and counts in LDS, so an append costs no global atomic at all (a first version that reserved slots with
-// one returning atomic per workgroup and bin was slower than the direct atomics) --; a second kernel reduces each
-// bin in an LDS tile and adds the tile to the matrices once.  Rows are folded (i with H-2-i: H partners per folded row) so that the
-// bins of the upper triangle fill evenly.  A bin region that is full falls back to the direct atomics.
-// ---------------------------------------------------------------------------------------
-#define PB_TILE 4096  // pair slots per LDS tile (x 16 bytes = 64 KiB)
-#define PB_MAX_BINS 256
-#define PB_NSH 8      // reduce workgroups per bin
-struct PairBins {
-  unsigned *keys;  // nb x nwg private regions of `cap` entries: (tile row << 16) | j
-  double2 *qv;     // {q, q (Lam_01 + kappa_0 kappa_1)}
-  int *gcnt;       // nb x nwg: entries each producer workgroup left in each bin (the reduce kernel zeroes them)
-  int cap, nb, rf, nwg;  // rf folded rows per bin: the tile holds 2 rf rows x H columns; nwg producer workgroups
-};
-__device__ __forceinline__ int pb_fold(int i, int H) { return i < H - 2 - i ? i : H - 2 - i; }
-
-// Workgroup (bin, s) reduces the regions that the producer workgroups w = s, s + PB_NSH, ... left in `bin`: LDS tile
-// <- their entries (ds_add_f64), then the non-zero slots once to the matrices.  One wave per region at a time.
-// 2 rf H <= PB_TILE.
-__global__ __launch_bounds__(256) void pair_bins_reduce_kernel(PairBins pb, int H, double *__restrict__ xss,
-                                                               double *__restrict__ xszsz) {
-  extern __shared__ double2 pb_tile[];
-  const int bin = blockIdx.x / PB_NSH, sh = blockIdx.x - bin * PB_NSH;
-  const int slots = 2 * pb.rf * H;
-  for (int i = threadIdx.x; i < slots; i += 256) pb_tile[i] = make_double2(0.0, 0.0);
-  lds_barrier();
-  const int lane = lane_id(), wave = wave_id_uniform();
-  for (int w = sh + PB_NSH * wave; w < pb.nwg; w += PB_NSH * 4) {
-    const size_t reg = (size_t)bin * pb.nwg + w;
-    int n = pb.gcnt[reg];
-    if (n > pb.cap) n = pb.cap;
-    if (n == 0) continue;  // wave-uniform
-    if (lane == 0) pb.gcnt[reg] = 0;  // ready for the next pass
-    const unsigned *keys = pb.keys + reg * pb.cap;
-    const double2 *qv = pb.qv + reg * pb.cap;
-    for (int e0 = 0; e0 < n; e0 += 128) {  // two entries in flight per lane
-      const int ea = e0 + lane, eb = e0 + 64 + lane;
-      const unsigned ka = ea < n ? keys[ea] : 0xFFFFFFFFu, kb = eb < n ? keys[eb] : 0xFFFFFFFFu;
-      const double2 va = ea < n ? qv[ea] : make_double2(0.0, 0.0), vb = eb < n ? qv[eb] : make_double2(0.0, 0.0);
-      if (ka != 0xFFFFFFFFu) {
-        double2 *t = &pb_tile[(int)(ka >> 16) * H + (int)(ka & 0xFFFFu)];
-        unsafeAtomicAdd(&t->x, va.x);
-        unsafeAtomicAdd(&t->y, va.y);
-      }
-      if (kb != 0xFFFFFFFFu) {
-        double2 *t = &pb_tile[(int)(kb >> 16) * H + (int)(kb & 0xFFFFu)];
-        unsafeAtomicAdd(&t->x, vb.x);
-        unsafeAtomicAdd(&t->y, vb.y);
-      }
-    }
-  }
-  lds_barrier();
-  for (int idx = threadIdx.x; idx < slots; idx += 256) {
-    const double2 v = pb_tile[idx];
-    if (v.x != 0.0 || v.y != 0.0) {
-      const int r = idx / H, j = idx - r * H;
-      const int f = bin * pb.rf + (r >> 1);
-      const int i = (r & 1) ? H - 2 - f : f;
-      const i64 o = (i64)i * H + j;
-      unsafeAtomicAdd(&xss[o], v.x);
-      unsafeAtomicAdd(&xszsz[o], v.y);
-    }
-  }
 }
 
 // Main statistics pass over the resident K^n (sssc.py:553-611), states with |A| <= 2 (the others go to the
@@ -782,7 +830,7 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
   double *accS = wrows + (size_t)W * 2 * H, *accZ = accS + H, *accD = accZ + H;
   double *rowB = accD + H + (size_t)wave * H;                 // stage only
   double4 *d1s = (double4 *)(accD + H + (size_t)W * H);       // stage only (32-byte aligned: all offsets are multiples of H doubles, H even)
-  const bool binned = pb.keys != nullptr;
+  const bool binned = pb.ent != nullptr;
   for (int i = threadIdx.x; i < 3 * H; i += 64 * W) accS[i] = 0.0;
   if (HWT > 0 || stage)
     for (int i = threadIdx.x; i < H; i += 64 * W) d1s[i] = a.D1[i];
@@ -949,7 +997,7 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
             mu1 = d1.x;
             g11 = d1.z;
             bb1 = Bn[idx1[u]];
-            if (pe[u].singular != 0.0) atomicOr(a.err, 2);
+            if (pair_singular_lam(pe[u].l00)) atomicOr(a.err, 2);
           }
           const double mu0 = d0.x;
           const double v0 = b0 - d0.z * mu0 - g01 * mu1;
@@ -963,27 +1011,21 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
             unsafeAtomicAdd(&rowS[idx1[u]], qn);
             unsafeAtomicAdd(&rowZ[idx1[u]], qn * k1);
             unsafeAtomicAdd(&accD[idx1[u]], qn * (l11 + k1 * k1));
-            // element (idx0, idx1) of the two H x H sums; the (idx1, idx0) element of xszsz differs by
-            // qn (l10 - l01), a per-PAIR constant times xss[o01]: sssc_finish_kernel adds it
+            // element (idx0, idx1) of the two H x H sums.  Without bins: the (idx1, idx0) element of xszsz
+            // differs by qn (l10 - l01), a per-PAIR constant times xss[o01]: sssc_finish_kernel adds it
             const double pq = qn, pv = qn * (l01 + k0 * k1);
-            bool direct = !binned;
-            if (binned) {
-              const int f = pb_fold(idx0[u], H);
-              const int bin = f / pb.rf;
-              const int pos = atomicAdd(&bcnt[bin], 1);  // LDS: the workgroup's running count for this bin
-              if (pos < pb.cap) {
-                const int r = 2 * (f - bin * pb.rf) + (idx0[u] != f ? 1 : 0);
-                const size_t at = ((size_t)bin * pb.nwg + blockIdx.x) * pb.cap + pos;
-                pb.keys[at] = ((unsigned)r << 16) | (unsigned)idx1[u];
-                pb.qv[at] = make_double2(pq, pv);
-              } else {
-                direct = true;  // region full
-              }
-            }
-            if (direct) {
-              const i64 o01 = (i64)idx0[u] * H + idx1[u];
+            const i64 o01 = (i64)idx0[u] * H + idx1[u];
+            if (!binned) {
               unsafeAtomicAdd(&a.xss[o01], pq);
               unsafeAtomicAdd(&a.xszsz[o01], pv);
+            } else {
+              // the bins carry both triangles explicitly (like the overflow kernels' contributions)
+              const double pw = qn * (l10 + k1 * k0);
+              if (!pb_append(pb, bcnt, blockIdx.x, H, idx0[u], idx1[u], pq, pv, pw)) {  // region full
+                unsafeAtomicAdd(&a.xss_o[o01], pq);
+                unsafeAtomicAdd(&a.xszsz_o[o01], pv);
+                unsafeAtomicAdd(&a.xszsz_o[(i64)idx1[u] * H + idx0[u]], pw);
+              }
             }
           }
         }
@@ -1301,7 +1343,7 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
                                                           const double *__restrict__ y2sum, double *__restrict__ y2out,
                                                           int D, const double *__restrict__ xss_o,
                                                           const double *__restrict__ xszsz_o,
-                                                          const PairEntry *__restrict__ PT) {
+                                                          const PairEntry *__restrict__ PT, PairBins pb) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t < D) y2out[t] = y2sum[t];
   if (t >= (i64)H * H) return;
@@ -1327,11 +1369,13 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
       const PairEntry pe = PT[t];
       lower = u + (pe.l10 - pe.l01) * uss;
     }
-    const double ss = uss + xss_o[t];
+    double bq = 0.0, bu = 0.0, bl = 0.0;
+    if (pb.part) pb_collect(pb, H, i, j, bq, bu, bl);  // what went through the pair bins in this pass
+    const double ss = uss + xss_o[t] + bq;
     xss[t] = ss;
     xss[tl] = ss;
-    xszsz[t] = u + xszsz_o[t];
-    xszsz[tl] = lower + xszsz_o[tl];
+    xszsz[t] = u + xszsz_o[t] + bu;
+    xszsz[tl] = lower + xszsz_o[tl] + bl;
   }
 }
 
@@ -1379,8 +1423,7 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
   e.l01 = (T11 * P01 - T01 * P11) * rdet;
   e.l10 = (T00 * P10 - T10 * P00) * rdet;
   e.l11 = (T00 * P11 - T10 * P01) * rdet;
-  e.singular = (det == 0.0) ? 1.0 : 0.0;
-  e.pad = 0.0;
+  e.pad[0] = e.pad[1] = 0.0;  // det == 0: L = +inf and Lam non-finite carry the "singular" mark
   PT[t] = e;
 }
 
