@@ -154,6 +154,9 @@ struct evoamd_ctx {
   int stats_stage = 1;  // option "stats_stage" (measurement): 0 = no LDS staging of B rows / singleton table
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
+  int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
+  double *gemm_ws = nullptr;  // partial tiles of the stream-K contractions (gemm_sk_reduce_kernel adds them to C)
+  size_t gemm_ws_n = 0;
   int pair_bins = 1;
   int gemm_streamk = 1;  // option "gemm_streamk": long-K 128-tile contraction as one resident-sized stream-K grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
@@ -441,7 +444,7 @@ static void free_all(evoamd_ctx *c) {
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
-                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
+                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -520,6 +523,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_streamk") == 0) {
     c->gemm_streamk = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_workspace") == 0) {
+    c->gemm_ws_opt = value;
     return 0;
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
@@ -961,6 +968,25 @@ static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const do
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
 // accumulate: C += A^T B with the atomic epilogue whatever the split (C holds earlier blocks of the same product: the
 // chunked statistics pass); mirror = false leaves the lower tiles of a symmetric block for a later call.
+// Workspace of the stream-K contractions: `segmax` 128 x 128 slabs per workgroup (a run of U / wpx units touches at
+// most n_real / wpx + 2 tiles).  Returns nullptr (atomic epilogue) when it cannot be had.
+static double *streamk_workspace(evoamd_ctx *c, unsigned wpx, i64 n_real, int *segmax) {
+  *segmax = (int)(n_real / wpx) + 2;
+  const size_t need = (size_t)8 * wpx * (size_t)*segmax * GEMM_T * GEMM_T;
+  if (need > c->gemm_ws_n) {
+    if (c->gemm_ws) (void)hipFree(c->gemm_ws);
+    c->gemm_ws = nullptr;
+    c->gemm_ws_n = 0;
+    if (hipMalloc((void **)&c->gemm_ws, need * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      c->gemm_ws = nullptr;
+      return nullptr;
+    }
+    c->gemm_ws_n = need;
+  }
+  return c->gemm_ws;
+}
+
 static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                           int M, int Nc, i64 K, bool deterministic = false, int sym_row0 = -1,
                           bool c_is_zero = false, bool accumulate = false, bool mirror = true) {
@@ -1042,8 +1068,13 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     }
     const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
+    int segmax = 0;
+    double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, real, &segmax) : nullptr;
     gemm_tn128_sk_f64<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0,
-                                                                       (int)real);
+                                                                       (int)real, ws, segmax);
+    if (ws)
+      gemm_sk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(
+          ws, segmax, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0, (int)real, (int)wpx);
   } else if (big)
     gemm_tn128_f64<<<grid, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   else if (vec)
@@ -1192,7 +1223,13 @@ static int launch_gemm_tn_f32(evoamd_ctx *c, const float *A, int lda, const floa
     const int gx = (int)cdiv(Nc, GEMM_T), gy = (int)cdiv(M, GEMM_T);
     const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
-    gemm_tn128_sk_f32<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, gx * gy);
+    int segmax = 0;
+    double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, (i64)gx * gy, &segmax) : nullptr;
+    gemm_tn128_sk_f32<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, gx * gy, ws,
+                                                                       segmax);
+    if (ws)
+      gemm_sk_reduce_kernel<<<dim3((unsigned)(gx * gy), GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(
+          ws, segmax, C, ldc, M, Nc, K, Kx, gx, gy, -1, gx * gy, (int)wpx);
   } else {
     gemm_tn_naive_f32<<<cdiv((i64)M * Nc, 256), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K);
   }

@@ -81,10 +81,10 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
         // outside; M and Nc are even in the VEC instantiation, so a piece is inside or outside as a whole
         const i64 krc = kin ? kr : kend - 1;
         const int ma = m0 + cc, nb = n0 + cc;
+        // (what lies outside is zeroed in stash(): a select on the loaded value HERE makes the compiler wait for the
+        // load right behind its issue, i.e. a full memory round trip per slab in front of the barrier)
         double2 va = *(const double2 *)(A + krc * lda + (ma < M ? ma : M - 2));
         double2 vb = *(const double2 *)(B + krc * ldb + (nb < Nc ? nb : Nc - 2));
-        if (!(kin && ma < M)) va = make_double2(0.0, 0.0);
-        if (!(kin && nb < Nc)) vb = make_double2(0.0, 0.0);
         qa[2 * i] = va.x;
         qa[2 * i + 1] = va.y;
         qb[2 * i] = vb.x;
@@ -101,13 +101,15 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
       }
     }
   };
-  auto stash = [&](const double(&qa)[4], const double(&qb)[4], int buf) {
+  auto stash = [&](const double(&qa)[4], const double(&qb)[4], int buf, i64 k0) {
     if (VEC) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int p = t + 256 * i, r = p >> 5, cc = (p & 31) * 2;
-        *(double2 *)&As[buf][r][cc] = make_double2(qa[2 * i], qa[2 * i + 1]);
-        *(double2 *)&Bs[buf][r][cc] = make_double2(qb[2 * i], qb[2 * i + 1]);
+        const bool kin = k0 + r < kend;
+        const bool ina = kin && m0 + cc < M, inb = kin && n0 + cc < Nc;
+        *(double2 *)&As[buf][r][cc] = ina ? make_double2(qa[2 * i], qa[2 * i + 1]) : make_double2(0.0, 0.0);
+        *(double2 *)&Bs[buf][r][cc] = inb ? make_double2(qb[2 * i], qb[2 * i + 1]) : make_double2(0.0, 0.0);
       }
     } else {
 #pragma unroll
@@ -136,10 +138,16 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
   const i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
   if (nslab > 0) {
     fetch(ra[0], rb[0], kbeg);
-    stash(ra[0], rb[0], 0);
-    if (nslab > 1) fetch(ra[0], rb[0], kbeg + GEMM_BK);
-    if (nslab > 2) fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
-    if (nslab > 3) fetch(ra[2], rb[2], kbeg + 3 * GEMM_BK);
+    stash(ra[0], rb[0], 0, kbeg);
+    if (VEC) {  // (clamped addresses: fetching behind the end is harmless, see the loop)
+      fetch(ra[0], rb[0], kbeg + GEMM_BK);
+      fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+      fetch(ra[2], rb[2], kbeg + 3 * GEMM_BK);
+    } else {
+      if (nslab > 1) fetch(ra[0], rb[0], kbeg + GEMM_BK);
+      if (nslab > 2) fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+      if (nslab > 3) fetch(ra[2], rb[2], kbeg + 3 * GEMM_BK);
+    }
   }
   __syncthreads();
   // slab s is in LDS buffer s & 1; slab s + 1 + j waits in register set j (rotating)
@@ -150,8 +158,10 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
       if (sl < nslab) {  // uniform
         const int buf = (int)(sl & 1);
         compute(buf);
-        if (sl + 1 < nslab) stash(ra[j], rb[j], buf ^ 1);                                   // slab sl + 1
-        if (sl + 4 < nslab) fetch(ra[j], rb[j], kbeg + (sl + 4) * GEMM_BK);                 // refill the set
+        // VEC: stash and fetch unconditionally (zeroed rows / clamped addresses behind the end) -- under `if (more)`
+        // the compiler counts the outstanding loads of the path without the newer fetches and waits for vmcnt(0)
+        if (VEC || sl + 1 < nslab) stash(ra[j], rb[j], buf ^ 1, kbeg + (sl + 1) * GEMM_BK);  // slab sl + 1
+        if (VEC || sl + 4 < nslab) fetch(ra[j], rb[j], kbeg + (sl + 4) * GEMM_BK);           // refill the set
         __syncthreads();
       }
     }
@@ -210,7 +220,7 @@ template <typename T, typename TO>
 __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb,
                                                    TO *__restrict__ C, int ldc, int M, int Nc, int m0, int n0, i64 kbeg,
                                                    i64 kend, bool atomic, T (*As)[GEMM_BK][GEMM_LDS2],
-                                                   T (*Bs)[GEMM_BK][GEMM_LDS2]) {
+                                                   T (*Bs)[GEMM_BK][GEMM_LDS2], TO *__restrict__ slab = nullptr) {
   typedef Mfma16<T> MM;
   typedef typename MM::piece_t piece_t;
   constexpr int EPP = MM::EPP;             // elements per 16-byte piece
@@ -236,20 +246,19 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
       const bool kin = kr < kend;
       const i64 krc = kin ? kr : kend - 1;
       const int ma = m0 + cc, nb = n0 + cc;
-      piece_t va = *(const piece_t *)(A + krc * lda + (ma < M ? ma : M - EPP));
-      piece_t vb = *(const piece_t *)(B + krc * ldb + (nb < Nc ? nb : Nc - EPP));
-      if (!(kin && ma < M)) va = MM::zero();
-      if (!(kin && nb < Nc)) vb = MM::zero();
-      qa[i] = va;
-      qb[i] = vb;
+      // clamped addresses only; what lies outside is zeroed in stash(), two slabs later (a select on the loaded value
+      // here would park the wave on the load it has just issued, in front of the slab's barrier)
+      qa[i] = *(const piece_t *)(A + krc * lda + (ma < M ? ma : M - EPP));
+      qb[i] = *(const piece_t *)(B + krc * ldb + (nb < Nc ? nb : Nc - EPP));
     }
   };
-  auto stash = [&](const piece_t(&qa)[NP], const piece_t(&qb)[NP], int buf) {
+  auto stash = [&](const piece_t(&qa)[NP], const piece_t(&qb)[NP], int buf, i64 k0) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const int p = t + 256 * i, r = p / PPR, cc = (p % PPR) * EPP;
-      *(piece_t *)&As[buf][r][cc] = qa[i];
-      *(piece_t *)&Bs[buf][r][cc] = qb[i];
+      const bool kin = k0 + r < kend;
+      *(piece_t *)&As[buf][r][cc] = (kin && m0 + cc < M) ? qa[i] : MM::zero();
+      *(piece_t *)&Bs[buf][r][cc] = (kin && n0 + cc < Nc) ? qb[i] : MM::zero();
     }
   };
   auto compute = [&](int buf) {
@@ -267,25 +276,27 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
         for (int j = 0; j < 4; j++) acc[i][j] = MM::mma(a[i], b[j], acc[i][j]);
     }
   };
-  const i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+  // The slab loop is branch-free: an odd slab count is padded with an all-zero slab (stash() zeroes rows >= kend),
+  // and the fetches behind the end re-read row kend - 1 (clamped).  With `if (more) fetch(...)` in the loop the
+  // compiler has to assume the path WITHOUT the newer fetch when it counts what is outstanding, and waits for
+  // vmcnt(0) -- the slab fetched one iteration ago, a full memory round trip -- before every stash.
+  i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
+  nslab = (nslab + 1) & ~(i64)1;
   if (nslab > 0) {
     fetch(ra[0], rb[0], kbeg);
-    stash(ra[0], rb[0], 0);
-    if (nslab > 1) fetch(ra[0], rb[0], kbeg + GEMM_BK);
-    if (nslab > 2) fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+    stash(ra[0], rb[0], 0, kbeg);
+    fetch(ra[0], rb[0], kbeg + GEMM_BK);
+    fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
   }
   __syncthreads();
   for (i64 s0 = 0; s0 < nslab; s0 += 2) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const i64 sl = s0 + j;
-      if (sl < nslab) {  // uniform
-        const int buf = (int)(sl & 1);
-        compute(buf);
-        if (sl + 1 < nslab) stash(ra[j], rb[j], buf ^ 1);
-        if (sl + 3 < nslab) fetch(ra[j], rb[j], kbeg + (sl + 3) * GEMM_BK);
-        __syncthreads();
-      }
+      compute(j);
+      stash(ra[j], rb[j], j ^ 1, kbeg + (sl + 1) * GEMM_BK);
+      fetch(ra[j], rb[j], kbeg + (sl + 3) * GEMM_BK);
+      __syncthreads();
     }
   }
 #pragma unroll
@@ -296,7 +307,9 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
       for (int r = 0; r < 4; r++) {
         const int row = m0 + wm * 64 + i * 16 + MM::row(lane, r);
         const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (row < M && col < Nc) {
+        if (slab) {  // the whole partial tile, row-major 128 x 128, plain stores (gemm_sk_reduce_kernel adds the slabs)
+          slab[(row - m0) * GEMM_T + (col - n0)] = (TO)acc[i][j][r];
+        } else if (row < M && col < Nc) {
           if (atomic)
             unsafeAtomicAdd((double *)&C[(i64)row * ldc + col], (double)acc[i][j][r]);  // TO is double on this path
           else
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // partial last round, and a third of the atomic epilogues (~ (tiles + wpx) per XCD instead of 8 tiles).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_sk_f64(
     const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M,
-    int Nc, i64 K, i64 Kx, int gx, int gy, int sym_row0, int n_real) {
+    int Nc, i64 K, i64 Kx, int gx, int gy, int sym_row0, int n_real, double *__restrict__ ws, int segmax) {
   extern __shared__ double lds128[];
   double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
   double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
@@ -343,6 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const i64 U = (i64)n_real * slabs;
   i64 u = U * w / wpx;
   const i64 u1 = U * (w + 1) / wpx;
+  int seg = 0;
   while (u < u1) {  // uniform
     const int rt = (int)(u / slabs);
     const i64 sb = u - (i64)rt * slabs;
@@ -362,16 +376,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const i64 kbeg = kx0 + sb * GEMM_BK;
     i64 kend = kx0 + se * GEMM_BK;
     if (kend > kx1) kend = kx1;
-    gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs);
+    // ws: the partial tile goes to this workgroup's seg-th slab; the f64 atomic epilogue (all workgroups finish
+    // together: 512 x 16 K atomics at the memory-side rate, ~0.35 ms of a 2 ms contraction) only without workspace
+    double *slab = (ws && seg < segmax) ? ws + ((size_t)blockIdx.x * segmax + seg) * (GEMM_T * GEMM_T) : nullptr;
+    gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs, slab);
     u += se - sb;
+    seg++;
   }
+}
+
+// C += the partial tiles the stream-K kernels left in their workspace: block (rt, part) adds, for 256 elements of the
+// rt-th real tile, the slabs of every workgroup whose run of (tile, K slab) units touched that tile -- the same
+// arithmetic as the kernels' unit split, in a fixed order (XCD, then workgroup): unlike the atomic epilogue the sum
+// is reproducible.
+__global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(const double *__restrict__ ws, int segmax,
+                                                             double *__restrict__ C, int ldc, int M, int Nc, i64 K, i64 Kx,
+                                                             int gx, int gy, int sym_row0, int n_real, int wpx) {
+  const int rt = blockIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;  // element of the tile, row-major
+  int tile = 0, seen = -1;
+  for (int tt = 0; tt < gx * gy; tt++) {
+    const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
+    if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
+    if (++seen == rt) {
+      tile = tt;
+      break;
+    }
+  }
+  const int row = (tile / gx) * GEMM_T + e / GEMM_T, col = (tile % gx) * GEMM_T + e % GEMM_T;
+  double sum = 0.0;
+  for (int xcd = 0; xcd < 8; xcd++) {
+    const i64 kx0 = (i64)xcd * Kx;
+    const i64 kx1 = (kx0 + Kx < K) ? kx0 + Kx : K;
+    if (kx1 <= kx0) break;
+    const i64 slabs = (kx1 - kx0 + GEMM_BK - 1) / GEMM_BK;
+    const i64 U = (i64)n_real * slabs;
+    const i64 a = (i64)rt * slabs, b = a + slabs;  // the units of this tile
+    i64 w = a * wpx / U;                           // about the first workgroup whose run ends behind a
+    while (w > 0 && U * w / wpx > a) w--;
+    while (w < wpx && U * (w + 1) / wpx <= a) w++;
+    for (; w < wpx; w++) {
+      const i64 u0 = U * w / wpx, u1 = U * (w + 1) / wpx;
+      if (u0 >= b) break;
+      if (u1 <= u0) continue;
+      const int seg = rt - (int)(u0 / slabs);
+      if (seg < segmax) sum += ws[((size_t)(xcd + 8 * w) * segmax + seg) * (GEMM_T * GEMM_T) + e];
+    }
+  }
+  if (row < M && col < Nc) C[(i64)row * ldc + col] += sum;
 }
 
 // ---- float32 forms (EBSC float32 mode: data, B = Y W and the Es rows in float, sums in double) --------------------
 // Stream-K contraction of float operands into a double C (atomic epilogue): Wp = Es^T Y.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_sk_f32(
     const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M,
-    int Nc, i64 K, i64 Kx, int gx, int gy, int n_real) {
+    int Nc, i64 K, i64 Kx, int gx, int gy, int n_real, double *__restrict__ ws, int segmax) {
   extern __shared__ double lds128[];
   float(*As)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])lds128;
   float(*Bs)[GEMM_BK][GEMM_LDS2] = (float(*)[GEMM_BK][GEMM_LDS2])((float *)lds128 + 2 * GEMM_BK * GEMM_LDS2);
@@ -383,6 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const i64 U = (i64)n_real * slabs;
   i64 u = U * w / wpx;
   const i64 u1 = U * (w + 1) / wpx;
+  int seg = 0;
   while (u < u1) {  // uniform
     const int tile = (int)(u / slabs);
     const i64 sb = u - (i64)tile * slabs;
@@ -392,8 +452,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const i64 kbeg = kx0 + sb * GEMM_BK;
     i64 kend = kx0 + se * GEMM_BK;
     if (kend > kx1) kend = kx1;
-    gemm_tn128_segment<float, double>(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs);
+    double *slab = (ws && seg < segmax) ? ws + ((size_t)blockIdx.x * segmax + seg) * (GEMM_T * GEMM_T) : nullptr;
+    gemm_tn128_segment<float, double>(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs, slab);
     u += se - sb;
+    seg++;
   }
 }
 
@@ -443,13 +505,13 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
         const int k = k0 + ak + 2 * i;
         // branch-free clamped loads (K and Nc are even in the VEC instantiation)
         const i64 mc = m < M ? m : M - 1;
-        double2 va = *(const double2 *)(A + mc * lda + (k < K ? k : K - 2));
-        if (!(m < M && k < K)) va = make_double2(0.0, 0.0);
+        // (zeroing of what lies outside: in stash(), after the slab's MFMAs -- a select on the loaded value here
+        // would make the wave wait for the load before it starts them)
+        const double2 va = *(const double2 *)(A + mc * lda + (k < K ? k : K - 2));
         ra[2 * i] = va.x;
         ra[2 * i + 1] = va.y;
         const int p = t + 256 * i, kb = k0 + (p >> 5), cc = (p & 31) * 2, nb = n0 + cc;
-        double2 vb = *(const double2 *)(B + (i64)(kb < K ? kb : K - 1) * ldb + (nb < Nc ? nb : Nc - 2));
-        if (!(kb < K && nb < Nc)) vb = make_double2(0.0, 0.0);
+        const double2 vb = *(const double2 *)(B + (i64)(kb < K ? kb : K - 1) * ldb + (nb < Nc ? nb : Nc - 2));
         rb[2 * i] = vb.x;
         rb[2 * i + 1] = vb.y;
       }
@@ -463,23 +525,27 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
       }
     }
   };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) As[buf][ak + q][am] = ra[q];
+  auto stash = [&](int buf, int k0) {
     if (VEC) {
+      const bool min = m0 + am < M;
+#pragma unroll
+      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = (min && k0 + ak + (q & ~1) < K) ? ra[q] : 0.0;
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int p = t + 256 * i, r = p >> 5, cc = (p & 31) * 2;
-        *(double2 *)&Bs[buf][r][cc] = make_double2(rb[2 * i], rb[2 * i + 1]);
+        const bool inb = k0 + r < K && n0 + cc < Nc;
+        *(double2 *)&Bs[buf][r][cc] = inb ? make_double2(rb[2 * i], rb[2 * i + 1]) : make_double2(0.0, 0.0);
       }
     } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = ra[q];
 #pragma unroll
       for (int q = 0; q < 4; q++) Bs[buf][br][bc + q] = rb[q];
     }
   };
   if (K > 0) {
     fetch(0);
-    stash(0);
+    stash(0, 0);
   }
   __syncthreads();
   int buf = 0;
@@ -500,7 +566,7 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
         for (int j = 0; j < 2; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
+    if (more) stash(buf ^ 1, k0 + GEMM_BK);
     __syncthreads();
   }
 #pragma unroll
