@@ -236,7 +236,11 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[i][j][r] = (T)0;
   // loader: the 16 x PPR grid of 16-byte pieces of a slab (16 rows x 128 columns), pieces p = t + 256 i
-  piece_t ra[2][NP], rb[2][NP];  // two slabs ahead (a slab is 4096 matrix-core cycles per wave in f64)
+  // one slab ahead in registers (the slab after the one in the other LDS buffer): fetched at the end of iteration
+  // s - 1, stashed at the end of iteration s, i.e. a whole slab of MFMAs (4096 matrix-core cycles per wave in f64,
+  // twice that in wall time at two waves per SIMD) later -- more than a loaded memory round trip.  (Two slabs ahead
+  // cost 32 more registers; they now hold the second set of LDS fragments, see compute().)
+  piece_t ra[NP], rb[NP];
   auto fetch = [&](piece_t(&qa)[NP], piece_t(&qb)[NP], i64 k0) {
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -261,19 +265,25 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
       *(piece_t *)&Bs[buf][r][cc] = (kin && n0 + cc < Nc) ? qb[i] : MM::zero();
     }
   };
+  // fragments of K step kk + 1 are read while the 16 MFMAs of step kk run (two register sets): read at the top of
+  // their own step, every step began with an exposed LDS round trip
+  auto frags = [&](int buf, int kk, T(&a)[4], T(&b)[4]) {
+    const int kl = kk * 4 + (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = As[buf][kl][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[j] = Bs[buf][kl][wn * 64 + j * 16 + (lane & 15)];
+  };
   auto compute = [&](int buf) {
+    T a[2][4], b[2][4];
+    frags(buf, 0, a[0], b[0]);
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
-      const int kl = kk * 4 + (lane >> 4);
-      T a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[buf][kl][wm * 64 + i * 16 + (lane & 15)];
-#pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[buf][kl][wn * 64 + j * 16 + (lane & 15)];
+      if (kk + 1 < GEMM_BK / 4) frags(buf, kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = MM::mma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; j++) acc[i][j] = MM::mma(a[kk & 1][i], b[kk & 1][j], acc[i][j]);
     }
   };
   // The slab loop is branch-free: an odd slab count is padded with an all-zero slab (stash() zeroes rows >= kend),
@@ -283,10 +293,9 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
   i64 nslab = (kend > kbeg) ? (kend - kbeg + GEMM_BK - 1) / GEMM_BK : 0;
   nslab = (nslab + 1) & ~(i64)1;
   if (nslab > 0) {
-    fetch(ra[0], rb[0], kbeg);
-    stash(ra[0], rb[0], 0, kbeg);
-    fetch(ra[0], rb[0], kbeg + GEMM_BK);
-    fetch(ra[1], rb[1], kbeg + 2 * GEMM_BK);
+    fetch(ra, rb, kbeg);
+    stash(ra, rb, 0, kbeg);
+    fetch(ra, rb, kbeg + GEMM_BK);
   }
   __syncthreads();
   for (i64 s0 = 0; s0 < nslab; s0 += 2) {
@@ -294,8 +303,8 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
     for (int j = 0; j < 2; j++) {
       const i64 sl = s0 + j;
       compute(j);
-      stash(ra[j], rb[j], j ^ 1, kbeg + (sl + 1) * GEMM_BK);
-      fetch(ra[j], rb[j], kbeg + (sl + 3) * GEMM_BK);
+      stash(ra, rb, j ^ 1, kbeg + (sl + 1) * GEMM_BK);
+      fetch(ra, rb, kbeg + (sl + 2) * GEMM_BK);
       __syncthreads();
     }
   }
@@ -392,37 +401,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(const double *__restrict__ ws, int segmax,
                                                              double *__restrict__ C, int ldc, int M, int Nc, i64 K, i64 Kx,
                                                              int gx, int gy, int sym_row0, int n_real, int wpx) {
+  // which slabs hold a part of tile rt: worked out once per block by thread xcd (64-bit divisions); up to
+  // wpx / n_real + 2 workgroups per XCD touch a tile; slab number = (xcd + 8 w) segmax + seg
+  constexpr int MAXW = 72;
+  __shared__ int slab_of[8][MAXW];
+  __shared__ int slab_n[8];
+  __shared__ int tile_sh;
   const int rt = blockIdx.x;
   const int e = blockIdx.y * 256 + threadIdx.x;  // element of the tile, row-major
-  int tile = 0, seen = -1;
-  for (int tt = 0; tt < gx * gy; tt++) {
-    const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
-    if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
-    if (++seen == rt) {
-      tile = tt;
-      break;
-    }
-  }
-  const int row = (tile / gx) * GEMM_T + e / GEMM_T, col = (tile % gx) * GEMM_T + e % GEMM_T;
-  double sum = 0.0;
-  for (int xcd = 0; xcd < 8; xcd++) {
+  if (threadIdx.x < 8) {
+    const int xcd = threadIdx.x;
+    int q = 0;
     const i64 kx0 = (i64)xcd * Kx;
     const i64 kx1 = (kx0 + Kx < K) ? kx0 + Kx : K;
-    if (kx1 <= kx0) break;
-    const i64 slabs = (kx1 - kx0 + GEMM_BK - 1) / GEMM_BK;
-    const i64 U = (i64)n_real * slabs;
-    const i64 a = (i64)rt * slabs, b = a + slabs;  // the units of this tile
-    i64 w = a * wpx / U;                           // about the first workgroup whose run ends behind a
-    while (w > 0 && U * w / wpx > a) w--;
-    while (w < wpx && U * (w + 1) / wpx <= a) w++;
-    for (; w < wpx; w++) {
-      const i64 u0 = U * w / wpx, u1 = U * (w + 1) / wpx;
-      if (u0 >= b) break;
-      if (u1 <= u0) continue;
-      const int seg = rt - (int)(u0 / slabs);
-      if (seg < segmax) sum += ws[((size_t)(xcd + 8 * w) * segmax + seg) * (GEMM_T * GEMM_T) + e];
+    if (kx1 > kx0) {
+      const i64 slabs = (kx1 - kx0 + GEMM_BK - 1) / GEMM_BK;
+      const i64 U = (i64)n_real * slabs;
+      const i64 a = (i64)rt * slabs, b = a + slabs;  // the units of this tile
+      i64 w = a * wpx / U;                           // about the first workgroup whose run ends behind a
+      while (w > 0 && U * w / wpx > a) w--;
+      while (w < wpx && U * (w + 1) / wpx <= a) w++;
+      for (; w < wpx && q < MAXW; w++) {
+        const i64 u0 = U * w / wpx, u1 = U * (w + 1) / wpx;
+        if (u0 >= b) break;
+        if (u1 <= u0) continue;
+        const int seg = rt - (int)(u0 / slabs);
+        if (seg < segmax) slab_of[xcd][q++] = (int)((xcd + 8 * w) * segmax + seg);
+      }
     }
+    slab_n[xcd] = q;
+  } else if (threadIdx.x == 64) {
+    int tile = 0, seen = -1;
+    for (int tt = 0; tt < gx * gy; tt++) {
+      const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
+      if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
+      if (++seen == rt) {
+        tile = tt;
+        break;
+      }
+    }
+    tile_sh = tile;
   }
+  __syncthreads();
+  const int tile = tile_sh;
+  const int row = (tile / gx) * GEMM_T + e / GEMM_T, col = (tile % gx) * GEMM_T + e % GEMM_T;
+  double sum = 0.0;
+  for (int xcd = 0; xcd < 8; xcd++)
+    for (int q = 0; q < slab_n[xcd]; q++) sum += ws[(size_t)slab_of[xcd][q] * (GEMM_T * GEMM_T) + e];  // uniform bounds
   if (row < M && col < Nc) C[(i64)row * ldc + col] += sum;
 }
 
