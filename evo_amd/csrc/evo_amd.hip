@@ -186,6 +186,9 @@ struct evoamd_ctx {
   bool f32_opt = false, f32 = false;
   float *Yf = nullptr, *Ytf = nullptr, *Wf = nullptr, *Bf = nullptr, *Esf = nullptr;
   i64 ldYt = 0;
+  // double precision: Y^T (D, ldYt) for B = Y W on the 128-tile kernel (large N; option "b_transposed", default 1)
+  double *Yt = nullptr;
+  int b_tn_opt = 1;
   uint8_t *mask_infr = nullptr, *mask_x = nullptr;  // EBSC incomplete data: reliable entries / entries that keep their value
   double *Yrec = nullptr;       // y_reconstructed (N x D): what the M-step's Wp contraction reads then
   bool yrec_valid = false, rec_in_stats = false;
@@ -416,6 +419,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
+  HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_rows_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)GEMM128_LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_sk_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_sk_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -444,7 +449,7 @@ static void free_all(evoamd_ctx *c) {
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
-                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
+                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -523,6 +528,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_streamk") == 0) {
     c->gemm_streamk = value;
+    return 0;
+  }
+  if (strcmp(name, "b_transposed") == 0) {  // takes effect at the next evoamd_configure
+    c->b_tn_opt = value;
     return 0;
   }
   if (strcmp(name, "gemm_workspace") == 0) {
@@ -668,7 +677,14 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     if (*fp) (void)hipFree(*fp);
     *fp = nullptr;
   }
+  if (c->Yt) (void)hipFree(c->Yt);
+  c->Yt = nullptr;
   c->f32 = model == EVOAMD_MODEL_BSC && c->f32_opt;
+  if (!c->f32 && c->b_tn_opt && N >= 8192 && H >= 128 && D >= 32 && (H % 2) == 0) {
+    c->ldYt = ((N + 3) / 4) * 4;
+    ALLOC(c->Yt, (size_t)D * c->ldYt);
+    HIP_TRY(hipMemsetAsync(c->Yt, 0, (size_t)D * c->ldYt * sizeof(double), c->stream));
+  }
   if (c->f32) REQUIRE((H % 4) == 0 && (D % 4) == 0, "float32 mode needs H and D to be multiples of 4 (16-byte rows)");
   if (model == EVOAMD_MODEL_BSC) {
     ALLOC(c->Wt, (size_t)H * D);
@@ -779,6 +795,8 @@ extern "C" int evoamd_upload_data(evoamd_ctx *c, const double *Y) {
   {
     launch_colsum<true>(c, c->Y, c->ldY, c->N, c->D, c->y2sum);
   }
+  if (c->Yt)
+    transpose_to_f64_kernel<<<dim3(cdiv(c->N, 32), cdiv(c->D, 32)), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->Yt, c->ldYt);
   if (c->f32) {  // float copies for the two long contractions: Y (N,D) and Y^T (D,N)
     to_f32_kernel<<<cdiv(c->N * (i64)c->D, 256), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->Yf, c->D);
     transpose_to_f32_kernel<<<dim3(cdiv(c->N, 32), cdiv(c->D, 32)), 256, 0, c->stream>>>(c->Y, c->ldY, c->N, c->D, c->Ytf,
@@ -1100,6 +1118,18 @@ static int launch_gemm_nn(evoamd_ctx *c, const double *A, int lda, const double 
 // ---------------------------------------------------------------------------------------
 static int launch_B_f32(evoamd_ctx *c);
 
+// B = Y W (N x H): float32 mode, or from Y^T on the 128-tile kernel (large N), or the 64-tile row-major product
+static int launch_B(evoamd_ctx *c) {
+  if (c->f32) return launch_B_f32(c);
+  if (!c->Yt) return launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
+  SpanGuard g(c, KID_GEMM);
+  const int gx = (int)cdiv(c->H, GEMM_T), gy = (int)cdiv(c->N, GEMM_T);
+  gemm_tn128_rows_f64<<<(unsigned)(8 * cdiv(gy, 8) * gx), 256, GEMM128_LDS_BYTES, c->stream>>>(
+      c->Yt, (int)c->ldYt, c->W, c->H, c->Bm, c->H, (int)c->N, c->H, c->D, gx, gy);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, double sigma, double *ljc) {
   REQUIRE(c && c->configured && c->model == EVOAMD_MODEL_BSC, "context is not configured for BSC");
   REQUIRE(W, "W is NULL");
@@ -1130,7 +1160,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
     int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D);  // G = W^T W
     if (r) return r;
     if (c->have_data) {
-      r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);  // B = Y W
+      r = launch_B(c);  // B = Y W
       if (r) return r;
       c->B_valid = true;
     }
@@ -1203,7 +1233,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   HIP_TRY(hipGetLastError());
   c->B_valid = false;
   if (c->have_data) {
-    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);  // B = Y W
+    r = launch_B(c);  // B = Y W
     if (r) return r;
     c->B_valid = true;
   }
@@ -1256,7 +1286,7 @@ static int launch_B_f32(evoamd_ctx *c) {
 // B = Y W depends on both the data and Theta; recompute it if either arrived later.
 static int ensure_B(evoamd_ctx *c) {
   if (c->B_valid || (c->model == EVOAMD_MODEL_BSC && c->bsc_direct)) return 0;
-  int r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, c->H, c->Bm, c->H, c->N, c->H, c->D);
+  int r = launch_B(c);
   if (r) return r;
   DBG_SYNC(c, "B = Y W");
   c->B_valid = true;
@@ -2460,13 +2490,13 @@ static int refresh_after_update(evoamd_ctx *c) {
     sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
                                                                      c->PT, c->GP, c->DG);
     HIP_TRY(hipGetLastError());
-    r = launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    r = launch_B(c);
     if (r) return r;
     c->B_valid = true;
   } else if (!c->bsc_direct) {
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
     if (r) return r;
-    r = c->f32 ? launch_B_f32(c) : launch_gemm_nn(c, c->Y, c->ldY, c->W, H, c->Bm, H, c->N, H, D);
+    r = launch_B(c);
     if (r) return r;
     c->B_valid = true;
   }

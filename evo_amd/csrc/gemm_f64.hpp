@@ -451,6 +451,21 @@ __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(const double *__res
   if (row < M && col < Nc) C[(i64)row * ldc + col] += sum;
 }
 
+// C (M x Nc) = A^T B with the whole (short) K per tile and plain stores: B = Y W as (Y^T)^T W from the transposed copy of
+// the data, M = N datapoints.  XCD x owns the row tiles x, x + 8, ...: the column tiles of a row tile run on the same
+// XCD back to back, so the 128 columns of Y^T they share are fetched into one L2.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_rows_f64(
+    const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M,
+    int Nc, i64 K, int gx, int gy) {
+  extern __shared__ double lds128[];
+  double(*As)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])lds128;
+  double(*Bs)[GEMM_BK][GEMM_LDS2] = (double(*)[GEMM_BK][GEMM_LDS2])(lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int ty = xcd + 8 * (j / gx), tx = j % gx;
+  if (ty >= gy) return;  // uniform
+  gemm_tn128_segment(A, lda, B, ldb, C, ldc, M, Nc, ty * GEMM_T, tx * GEMM_T, 0, K, false, As, Bs);
+}
+
 // ---- float32 forms (EBSC float32 mode: data, B = Y W and the Es rows in float, sums in double) --------------------
 // Stream-K contraction of float operands into a double C (atomic epilogue): Wp = Es^T Y.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_sk_f32(

@@ -251,6 +251,18 @@ __global__ __launch_bounds__(256) void transpose_to_f32_kernel(const double *__r
   for (int j = ty; j < 32; j += 8)
     if (c0 + j < C && r0 + tx < R) dst[(i64)(c0 + j) * ldd + r0 + tx] = tile[tx][j];
 }
+// the same in double: Y^T for the B = Y W product (gemm_tn128_rows_f64)
+__global__ __launch_bounds__(256) void transpose_to_f64_kernel(const double *__restrict__ src, int lds_, i64 R, int C,
+                                                               double *__restrict__ dst, i64 ldd) {
+  __shared__ double tile[32][33];
+  const i64 r0 = (i64)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) tile[j][tx] = (r0 + j < R && c0 + tx < C) ? src[(r0 + j) * lds_ + c0 + tx] : 0.0;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < C && r0 + tx < R) dst[(i64)(c0 + j) * ldd + r0 + tx] = tile[tx][j];
+}
 // Small shapes of the float32 mode (the 128-tile kernels need outputs >= 256 wide): one thread per output element.
 // C (M x Nc double) = A^T B, A (K x M float), B (K x Nc float), double accumulation.
 __global__ __launch_bounds__(256) void gemm_tn_naive_f32(const float *__restrict__ A, int lda, const float *__restrict__ B,
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
   if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
     clear_lists_checked(list_n, n_list, skipped_mask, err);
   __shared__ double wsum[4];
-  __shared__ double new_v[4][64 * CPL], old_v[4][64 * CPL];
+  __shared__ double new_v[4][64 * CPL];
   __shared__ int new_i[4][64 * CPL], old_i[4][64 * CPL];
   const int lane = lane_id(), wave = wave_id_uniform();
   const i64 n = (i64)blockIdx.x * 4 + wave;
@@ -581,9 +593,23 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
           }
         }
       }
-      // the M worst old states in ascending order (ties: lower index first).  M <= Cmax is small,
-      // so M rounds of a wave-wide arg-min replace the full O(S^2 / 64) ranking of all S states
-      // (S = 256: ~4000 instructions per wave, most of this kernel's time at c5).
+      // rank-j owners publish (value, index)
+#pragma unroll
+      for (int q = 0; q < CPL; q++) {
+        const int c = lane + 64 * q;
+        if (c < cnt && keep[q] && nrank[q] < M) {
+          new_v[wave][nrank[q]] = nv[q];
+          new_i[wave][nrank[q]] = c;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      // The worst old states in ascending order (ties: lower index first), one wave-wide arg-min per round, and only
+      // while they are needed: swap j happens iff the j-th best candidate beats the j-th worst old state, the
+      // candidates descend and the old states ascend, so the accepted swaps are a prefix and the first failure ends
+      // the search (typically after 3-4 of the M = 10 rounds; a full O(S^2 / 64) ranking of all S states was ~4000
+      // instructions per wave at S = 256, M rounds of this were still 40 % of the kernel).
+      int g = 0;
       {
         double ow[SPL];
 #pragma unroll
@@ -596,46 +622,22 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
 #pragma unroll
           for (int q = 1; q < SPL; q++) lm = fmin(lm, ow[q]);
           const double gm = wave_min(lm);
+          if (!(new_v[wave][j] > gm)) break;  // uniform (LDS broadcast): the accepted prefix ends here
           unsigned gi = 0xFFFFFFFFu;
 #pragma unroll
           for (int q = 0; q < SPL; q++) {
             const u64 hit = __ballot(ow[q] == gm);
             if (gi == 0xFFFFFFFFu && hit != 0ull) gi = (unsigned)(64 * q + __ffsll((long long)hit) - 1);
           }
-          if (lane == 0) {
-            old_v[wave][j] = gm;
-            old_i[wave][j] = (int)gi;
-          }
+          if (lane == 0) old_i[wave][j] = (int)gi;
 #pragma unroll
           for (int q = 0; q < SPL; q++)
             if ((unsigned)(lane + 64 * q) == gi) ow[q] = INFINITY;
-        }
-      }
-      // rank-j owners publish (value, index)
-#pragma unroll
-      for (int q = 0; q < CPL; q++) {
-        const int c = lane + 64 * q;
-        if (c < cnt && keep[q] && nrank[q] < M) {
-          new_v[wave][nrank[q]] = nv[q];
-          new_i[wave][nrank[q]] = c;
+          g++;
         }
       }
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
-      // accepted prefix: j-th best candidate strictly better than j-th worst old state
-      int g = 0;
-      bool open = true;
-#pragma unroll
-      for (int q = 0; q < CPL; q++) {
-        const int j = lane + 64 * q;
-        const bool ok = (j < M) && (new_v[wave][j < M ? j : 0] > old_v[wave][j < M ? j : 0]);
-        const u64 m = __ballot(ok);
-        if (open) {
-          const int run = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
-          g += run;
-          if (run < 64) open = false;
-        }
-      }
       n_sub = g;
       // swap j: candidate new_i[j] -> slot old_i[j]
 #pragma unroll

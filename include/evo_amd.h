@@ -97,6 +97,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * in LDS when two workgroups per CU still fit.  "stats_waves" (0 / 8 / 16, measurement aid): waves per workgroup of the
  * ES3C statistics kernel (0 = 4).  "gemm_streamk" (0/1, default 1): the long-K 128-tile contraction runs as ONE resident-sized grid -- every XCD owns an eighth
  * of K, its workgroups cut the (tile, K slab) units of that range into equal runs -- instead of tiles x 64 K chunks.
+ * "b_transposed" (0/1, default 1; read by the next evoamd_configure): from N = 8192 datapoints on the context keeps Y^T as well
+ * and computes B = Y W with the 128 x 128 tile kernel; 0: the row-major 64 x 64 tile product.
  * "gemm_workspace" (0/1, default 1): the stream-K workgroups store their partial tiles to a workspace and a second kernel
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
