@@ -154,6 +154,7 @@ struct evoamd_ctx {
   int stats_stage = 1;  // option "stats_stage" (measurement): 0 = no LDS staging of B rows / singleton table
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
+  int bins_min = 256;  // option "pair_bins_min": pair bins from this many resident states (x 1024) on
   int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
   double *gemm_ws = nullptr;  // partial tiles of the stream-K contractions (gemm_sk_reduce_kernel adds them to C)
   size_t gemm_ws_n = 0;
@@ -532,6 +533,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "b_transposed") == 0) {  // takes effect at the next evoamd_configure
     c->b_tn_opt = value;
+    return 0;
+  }
+  if (strcmp(name, "pair_bins_min") == 0) {
+    c->bins_min = value;
     return 0;
   }
   if (strcmp(name, "gemm_workspace") == 0) {
@@ -2095,11 +2100,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const ListOut none_out = {nullptr, nullptr, 0};
   const double *Ywp = c->Y;  // EBSC: what the Wp contraction reads
   int ldwp = c->ldY;
-  // ES3C pair bins (decided once per pass): they pay when the tiles' fixed cost is a small part of the contributions
-  // they absorb
+  // ES3C pair bins (decided once per pass): they pay when the fixed cost of the reduce pass (zero + store nb x PB_NSH
+  // tiles, ~20 us) is less than the global atomics they absorb -- from ~256k resident states on (N = 12.5k x S = 200:
+  // statistics pass 0.63 -> 0.40 ms)
   PairBins pb = {};
   if (c->model == EVOAMD_MODEL_SSSC && !masked && c->pbins.ent &&
-      (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S / 2 >= 6 * (i64)c->pbins.nb * PB_NSH * (PB_TILE / 2))))
+      (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S >= (i64)c->bins_min * 1024)))
     pb = c->pbins;
 
   for (int ci = 0; ci < nchunks; ci++) {
@@ -2237,7 +2243,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         bool merged23 = false;
         if (need[0])
           sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2, pb);
-        if (use_k8_kernel(c, tg)) {
+        // (statistics mode of the K = 8 register kernel: 256 registers + 736 bytes of scratch per lane, one wave per
+        // SIMD -- measured slower than the wavefront kernel at every size seen: 187 vs ~110 us at 5k states, 0.32
+        // vs 0.25 ms for the pass's levels at the north-star shape; only when forced by option "sssc_k8" = 1)
+        if (c->k8_mode == 1) {
           if (need[1])
             sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3, pb);
         } else if (need[1] && few_dense_states(c, tg)) {

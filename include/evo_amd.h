@@ -99,6 +99,7 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * of K, its workgroups cut the (tile, K slab) units of that range into equal runs -- instead of tiles x 64 K chunks.
  * "b_transposed" (0/1, default 1; read by the next evoamd_configure): from N = 8192 datapoints on the context keeps Y^T as well
  * and computes B = Y W with the 128 x 128 tile kernel; 0: the row-major 64 x 64 tile product.
+ * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
  * "gemm_workspace" (0/1, default 1): the stream-K workgroups store their partial tiles to a workspace and a second kernel
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
