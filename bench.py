@@ -526,6 +526,8 @@ def main():
         r_lpj = roof(lpj_ms, lpj_n, pass_kernels(cfg), "whole pass over the resident K^n: lpj of all N x S states "
                      "(main kernel + every overflow level it spawns), one HIP-event span per pass")
         r_lpj["states_in_main_kernel"] = (1.0 - n_gt2 / (float(n_loc) * cfg["S"])) if n_gt2 == n_gt2 else None
+        ld = getattr(model, "last_dpar", {})
+        r_lpj["overflow_census"] = {k: ld.get(k) for k in ("n_gt2", "n_gt4", "n_gt8") if k in ld}
         r_lpj["layout_bytes_per_launch"] = lay_bytes
         r_lpj["frac_of_layout_bytes"] = (lay_bytes / (lpj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpj_ms > 0 else 0.0
         r_lpj["layout_note"] = ("`achieved` / `frac` price SURVEY 8d's algorithmic bytes (bit-packed states + y_n); the kernels "
