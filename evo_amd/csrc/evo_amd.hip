@@ -155,6 +155,7 @@ struct evoamd_ctx {
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
   int bins_min = 256;  // option "pair_bins_min": pair bins from this many resident states (x 1024) on
+  int bsc_wave_opt = 1;  // option "bsc_stats_wave": EBSC statistics on the wave-per-datapoint kernel (0: round-1 kernel)
   int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
   double *gemm_ws = nullptr;  // partial tiles of the stream-K contractions (gemm_sk_reduce_kernel adds them to C)
   size_t gemm_ws_n = 0;
@@ -539,6 +540,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->bins_min = value;
     return 0;
   }
+  if (strcmp(name, "bsc_stats_wave") == 0) {
+    c->bsc_wave_opt = value;
+    return 0;
+  }
   if (strcmp(name, "gemm_workspace") == 0) {
     c->gemm_ws_opt = value;
     return 0;
@@ -671,7 +676,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->acc_n = acc_len(c);
   // in front of the packed accumulator, cleared by the same memset: [overflow census (4) | CS_SLICES column-sum
   // slices of 3 H | overflow H x H pair] (ES3C)
-  c->pre_n = (model == EVOAMD_MODEL_SSSC) ? 4 + (i64)CS_SLICES * 3 * H : 4;
+  c->pre_n = (model == EVOAMD_MODEL_SSSC) ? 4 + (i64)CS_SLICES * 3 * H : 4 + (i64)BSC_CS_SLICES * H;
   c->ovf_n = c->pre_n + ((model == EVOAMD_MODEL_SSSC) ? 2 * (i64)H * H : 0);
   ALLOC(c->acc_base, (size_t)c->ovf_n + c->acc_n + DP_COUNT);  // [... |] packed accumulator, then the scalar block (one D2H)
   c->census = c->acc_base;
@@ -719,6 +724,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     int rl = ensure_lists(c, (i64)N * SC);
     if (rl) return rl;
     ALLOC(c->list_n, 4 * LIST_SHARDS);
+  }
+  {
     // pair bins of the statistics pass: 2 rf folded rows x H columns per LDS tile
     if (c->pbins.ent) (void)hipFree(c->pbins.ent);
     if (c->pbins.gcnt) (void)hipFree(c->pbins.gcnt);
@@ -2108,41 +2115,80 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S >= (i64)c->bins_min * 1024)))
     pb = c->pbins;
 
+  bool bsc_wave = false;
+  int bsc_grid = 0;
+  PairBins bsc_pb = {};
   for (int ci = 0; ci < nchunks; ci++) {
     const i64 n0 = (i64)ci * rows_per_chunk;
     const i64 nc = std::min<i64>(rows_per_chunk, N - n0);
     const int blk0 = (int)(n0 / rpb), nblk_c = (int)cdiv(nc, rpb);
     c->grid_scale = (double)nc / (double)N;
     if (c->model == EVOAMD_MODEL_BSC) {
+      // wave-per-datapoint kernel with prefetch, pair bins and in-kernel column sums where it applies (digests, S <= 256,
+      // one block); else the round-1 kernel + column-sum pass
+      const u64 *bdig = dig_for(c, c->states);
+      const int SRb = (int)cdiv(c->S, 64);
+      bsc_wave = c->bsc_wave_opt && bdig && (SRb == 1 || SRb == 2 || SRb == 4 || SRb == 3) && nchunks == 1 &&
+                 (size_t)5 * H * sizeof(double) <= 150 * 1024;
+      if (bsc_wave) {
+        SpanGuard g(c, KID_STATS);
+        const size_t ldsb = (size_t)5 * H * sizeof(double);
+        int per_cu = (int)((160 * 1024) / (ldsb + 2048));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        bsc_pb = PairBins{};
+        if (c->pbins.ent && (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S >= (i64)c->bins_min * 1024))) bsc_pb = c->pbins;
+        int sgrid = (int)std::min<i64>(cdiv(nc, 4), (i64)c->n_cu * per_cu * 2);
+        if (sgrid > 2048) sgrid = 2048;  // pb.nwg, and the size of the sigma partials
+        bsc_grid = sgrid;
+        void *EsP = c->f32 ? (void *)c->Esf : (void *)c->Es;
+        double *csb = c->acc_base + 4;
+#define BSC_WAVE(SR)                                                                                                      \
+  bsc_stats_wave_kernel<SR><<<sgrid, 256, ldsb, c->stream>>>(c->states, c->lpj, c->rowmax, c->rowsum, c->yy, nc, c->S,     \
+                                                            c->S_perm, H, c->HW, c->dpar, EsP, c->acc + a.Wq, c->partial2, \
+                                                            bdig, c->f32 ? 1 : 0, bsc_pb, csb)
+        if (SRb == 1) BSC_WAVE(1);
+        else if (SRb == 2) BSC_WAVE(2);
+        else BSC_WAVE(4);
+#undef BSC_WAVE
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "bsc stats (wave)");
+        if (bsc_pb.ent) {
+          pair_bins_reduce_kernel<<<bsc_pb.nb * PB_NSH, PB_RTHREADS, (size_t)3 * 2 * bsc_pb.rf * H * sizeof(double), c->stream>>>(
+              bsc_pb, H, 0);
+          HIP_TRY(hipGetLastError());
+        }
+      } else {
       {
         SpanGuard g(c, KID_STATS);
-#define BSC_STATS(HWT)                                                                                              \
-  bsc_stats_kernel<HWT><<<cdiv(nc, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                           \
-      c->states + (size_t)n0 * c->S * c->HW, c->lpj + (size_t)n0 * c->L, c->rowmax + n0, c->rowsum + n0, c->yy + n0, nc, \
-      c->S, c->S_perm, H, c->HW, c->dpar,                                                                           \
-      c->f32 ? (void *)(c->Esf + (size_t)n0 * H) : (void *)(c->Es + (size_t)n0 * H), c->acc + a.Wq, c->partial2 + n0 / 4, \
-      dig_for(c, c->states) ? dig_for(c, c->states) + (size_t)n0 * c->S : nullptr, c->f32 ? 1 : 0)
-        switch (c->HW) {
-          case 1: BSC_STATS(1); break;
-          case 2: BSC_STATS(2); break;
-          case 4: BSC_STATS(4); break;
-          case 8: BSC_STATS(8); break;
-          case 16: BSC_STATS(16); break;
-          default: BSC_STATS(0); break;
+  #define BSC_STATS(HWT)                                                                                              \
+    bsc_stats_kernel<HWT><<<cdiv(nc, 4), 256, (size_t)4 * H * sizeof(double), c->stream>>>(                           \
+        c->states + (size_t)n0 * c->S * c->HW, c->lpj + (size_t)n0 * c->L, c->rowmax + n0, c->rowsum + n0, c->yy + n0, nc, \
+        c->S, c->S_perm, H, c->HW, c->dpar,                                                                           \
+        c->f32 ? (void *)(c->Esf + (size_t)n0 * H) : (void *)(c->Es + (size_t)n0 * H), c->acc + a.Wq, c->partial2 + n0 / 4, \
+        dig_for(c, c->states) ? dig_for(c, c->states) + (size_t)n0 * c->S : nullptr, c->f32 ? 1 : 0)
+          switch (c->HW) {
+            case 1: BSC_STATS(1); break;
+            case 2: BSC_STATS(2); break;
+            case 4: BSC_STATS(4); break;
+            case 8: BSC_STATS(8); break;
+            case 16: BSC_STATS(16); break;
+            default: BSC_STATS(0); break;
+          }
+  #undef BSC_STATS
+          HIP_TRY(hipGetLastError());
+          DBG_SYNC(c, "bsc stats");
         }
-#undef BSC_STATS
-        HIP_TRY(hipGetLastError());
-        DBG_SYNC(c, "bsc stats");
-      }
-      {
-        SpanGuard g(c, KID_MISC);
-        if (c->f32)
-          colsum_partial_f32_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Esf + (size_t)n0 * H, H, nc, H, rpb,
-                                                                                      c->colpart + (size_t)blk0 * H);
-        else
-          colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Es + (size_t)n0 * H, H, nc, H, rpb,
-                                                                                  c->colpart + (size_t)blk0 * H);
-        HIP_TRY(hipGetLastError());
+        {
+          SpanGuard g(c, KID_MISC);
+          if (c->f32)
+            colsum_partial_f32_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Esf + (size_t)n0 * H, H, nc, H, rpb,
+                                                                                        c->colpart + (size_t)blk0 * H);
+          else
+            colsum_partial_kernel<<<dim3(cdiv(H, 64), nblk_c), 256, 0, c->stream>>>(c->Es + (size_t)n0 * H, H, nc, H, rpb,
+                                                                                    c->colpart + (size_t)blk0 * H);
+          HIP_TRY(hipGetLastError());
+        }
       }
       if (masked) {  // incomplete data: the Wp contraction reads y_reconstructed (bsc.py:184-189,211); one block only
         if (c->rec_in_stats) {
@@ -2278,8 +2324,13 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       {
         SpanGuard g(c, KID_MISC);
         if (c->model == EVOAMD_MODEL_BSC) {
-          bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
-                                                                           c->partial2, cdiv(N, 4), c->acc + a.sigma);
+          if (bsc_wave)
+            bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->acc_base + 4,
+                                                                             BSC_CS_SLICES, H, c->partial2, bsc_grid,
+                                                                             c->acc + a.sigma, bsc_pb);
+          else
+            bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
+                                                                             c->partial2, cdiv(N, 4), c->acc + a.sigma, PairBins{});
         } else {
           const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
           // complete data: the kernels left the column sums in CS_SLICES slices; else per-block partials of the rows

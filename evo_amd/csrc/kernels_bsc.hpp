@@ -3,6 +3,7 @@
 #pragma once
 #include "common.hpp"
 #include "kernels_mstep.hpp"
+#include "pair_bins.hpp"
 
 #define BSC_CHUNK 8  // states handled by one wavefront before it moves on (y_n stays in registers)
 
@@ -530,12 +531,157 @@ __global__ __launch_bounds__(256) void bsc_stats_kernel(
   if (threadIdx.x == 0) sig_partial[blockIdx.x] = ((wsig[0] + wsig[1]) + wsig[2]) + wsig[3];
 }
 
+// The same sums with the structure of the ES3C statistics kernel (kernels_sssc.hpp: sssc_stats_wave_kernel):
+// persistent workgroups of four waves, a wave per datapoint at a time,
+//   * the next datapoint's digests, lpj values and row statistics are loaded into registers while the current one is
+//     processed (SR = ceil(S / 64) rounds of 64 states, every prefetch load unconditional);
+//   * Wq pairs through the pair bins (pair_bins.hpp; plain 32-byte appends to private regions, no global atomic) --
+//     the one-atomic-per-pair form above runs at the memory-side atomic rate, 15 M pairs = 0.65 ms at c5;
+//   * no column-sum kernel: a wave adds the row it writes out to workgroup column sums in LDS, which reach CS_SLICES
+//     slices with H atomics per WORKGROUP at the end (bsc_finish_kernel adds the slices).
+// Needs the digests (k <= DIG_SLOTS from the digest; denser states walk their words and use global atomics).
+// Dynamic LDS: (4 + 1) x H doubles.  sig_partial: one partial per workgroup.
+#define BSC_CS_SLICES 16
+template <int SR>
+__global__ __launch_bounds__(256) void bsc_stats_wave_kernel(
+    const u64 *__restrict__ states, const double *__restrict__ lpj, const double *__restrict__ rowmax,
+    const double *__restrict__ rowsum, const double *__restrict__ yy, i64 N, int S, int S_perm, int H, int HW,
+    const double *__restrict__ dpar, void *__restrict__ Es_, double *__restrict__ Wq, double *__restrict__ sig_partial,
+    const u64 *__restrict__ dig, int es_f32, PairBins pb, double *__restrict__ cs) {
+  extern __shared__ double es_lds[];  // 4 waves x H rows, then H column sums
+  __shared__ int bcnt[PB_MAX_BINS];
+  __shared__ double wsig[4];
+  const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  double *es = es_lds + (size_t)wave * H, *acc = es_lds + (size_t)4 * H;
+  const bool binned = pb.ent != nullptr;
+  for (int i = threadIdx.x; i < H; i += 256) acc[i] = 0.0;
+  if (binned)
+    for (int i = threadIdx.x; i < pb.nb; i += 256) bcnt[i] = 0;
+  __syncthreads();
+  const int L = S + S_perm;
+  struct Pre {
+    double rmax, rsum, yyn, perm, l[SR];
+    u64 d[SR];
+  };
+  auto issue = [&](i64 nn, Pre &p) {
+    p.rmax = rowmax[nn];
+    p.rsum = rowsum[nn];
+    p.yyn = yy[nn];
+    const double *row = lpj + nn * L;
+    p.perm = row[0];  // the permanent state's lpj when S_perm = 1 (else unused)
+    const u64 *dgn = dig + nn * (i64)S;
+#pragma unroll
+    for (int u = 0; u < SR; u++) {
+      const int sidx = 64 * u + lane, sc = sidx < S ? sidx : 0;
+      p.d[u] = dgn[sc];
+      p.l[u] = row[S_perm + sc];
+    }
+  };
+  const i64 n_first = (i64)blockIdx.x * 4 + wave, n_stride = (i64)gridDim.x * 4;
+  Pre cur = {};
+  if (n_first < N) issue(n_first, cur);
+  double sigw = 0.0;
+  for (i64 n = n_first; n < N; n += n_stride) {
+    const i64 n_next = n + n_stride < N ? n + n_stride : n;
+    for (int h = lane; h < H; h += 64) es[h] = 0.0;
+    const double B = 0.0 - cur.rmax, inv = 1.0 / cur.rsum;
+    double sig = 0.0;
+    if (S_perm && lane == 0) sig += exp(cur.perm + B) * cur.yyn;
+    double l[SR];
+    u64 d[SR];
+#pragma unroll
+    for (int u = 0; u < SR; u++) {
+      l[u] = cur.l[u];
+      d[u] = cur.d[u];
+    }
+    lds_wave_fence();
+    issue(n_next, cur);  // every member of `cur` has been consumed: the loads land in the loop-carried registers
+#pragma unroll
+    for (int u = 0; u < SR; u++) {
+      const int sidx = 64 * u + lane;
+      const double q = sidx < S ? exp(l[u] + B) : 0.0;
+      if (q == 0.0) continue;
+      const double qn = q * inv;
+      int k = dig_k(d[u]);
+      if (k <= BSC_KR) {
+        int idx[BSC_KR];
+#pragma unroll
+        for (int j = 0; j < BSC_KR; j++) idx[j] = dig_idx(d[u], j);
+#pragma unroll
+        for (int i = 0; i < BSC_KR; i++) {
+          if (i < k) {
+            unsafeAtomicAdd(&es[idx[i]], q);
+#pragma unroll
+            for (int j = i + 1; j < BSC_KR; j++)
+              if (j < k) {  // strict upper triangle (idx ascending)
+                if (!(binned && pb_append(pb, bcnt, blockIdx.x, H, idx[i], idx[j], qn, 0.0, 0.0)))
+                  unsafeAtomicAdd(&Wq[(i64)idx[i] * H + idx[j]], qn);
+              }
+          }
+        }
+      } else {  // dense state: its words, global atomics
+        const u64 *sp = states + (n * (i64)S + sidx) * HW;
+        k = 0;
+        for (int w = 0; w < HW; w++) {
+          u64 bits = sp[w];
+          k += __popcll(bits);
+          while (bits) {
+            const int h = w * 64 + pop_msb(bits);
+            unsafeAtomicAdd(&es[h], q);
+            u64 b2 = bits;
+            int w2 = w;
+            for (;;) {
+              while (b2) {
+                const int h2 = w2 * 64 + pop_msb(b2);
+                unsafeAtomicAdd(&Wq[(i64)h * H + h2], qn);
+              }
+              if (++w2 >= HW) break;
+              b2 = sp[w2];
+            }
+          }
+        }
+      }
+      sig += q * ((l[u] - pil_bar * (double)k) / pre1);
+    }
+    lds_wave_fence();
+    if (es_f32) {  // float32 mode: the rows the Wp contraction reads are float
+      float *Es = (float *)Es_;
+      for (int h = lane; h < H; h += 64) {
+        const double v = es[h] * inv;
+        Es[n * H + h] = (float)v;
+        if (v != 0.0) unsafeAtomicAdd(&acc[h], v);
+      }
+    } else {
+      double *Es = (double *)Es_;
+      for (int h = lane; h < H; h += 64) {
+        const double v = es[h] * inv;
+        Es[n * H + h] = v;
+        if (v != 0.0) unsafeAtomicAdd(&acc[h], v);
+      }
+    }
+    lds_wave_fence();
+    sigw += wave_sum(sig) * inv;
+  }
+  if (lane == 0) wsig[wave] = sigw;
+  __syncthreads();
+  if (threadIdx.x == 0) sig_partial[blockIdx.x] = ((wsig[0] + wsig[1]) + wsig[2]) + wsig[3];
+  double *sl = cs + (size_t)(blockIdx.x % BSC_CS_SLICES) * H;
+  for (int h = threadIdx.x; h < H; h += 256)
+    if (acc[h] != 0.0) unsafeAtomicAdd(&sl[h], acc[h]);
+  if (binned)
+    for (int i = threadIdx.x; i < pb.nb; i += 256) {
+      const int cnt = bcnt[i];
+      pb.gcnt[(size_t)i * pb.nwg + blockIdx.x] = cnt < pb.cap ? cnt : pb.cap;
+    }
+}
+
 // Finishes the EBSC accumulator in one launch: mirror Wq, Wq[h][h] = pies[h] = column sum of Es
 // (nblk partials of H columns); thread 0 also adds the per-workgroup sigma partials in order.
 __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq, double *__restrict__ pies,
                                                          const double *__restrict__ part, int nblk, int H,
                                                          const double *__restrict__ sig_part, i64 nsig,
-                                                         double *__restrict__ sigma) {
+                                                         double *__restrict__ sigma, PairBins pb) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {  // last workgroup: sigma (tree over 256 threads, fixed order)
     __shared__ double sh[256];
@@ -554,7 +700,11 @@ __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq
     const double s = ordered_strided_sum(part + i, H, nblk);
     pies[i] = s;
     Wq[t] = s;
-  } else if (i > j) {
-    Wq[t] = Wq[(i64)j * H + i];
+  } else if (i < j) {  // this thread owns (i, j) and (j, i): atomics' sum + what went through the pair bins
+    double bq = 0.0, bu, bl;
+    if (pb.part) pb_collect(pb, H, i, j, bq, bu, bl);
+    const double v = Wq[t] + bq;
+    Wq[t] = v;
+    Wq[(i64)j * H + i] = v;
   }
 }

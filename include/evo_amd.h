@@ -100,6 +100,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "b_transposed" (0/1, default 1; read by the next evoamd_configure): from N = 8192 datapoints on the context keeps Y^T as well
  * and computes B = Y W with the 128 x 128 tile kernel; 0: the row-major 64 x 64 tile product.
  * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
+ * "bsc_stats_wave" (0/1, default 1): EBSC statistics on the wave-per-datapoint kernel (next datapoint prefetched, Wq pairs
+ * through the pair bins, column sums in the kernel); 0: the one-shot kernel + column-sum pass.
  * "gemm_workspace" (0/1, default 1): the stream-K workgroups store their partial tiles to a workspace and a second kernel
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction

@@ -64,6 +64,26 @@ def test_trajectory_es3c_pair_bins(engine, name):
         engine.set_option("pair_bins", 1)
 
 
+@pytest.mark.parametrize("name", ["ebsc_bars", "ebsc_mid", "ebsc_dense", "ebsc_perm"])
+def test_trajectory_ebsc_pair_bins_and_round1_kernel(engine, name):
+    """EBSC statistics: the wave-per-datapoint kernel with the Wq pairs through the pair bins (forced at any size), at
+    BASELINE shapes as well, and the round-1 one-shot kernel (option bsc_stats_wave = 0) on the same trajectories."""
+    try:
+        engine.set_option("pair_bins", 2)
+        test_trajectory_reference_rng(engine, name)
+        if name == "ebsc_mid":
+            test_shape_trajectory(engine, "c3_small", False)
+            test_shape_trajectory(engine, "c5_small", False)
+            test_shape_trajectory(engine, "c3_small", True)
+    finally:
+        engine.set_option("pair_bins", 1)
+    try:
+        engine.set_option("bsc_stats_wave", 0)
+        test_trajectory_reference_rng(engine, name)
+    finally:
+        engine.set_option("bsc_stats_wave", 1)
+
+
 @pytest.mark.parametrize("name", STEP_FIXTURES)
 def test_trajectory_reference_rng(engine, name):
     """Theta and K^n are carried from step to step (not reloaded), so errors would compound:
