@@ -57,6 +57,7 @@ CONFIGS["c4full"] = CONFIGS["c4"]  # round-1 name
 EA = dict(parent_selection="fit", mutation="randflip", n_parents=10, n_children=1, n_generations=1)  # examples' defaults
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = FP64 vector peak
+F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 # oracle (the timed "port") vs the imported reference, same container, same inputs, 1 core:
 # ES3C c2 shape 32.7 vs 37.4 ms per datapoint, EBSC c3 shape 2.33 vs 2.50 -- the port is 7-13 % FASTER
 ORACLE_VS_REFERENCE = "oracle is 7-13 % faster than the imported reference (ES3C c2 shape 32.7 vs 37.4 ms per " \
@@ -564,10 +565,16 @@ def main():
         if g:
             t_ms = g["avg_ms"] * g["launches_per_iteration"]
             fl = gemm_flops_per_iteration(cfg, n_loc)
-            out["mfma"] = {"kernels": "gemm_tn_f64 / gemm_tn128_f64 + gemm_nn_f64 (v_mfma_f64_16x16x4_f64)",
-                           "flops_per_iteration": fl, "ms_per_iteration": t_ms,
-                           "achieved": fl / (t_ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": fl / (t_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
+            f32 = bool(cfg.get("f32"))
+            peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
+            out["mfma"] = {"kernels": ("gemm_tn128_sk_f32 / gemm_tn128_store_f32 (v_mfma_f32_16x16x4_f32)" if f32 else
+                                       "gemm_tn128_sk_f64 / gemm_tn128_rows_f64 / gemm_tn_f64 / gemm_nn_f64 (v_mfma_f64_16x16x4_f64)"),
+                           "flops_per_iteration": fl,
+                           "flops_note": "nominal 2 M N K of every product (the symmetric block of the ES3C contraction "
+                                         "runs its upper tiles only: 34 of 40 tiles at H = 512)",
+                           "ms_per_iteration": t_ms,
+                           "achieved": fl / (t_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": fl / (t_ms * 1e-3) / 1e12 / peak}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
