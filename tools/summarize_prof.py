@@ -32,6 +32,11 @@ def main(out):
                                                                float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                                float(r["Percentage"])))
         print()
+        print("Note: a kernel's duration runs from its dispatch to its end.  The H x H elimination chain (gjs32_first_kernel, "
+              "then gjs32_step_kernel) is launched on the main stream while the persistent stream-K contraction "
+              "(gemm_tn128_sk_f64) holds every CU slot on the second stream: the first kernel of the chain waits for a slot "
+              "for most of the contraction, so its `avg us` (and its share of the GPU time) is queueing, not work -- its min "
+              "(~15 us) is the kernel itself.\n")
     pmc = {}
     for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         f = find(os.path.join(out, tag), "counter_collection.csv")
