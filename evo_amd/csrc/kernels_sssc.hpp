@@ -629,23 +629,23 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
       live[p] = !(a.counts && c[p] >= a.counts[n_first + r]);
     }
   }
+  // Order of the memory traffic (the workgroup's life is its chain of round trips): digests and yy are REQUESTED
+  // first (unconditional loads, clamped addresses) but not looked at; the B rows are staged while they fly; then
+  // the digests are decoded and the pair-table entries requested -- again unconditionally, entry 0 where there is no
+  // pair -- so that they fly during the barriers of the overflow compaction.  Before: digest round trip, staging
+  // round trip, barriers, pair-table round trip, one after the other.
+  u64 dgv[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; p++) {
-    if (live[p]) {
+    dgv[p] = 0ull;
+    if (a.dig) {  // 8 coalesced bytes per state instead of HW words (dig is nullptr for shared sets)
+      const i64 tc = live[p] ? (n_first + nloc[p]) * (i64)a.C + c[p] : 0;
+      dgv[p] = a.dig[tc];
+    } else if (live[p]) {
       const i64 n = n_first + nloc[p];
-      // popcount and the (at most two) active latents right after the loads, so that the state
-      // words are dead before the barriers
-      if (a.dig) {  // 8 coalesced bytes per state instead of HW words (dig is nullptr for shared sets)
-        const u64 d = a.dig[n * (i64)a.C + c[p]];
-        ktot[p] = dig_k(d);
-        idx0[p] = dig_idx(d, 0);
-        idx1[p] = dig_idx(d, 1);
-      } else {
-        load_state_k2<HWT>(a.states + ((a.shared ? 0 : n * (i64)a.C) + c[p]) * a.HW, a.HW, ktot[p], idx0[p], idx1[p]);
-      }
-      yyn[p] = a.yy[n];
+      load_state_k2<HWT>(a.states + ((a.shared ? 0 : n * (i64)a.C) + c[p]) * a.HW, a.HW, ktot[p], idx0[p], idx1[p]);
     }
-    over[p] = live[p] && ktot[p] > 2;
+    yyn[p] = a.yy[live[p] ? n_first + nloc[p] : 0];
   }
   {  // stage B rows n_first .. n_last (contiguous) and the singleton table
     const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
@@ -654,6 +654,18 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
     for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
     if (stage_dg)
       for (int i = threadIdx.x; i < a.H; i += BS) DGs[i] = a.D1[i];
+  }
+  PairEntry pe[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; p++) {
+    if (a.dig && live[p]) {
+      ktot[p] = dig_k(dgv[p]);
+      idx0[p] = dig_idx(dgv[p], 0);
+      idx1[p] = dig_idx(dgv[p], 1);
+    }
+    over[p] = live[p] && ktot[p] > 2;
+    const bool pair = live[p] && ktot[p] == 2;
+    pe[p] = a.PT[pair ? (i64)idx0[p] * a.H + idx1[p] : 0];  // idx0 < idx1
   }
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
   append_begin<BS, PPT>(lo, shard, tv, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
@@ -676,14 +688,13 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
       if (k == 2) {
         d1 = D1t[idx1[p]];
         b1 = Bn[idx1[p]];
-        const PairEntry pe = a.PT[(i64)idx0[p] * a.H + idx1[p]];  // idx0 < idx1
-        g01 = pe.g01;
-        L = pe.L;
-        l00 = pe.l00;
-        l01 = pe.l01;
-        l10 = pe.l10;
-        l11 = pe.l11;
-        if (pair_singular_L(pe.L)) atomicOr(a.err, 2);
+        g01 = pe[p].g01;
+        L = pe[p].L;
+        l00 = pe[p].l00;
+        l01 = pe[p].l01;
+        l10 = pe[p].l10;
+        l11 = pe[p].l11;
+        if (pair_singular_L(pe[p].L)) atomicOr(a.err, 2);
       }
       const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
       const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
