@@ -345,6 +345,45 @@ def test_gemm_tn_dispatch(engine, K, M, Nc, sym):
     if sym:
         blk = C[M - Nc:]
         assert np.abs(blk - blk.T).max() <= 1e-11 * np.abs(ref).max()
+    if K >= 8192:
+        # stream-K grid: partial tiles through the workspace + reduce kernel (above; a fixed order of additions, so a
+        # second call returns the same bits) against the f64 atomic epilogue and against the split-K grid
+        C2 = engine.gemm_tn(A, B, M - Nc if sym else -1)
+        np.testing.assert_array_equal(C2, C)
+        for opt in ("gemm_workspace", "gemm_streamk"):
+            engine.set_option(opt, 0)
+            try:
+                Ca = engine.gemm_tn(A, B, M - Nc if sym else -1)
+            finally:
+                engine.set_option(opt, 1)
+            assert np.abs(Ca - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_b_transposed_matches_rowmajor(engine):
+    """From N = 8192 datapoints on the context keeps Y^T and computes B = Y W on the 128-tile kernel (option
+    b_transposed); the lpj of a resident K^n must not care which product fed it."""
+    from oracle import evo_oracle as orc
+    rng = np.random.default_rng(3)
+    N, D, H, S = 8300, 40, 128, 8
+    Y = rng.standard_normal((N, D))
+    ss = rng.random((N, S, H)) < 1.5 / H
+    W = rng.standard_normal((D, H))
+    got = {}
+    for opt in (1, 0):
+        engine.set_option("b_transposed", opt)
+        try:
+            engine.configure("bsc", N, D, H, S, 0, 4)
+            engine.upload_data(Y)
+            engine.upload_states(ss)
+            engine.set_params_bsc(W, 0.02, 1.3)
+            engine.lpj_resident()
+            got[opt] = engine.download_lpj()
+        finally:
+            engine.set_option("b_transposed", 1)
+    np.testing.assert_allclose(got[1], got[0], rtol=1e-12, atol=0)
+    th = {"W": W, "pre1": -1.0 / 2.0 / 1.3 / 1.3, "pil_bar": np.log(0.02 / (1.0 - 0.02))}
+    want = np.array([orc.bsc_lpj(th, ss[n], Y[n], orc.new_counters()) for n in range(0, N, 997)])
+    np.testing.assert_allclose(got[1][::997], want, rtol=1e-10)
 
 
 def test_inverse_above_blocked_limit(engine):
