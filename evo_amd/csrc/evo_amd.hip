@@ -1834,7 +1834,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
     else if (c->S <= 512) { if (c1) VK_LAUNCH(8, 1); else VK_LAUNCH(8, 4); }
     else { if (c1) VK_LAUNCH(16, 1); else VK_LAUNCH(16, 4); }
 #undef VK_LAUNCH
-    reduce3_partials_kernel<<<1, 256, 0, c->stream>>>(c->partial, cdiv(c->N, 4), c->dpar);
+    reduce3_partials_kernel<<<1, R3_THREADS, 0, c->stream>>>(c->partial, cdiv(c->N, 4), c->dpar);
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "vary_kn");
     c->rows_fresh = true;

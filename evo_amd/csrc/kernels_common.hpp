@@ -171,21 +171,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
 // Three partial arrays of length n laid out back to back (free-energy terms, #new-unique, #swapped
 // per workgroup of vary_kn) -> dpar[DP_FS] (assigned), dpar[DP_ECNT0/1] (accumulated).  Fixed
 // summation order: reproducible run to run.
-__global__ __launch_bounds__(256) void reduce3_partials_kernel(const double *__restrict__ partial, i64 n,
-                                                               double *__restrict__ dpar) {
-  __shared__ double sh[3][256];
+#define R3_THREADS 1024
+__global__ __launch_bounds__(R3_THREADS) void reduce3_partials_kernel(const double *__restrict__ partial, i64 n,
+                                                                      double *__restrict__ dpar) {
+  __shared__ double sh[3][R3_THREADS];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  if ((i64)threadIdx.x < n) {
-    const i64 cnt = (n - threadIdx.x + 255) / 256;
-    s0 = ordered_strided_sum(partial + threadIdx.x, 256, cnt);
-    s1 = ordered_strided_sum(partial + n + threadIdx.x, 256, cnt);
-    s2 = ordered_strided_sum(partial + 2 * n + threadIdx.x, 256, cnt);
+  if ((i64)threadIdx.x < n) {  // (25k-50k partials at the large shapes: 1024 chains of ~25-50 dependent additions)
+    const i64 cnt = (n - threadIdx.x + R3_THREADS - 1) / R3_THREADS;
+    s0 = ordered_strided_sum(partial + threadIdx.x, R3_THREADS, cnt);
+    s1 = ordered_strided_sum(partial + n + threadIdx.x, R3_THREADS, cnt);
+    s2 = ordered_strided_sum(partial + 2 * n + threadIdx.x, R3_THREADS, cnt);
   }
   sh[0][threadIdx.x] = s0;
   sh[1][threadIdx.x] = s1;
   sh[2][threadIdx.x] = s2;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = R3_THREADS / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o)
       for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
     __syncthreads();
