@@ -126,6 +126,9 @@ def stats_kernels(cfg):
     if cfg["algo"] == "es3c":
         return ["void sssc_stats_wave_kernel<%d, 4>" % hwt, "pair_bins_reduce_kernel", "void sssc_small_kernel<4, 1, 2, 256>",
                 "void sssc_small_kernel<8, 1, 2, 256>", "void sssc_big_kernel<1, 2>", "sssc_finish_kernel"]
+    sr = (cfg["S"] + 63) // 64
+    if sr <= 4:  # wave-per-datapoint kernel + pair bins (evo_amd.hip: bsc_wave)
+        return ["void bsc_stats_wave_kernel<%d>" % (sr if sr in (1, 2) else 4), "pair_bins_reduce_kernel", "bsc_finish_kernel"]
     return ["void bsc_stats_kernel<%d>" % hwt, "colsum_partial_kernel", "bsc_finish_kernel"]
 
 
