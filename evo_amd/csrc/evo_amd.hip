@@ -690,7 +690,10 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (c->Yt) (void)hipFree(c->Yt);
   c->Yt = nullptr;
   c->f32 = model == EVOAMD_MODEL_BSC && c->f32_opt;
-  if (!c->f32 && c->b_tn_opt && N >= 8192 && H >= 128 && D >= 32 && (H % 2) == 0) {
+  // (measured: pays at H = 1024, D = 256 -- c5 2.07 -> 1.90 ms --, equal at H = 512, slower at H = 256 / D = 64 where a
+  // tile has four K slabs; option value 2 forces it from H = 128 on for the tests)
+  if (!c->f32 && c->b_tn_opt && N >= 8192 && (H % 2) == 0 &&
+      ((H >= 768 && D >= 128) || (c->b_tn_opt == 2 && H >= 128 && D >= 32))) {
     c->ldYt = ((N + 3) / 4) * 4;
     ALLOC(c->Yt, (size_t)D * c->ldYt);
     HIP_TRY(hipMemsetAsync(c->Yt, 0, (size_t)D * c->ldYt * sizeof(double), c->stream));

@@ -97,8 +97,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * in LDS when two workgroups per CU still fit.  "stats_waves" (0 / 8 / 16, measurement aid): waves per workgroup of the
  * ES3C statistics kernel (0 = 4).  "gemm_streamk" (0/1, default 1): the long-K 128-tile contraction runs as ONE resident-sized grid -- every XCD owns an eighth
  * of K, its workgroups cut the (tile, K slab) units of that range into equal runs -- instead of tiles x 64 K chunks.
- * "b_transposed" (0/1, default 1; read by the next evoamd_configure): from N = 8192 datapoints on the context keeps Y^T as well
- * and computes B = Y W with the 128 x 128 tile kernel; 0: the row-major 64 x 64 tile product.
+ * "b_transposed" (0/1/2, default 1; read by the next evoamd_configure): from N = 8192 datapoints, H = 768 and D = 128 on
+ * (2: from H = 128, D = 32 on) the context keeps Y^T as well and computes B = Y W with the 128 x 128 tile kernel; 0: always
+ * the row-major 64 x 64 tile product.
  * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
  * "bsc_stats_wave" (0/1, default 1): EBSC statistics on the wave-per-datapoint kernel (next datapoint prefetched, Wq pairs
  * through the pair bins, column sums in the kernel); 0: the one-shot kernel + column-sum pass.
