@@ -380,10 +380,10 @@ def test_b_transposed_matches_rowmajor(engine):
             got[opt] = engine.download_lpj()
         finally:
             engine.set_option("b_transposed", 1)
-    np.testing.assert_allclose(got[1], got[0], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got[2], got[0], rtol=1e-12, atol=0)
     th = {"W": W, "pre1": -1.0 / 2.0 / 1.3 / 1.3, "pil_bar": np.log(0.02 / (1.0 - 0.02))}
     want = np.array([orc.bsc_lpj(th, ss[n], Y[n], orc.new_counters()) for n in range(0, N, 997)])
-    np.testing.assert_allclose(got[1][::997], want, rtol=1e-10)
+    np.testing.assert_allclose(got[2][::997], want, rtol=1e-10)
 
 
 def test_inverse_above_blocked_limit(engine):
