@@ -48,37 +48,68 @@ __device__ __forceinline__ bool pb_append(const PairBins &pb, int *bcnt, int wg,
 // fixed order: no global atomic anywhere on this route.  One wave per region at a time.  2 rf H <= PB_TILE.
 __global__ __launch_bounds__(PB_RTHREADS) void pair_bins_reduce_kernel(PairBins pb, int H, int accumulate) {
   extern __shared__ double pb_tile[];
+  constexpr int NW = PB_RTHREADS / 64;
+  __shared__ int pre_sh[NW][65];  // per wave: exclusive prefix of the entry counts of its (up to 64) regions
   const int bin = blockIdx.x / PB_NSH, sh = blockIdx.x - bin * PB_NSH;
   const int slots = 2 * pb.rf * H;
   double *tq = pb_tile, *tu = pb_tile + slots, *tl = pb_tile + 2 * slots;
   for (int i = threadIdx.x; i < 3 * slots; i += PB_RTHREADS) pb_tile[i] = 0.0;
   lds_barrier();
   const int lane = lane_id(), wave = wave_id_uniform();
-  for (int w = sh + PB_NSH * wave; w < pb.nwg; w += PB_NSH * (PB_RTHREADS / 64)) {
-    const size_t reg = (size_t)bin * pb.nwg + w;
-    int n = pb.gcnt[reg];
-    if (n > pb.cap) n = pb.cap;
-    if (n == 0) continue;  // wave-uniform
-    if (lane == 0) pb.gcnt[reg] = 0;  // ready for the next pass
-    const double4 *ent = pb.ent + reg * pb.cap;
-    for (int e0 = 0; e0 < n; e0 += 128) {  // two entries in flight per lane
-      const int ea = e0 + lane, eb = e0 + 64 + lane;
-      const double4 va = ent[ea < n ? ea : 0], vb = ent[eb < n ? eb : 0];
-      if (ea < n) {
-        const unsigned ka = (unsigned)__double_as_longlong(va.w);
-        const int t = (int)(ka >> 16) * H + (int)(ka & 0xFFFFu);
-        unsafeAtomicAdd(&tq[t], va.x);
-        unsafeAtomicAdd(&tu[t], va.y);
-        unsafeAtomicAdd(&tl[t], va.z);
-      }
-      if (eb < n) {
-        const unsigned kb = (unsigned)__double_as_longlong(vb.w);
-        const int t = (int)(kb >> 16) * H + (int)(kb & 0xFFFFu);
-        unsafeAtomicAdd(&tq[t], vb.x);
-        unsafeAtomicAdd(&tu[t], vb.y);
-        unsafeAtomicAdd(&tl[t], vb.z);
-      }
+  // A wave serves the regions w = sh + PB_NSH (wave + NW j), j = 0, 1, ...: 64 of them at a time.  Their counts are
+  // read with ONE load per lane and turned into a prefix, so that the wave walks ONE flat list of entries with four
+  // independent loads in flight per lane (region by region it was a chain of count -> entries round trips, 32 per
+  // wave: most of this kernel's time).
+  for (int j0 = 0; sh + PB_NSH * (wave + NW * j0) < pb.nwg; j0 += 64) {
+    const int w = sh + PB_NSH * (wave + NW * (j0 + lane));
+    int n = 0;
+    if (w < pb.nwg) {
+      const size_t reg = (size_t)bin * pb.nwg + w;
+      n = pb.gcnt[reg];
+      if (n > pb.cap) n = pb.cap;
+      if (n != 0) pb.gcnt[reg] = 0;  // ready for the next pass
     }
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    pre_sh[wave][lane + 1] = incl;
+    if (lane == 0) pre_sh[wave][0] = 0;
+    lds_wave_fence();
+    const int T = pre_sh[wave][64];
+    for (int t0 = 0; t0 < T; t0 += 256) {
+      double4 v[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int t = t0 + 64 * u + lane;
+        on[u] = t < T;
+        int lo = 0, hi = 64;  // region r with pre[r] <= t < pre[r + 1]
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+          const int mid = (lo + hi) >> 1;
+          if (pre_sh[wave][mid] <= t)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        const int wr = sh + PB_NSH * (wave + NW * (j0 + lo));
+        const size_t at = on[u] ? ((size_t)bin * pb.nwg + wr) * pb.cap + (t - pre_sh[wave][lo]) : 0;
+        v[u] = pb.ent[at];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (on[u]) {
+          const unsigned k = (unsigned)__double_as_longlong(v[u].w);
+          const int t = (int)(k >> 16) * H + (int)(k & 0xFFFFu);
+          unsafeAtomicAdd(&tq[t], v[u].x);
+          unsafeAtomicAdd(&tu[t], v[u].y);
+          unsafeAtomicAdd(&tl[t], v[u].z);
+        }
+    }
+    lds_wave_fence();
   }
   lds_barrier();
   double *out = pb.part + (size_t)blockIdx.x * 3 * slots;
