@@ -695,8 +695,12 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (!c->f32 && c->b_tn_opt && N >= 8192 && (H % 2) == 0 &&
       ((H >= 768 && D >= 128) || (c->b_tn_opt == 2 && H >= 128 && D >= 32))) {
     c->ldYt = ((N + 3) / 4) * 4;
-    ALLOC(c->Yt, (size_t)D * c->ldYt);
-    HIP_TRY(hipMemsetAsync(c->Yt, 0, (size_t)D * c->ldYt * sizeof(double), c->stream));
+    if (hipMalloc((void **)&c->Yt, (size_t)D * c->ldYt * sizeof(double)) == hipSuccess) {
+      HIP_TRY(hipMemsetAsync(c->Yt, 0, (size_t)D * c->ldYt * sizeof(double), c->stream));
+    } else {  // optional: the row-major product serves
+      (void)hipGetLastError();
+      c->Yt = nullptr;
+    }
   }
   if (c->f32) REQUIRE((H % 4) == 0 && (D % 4) == 0, "float32 mode needs H and D to be multiples of 4 (16-byte rows)");
   if (model == EVOAMD_MODEL_BSC) {
@@ -744,11 +748,20 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       pb.nwg = 2048;
       pb.cap = (int)std::max<i64>(64, 3 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
-      ALLOC(pb.ent, ne);
-      ALLOC(pb.part, (size_t)pb.nb * PB_NSH * 3 * 2 * pb.rf * H);
-      ALLOC(pb.gcnt, (size_t)pb.nb * pb.nwg);
-      HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
-      c->pbins = pb;
+      // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
+      // rest, the statistics kernels use their global-atomic paths
+      const bool got = hipMalloc((void **)&pb.ent, ne * sizeof(double4)) == hipSuccess &&
+                       hipMalloc((void **)&pb.part, (size_t)pb.nb * PB_NSH * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
+                       hipMalloc((void **)&pb.gcnt, (size_t)pb.nb * pb.nwg * sizeof(int)) == hipSuccess;
+      if (got) {
+        HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
+        c->pbins = pb;
+      } else {
+        (void)hipGetLastError();
+        if (pb.ent) (void)hipFree(pb.ent);
+        if (pb.part) (void)hipFree(pb.part);
+        if (pb.gcnt) (void)hipFree(pb.gcnt);
+      }
     }
   }
   if (c->h_acc) (void)hipHostFree(c->h_acc);
