@@ -427,7 +427,10 @@ def test_bench_path_with_rccl_communicator():
 
 
 @pytest.mark.parametrize("D,H,S,N,device_mstep", [(64, 64, 20, 300, False), (64, 64, 20, 300, True),
-                                                    (192, 128, 24, 160, True)])
+                                                    (192, 128, 24, 160, True),
+                                                    # S > 256: the statistics kernel's second (not prefetched) group of
+                                                    # rounds, five rounds of states per lane in the selection kernel
+                                                    (16, 24, 300, 40, False)])
 def test_es3c_tile_aligned_shapes_against_oracle(engine, D, H, S, N, device_mstep):
     """ES3C EM steps at shapes whose accumulator blocks are 64-aligned (D + H a multiple of 64), which
     switches the Ez^T Ez contraction to its upper-tiles-plus-mirror form and the GEMM loaders to their
