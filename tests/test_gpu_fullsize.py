@@ -1,0 +1,166 @@
+"""Size-independent properties at BASELINE.json's FULL sizes (run with ``-m gpu`` on an MI355X).
+
+The oracle finishes in seconds only at small N, so at the north-star shape (ES3C D=256 H=512 S=200, N = 100k on one
+GPU) and at configs[2] (EBSC D=64 H=256 S=128, N = 50k) the device path is checked through what must hold at any
+size:
+
+* idempotence -- the lpj pass and the statistics pass leave the same numbers when they run again;
+* a checksum of checksums -- the first and second moments the statistics pass accumulates, summed, must equal
+  sum_n sum_s q_ns |s| and sum_n sum_s q_ns |s| (|s| - 1) recomputed on the host from the downloaded K^n and lpj
+  (softmax weights and popcounts; sssc.py:553-611, bsc.py:193-223), and the free-energy term must equal the
+  log-sum-exp of the downloaded rows (_models.py:540-547);
+* structure -- E[s s^T] symmetric with E[s] on its diagonal, every datapoint's K^n free of duplicate states
+  (variational/utils.py:279-290);
+* path independence -- pair bins vs global atomics, stream-K workspace vs atomic epilogue give the same sums;
+* monotonicity -- with Theta fixed an E-step can only raise the free energy (vary_Kn keeps the best S states,
+  variational/utils.py:292-337).
+Everything goes through the C ABI; the workload is bench.py's (same seeds)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], dtype=np.uint8)
+
+
+def _setup(name, N=None):
+    import bench
+    from evo_amd.engine import Engine
+    from evo_amd.models import BSC, SSSC
+    cfg = dict(bench.CONFIGS[name])
+    if N is not None:
+        cfg["N"] = N
+    np.random.seed(1234 + 2)
+    Y = np.ascontiguousarray(np.random.randn(cfg["N"], cfg["D"]))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    chunks = list(bench.init_states_packed(cfg, cfg["N"], 4321, max(1, bench.host_cores())))
+    eng = Engine()
+    cls = BSC if cfg["algo"] == "ebsc" else SSSC
+    model = cls(cfg["D"], cfg["H"], cfg["S"], rng="device", sync_host=False, engine=eng, seed=17, device_mstep=False)
+    np.random.seed(99)
+    theta = model.check_params(model.standard_init(my_data))
+    suff = bench.ea_suff(cfg)
+    model.attach_resident_states(suff, my_data, chunks)
+    return cfg, eng, model, theta, suff, my_data
+
+
+def _weights_and_counts(eng, cfg):
+    """q (N, S) posterior weights of the truncated posterior and k (N, S) = |s| from the device's K^n and lpj."""
+    lpj = eng.download_lpj()
+    m = lpj.max(axis=1, keepdims=True)
+    e = np.exp(lpj - m)
+    z = e.sum(axis=1, keepdims=True)
+    q = e / z
+    Fs = float((np.log(z[:, 0]) + m[:, 0]).sum())
+    k = np.empty((cfg["N"], cfg["S"]), dtype=np.int32)
+    step = 10000
+    for n0 in range(0, cfg["N"], step):  # packed rows, popcount by table
+        st = eng.download_states_packed(n0, min(step, cfg["N"] - n0))
+        k[n0:n0 + st.shape[0]] = _POP8[st].sum(axis=2, dtype=np.int32)
+        if n0 % (7 * step) == 0:  # a sample of datapoints: no duplicate state in K^n
+            for r in range(0, st.shape[0], 997):
+                assert np.unique(st[r], axis=0).shape[0] == cfg["S"]
+    return lpj, q, k, Fs
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, float(np.abs(np.asarray(b)).max())))
+
+
+def test_north_star_shape_full_size_properties():
+    cfg, eng, model, theta, suff, my_data = _setup("c4")
+    try:
+        N, S, H = cfg["N"], cfg["S"], cfg["H"]
+        Fseq = []
+        for _ in range(2):  # two full EM iterations: Theta moves, K^n grows denser
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            Fseq.append(F)
+        assert np.isfinite(Fseq).all()
+        # --- Theta fixed from here on: an E-step can only raise F
+        Fe = [model.E_step(theta, suff, my_data)[0] for _ in range(3)]
+        assert Fe[1] >= Fe[0] - 1e-12 * abs(Fe[0]) and Fe[2] >= Fe[1] - 1e-12 * abs(Fe[1]), Fe
+        assert Fe[2] > Fe[0]
+        v1 = eng.acc_views(model.last_acc.copy())
+        # --- idempotence: lpj pass (bit for bit), statistics pass (order of the f64 additions only)
+        eng.lpj_resident()
+        l1 = eng.download_lpj()
+        eng.lpj_resident()
+        assert np.array_equal(l1, eng.download_lpj())
+        v2 = eng.acc_views(eng.stats())
+        for name in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "Wp", "s_sz_outer", "sz_sz_outer", "y_outer_diag"):
+            assert _rel(v2[name], v1[name]) <= 1e-11, name
+        assert float(v2["Fs"]) == float(v1["Fs"]) and float(v2["N"]) == N
+        # --- checksums from the raw K^n and lpj
+        lpj, q, k, Fs = _weights_and_counts(eng, cfg)
+        assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
+        s1 = float((q * k).sum())
+        s2 = float((q * (k * (k - 1.0))).sum())
+        xs, xss = v2["xpt_s"], v2["xpt_ss"]
+        assert abs(float(xs.sum()) - s1) <= 1e-10 * s1
+        assert np.array_equal(np.diag(xss), xs)
+        assert np.array_equal(xss, xss.T)
+        assert abs(float(xss.sum() - np.trace(xss)) - s2) <= 1e-10 * max(s2, 1.0)
+        # --- path independence
+        for opt, val in (("pair_bins", 0), ("gemm_workspace", 0), ("gemm_streamk", 0)):
+            eng.set_option(opt, val)
+            try:
+                v3 = eng.acc_views(eng.stats())
+            finally:
+                eng.set_option(opt, 1)
+            for name in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "Wp", "s_sz_outer", "sz_sz_outer"):
+                assert _rel(v3[name], v2[name]) <= 1e-10, (opt, name)
+        # sz_sz_outer is a Gram matrix: symmetric, non-negative diagonal
+        G = v2["sz_sz_outer"]
+        assert _rel(G, G.T) <= 1e-12 and (np.diag(G) >= 0).all()
+    finally:
+        eng.close()
+
+
+def test_ebsc_config3_full_size_properties():
+    cfg, eng, model, theta, suff, my_data = _setup("c3")
+    try:
+        N, S, H = cfg["N"], cfg["S"], cfg["H"]
+        for _ in range(2):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            assert np.isfinite(F)
+        Fe = [model.E_step(theta, suff, my_data)[0] for _ in range(3)]
+        assert Fe[1] >= Fe[0] - 1e-12 * abs(Fe[0]) and Fe[2] >= Fe[1] - 1e-12 * abs(Fe[1]), Fe
+        assert Fe[2] > Fe[0]
+        v1 = eng.acc_views(model.last_acc.copy())
+        eng.lpj_resident()
+        l1 = eng.download_lpj()
+        eng.lpj_resident()
+        assert np.array_equal(l1, eng.download_lpj())
+        v2 = eng.acc_views(eng.stats())
+        for name in ("Wp", "Wq", "pies", "sigma"):
+            assert _rel(v2[name], v1[name]) <= 1e-11, name
+        lpj, q, k, Fs = _weights_and_counts(eng, cfg)
+        assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
+        s1 = float((q * k).sum())
+        s2 = float((q * (k * (k - 1.0))).sum())
+        pies, Wq = v2["pies"], v2["Wq"]
+        assert abs(float(pies.sum()) - s1) <= 1e-10 * s1
+        assert np.array_equal(np.diag(Wq), pies)
+        assert np.array_equal(Wq, Wq.T)
+        assert abs(float(Wq.sum() - np.trace(Wq)) - s2) <= 1e-10 * max(s2, 1.0)
+        # sigma accumulates sum_ns q ||y - W s||^2 = sum_ns q (lpj - pil_bar |s|) / pre1 (bsc.py:214-218 through lpj's own terms)
+        pre1, pil_bar = float(theta["pre1"]), float(theta["pil_bar"])  # E_step_precompute left them in the dict (bsc.py:99-125)
+        sig = float((q * ((lpj - pil_bar * k) / pre1)).sum())
+        assert abs(float(v2["sigma"]) - sig) <= 1e-9 * abs(sig)
+        for opt, val in (("pair_bins", 0), ("bsc_stats_wave", 0)):
+            eng.set_option(opt, val)
+            try:
+                v3 = eng.acc_views(eng.stats())
+            finally:
+                eng.set_option(opt, 1)
+            for name in ("Wp", "Wq", "pies", "sigma"):
+                assert _rel(v3[name], v2[name]) <= 1e-10, (opt, name)
+    finally:
+        eng.close()
