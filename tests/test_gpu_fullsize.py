@@ -1,8 +1,8 @@
 """Size-independent properties at BASELINE.json's FULL sizes (run with ``-m gpu`` on an MI355X).
 
 The oracle finishes in seconds only at small N, so at the north-star shape (ES3C D=256 H=512 S=200, N = 100k on one
-GPU) and at configs[2] (EBSC D=64 H=256 S=128, N = 50k) the device path is checked through what must hold at any
-size:
+GPU), at configs[1] (ES3C H=128, N = 10k), configs[2] (EBSC D=64 H=256 S=128, N = 50k) and configs[4] (EBSC H=1024,
+N = 200k on one GPU, float64) the device path is checked through what must hold at any size:
 
 * idempotence -- the lpj pass and the statistics pass leave the same numbers when they run again;
 * a checksum of checksums -- the first and second moments the statistics pass accumulates, summed, must equal
@@ -74,8 +74,9 @@ def _rel(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, float(np.abs(np.asarray(b)).max())))
 
 
-def test_north_star_shape_full_size_properties():
-    cfg, eng, model, theta, suff, my_data = _setup("c4")
+@pytest.mark.parametrize("name", ["c2", "c4"])
+def test_es3c_full_size_properties(name):
+    cfg, eng, model, theta, suff, my_data = _setup(name)
     try:
         N, S, H = cfg["N"], cfg["S"], cfg["H"]
         Fseq = []
@@ -96,7 +97,8 @@ def test_north_star_shape_full_size_properties():
         v2 = eng.acc_views(eng.stats())
         for name in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "Wp", "s_sz_outer", "sz_sz_outer", "y_outer_diag"):
             assert _rel(v2[name], v1[name]) <= 1e-11, name
-        assert float(v2["Fs"]) == float(v1["Fs"]) and float(v2["N"]) == N
+        # (Fs of the E-step comes out of the selection kernel's row statistics, here out of the row pass: other tree)
+        assert abs(float(v2["Fs"]) - float(v1["Fs"])) <= 1e-14 * abs(float(v1["Fs"])) and float(v2["N"]) == N
         # --- checksums from the raw K^n and lpj
         lpj, q, k, Fs = _weights_and_counts(eng, cfg)
         assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
@@ -123,8 +125,9 @@ def test_north_star_shape_full_size_properties():
         eng.close()
 
 
-def test_ebsc_config3_full_size_properties():
-    cfg, eng, model, theta, suff, my_data = _setup("c3")
+@pytest.mark.parametrize("name", ["c3", "c5"])
+def test_ebsc_full_size_properties(name):
+    cfg, eng, model, theta, suff, my_data = _setup(name)
     try:
         N, S, H = cfg["N"], cfg["S"], cfg["H"]
         for _ in range(2):
@@ -141,19 +144,20 @@ def test_ebsc_config3_full_size_properties():
         v2 = eng.acc_views(eng.stats())
         for name in ("Wp", "Wq", "pies", "sigma"):
             assert _rel(v2[name], v1[name]) <= 1e-11, name
-        lpj, q, k, Fs = _weights_and_counts(eng, cfg)
-        assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
-        s1 = float((q * k).sum())
-        s2 = float((q * (k * (k - 1.0))).sum())
         pies, Wq = v2["pies"], v2["Wq"]
-        assert abs(float(pies.sum()) - s1) <= 1e-10 * s1
         assert np.array_equal(np.diag(Wq), pies)
         assert np.array_equal(Wq, Wq.T)
-        assert abs(float(Wq.sum() - np.trace(Wq)) - s2) <= 1e-10 * max(s2, 1.0)
-        # sigma accumulates sum_ns q ||y - W s||^2 = sum_ns q (lpj - pil_bar |s|) / pre1 (bsc.py:214-218 through lpj's own terms)
-        pre1, pil_bar = float(theta["pre1"]), float(theta["pil_bar"])  # E_step_precompute left them in the dict (bsc.py:99-125)
-        sig = float((q * ((lpj - pil_bar * k) / pre1)).sum())
-        assert abs(float(v2["sigma"]) - sig) <= 1e-9 * abs(sig)
+        if N * S * ((H + 7) // 8) <= 2 << 30:  # (configs[4]: 6.5 GB of packed K^n -- the checks above and below only)
+            lpj, q, k, Fs = _weights_and_counts(eng, cfg)
+            assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
+            s1 = float((q * k).sum())
+            s2 = float((q * (k * (k - 1.0))).sum())
+            assert abs(float(pies.sum()) - s1) <= 1e-10 * s1
+            assert abs(float(Wq.sum() - np.trace(Wq)) - s2) <= 1e-10 * max(s2, 1.0)
+            # sigma accumulates sum_ns q ||y - W s||^2 = sum_ns q (lpj - pil_bar |s|) / pre1 (bsc.py:214-218 through lpj's terms)
+            pre1, pil_bar = float(theta["pre1"]), float(theta["pil_bar"])  # left in the dict by E_step_precompute (bsc.py:99-125)
+            sig = float((q * ((lpj - pil_bar * k) / pre1)).sum())
+            assert abs(float(v2["sigma"]) - sig) <= 1e-9 * abs(sig)
         for opt, val in (("pair_bins", 0), ("bsc_stats_wave", 0)):
             eng.set_option(opt, val)
             try:
