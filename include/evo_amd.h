@@ -306,14 +306,14 @@ enum {
   EVOAMD_K_LPJ_OVERFLOW = 2,   /* ES3C states with |s| > 2: K=4 / K=8 register kernels + LDS wavefront kernel (any batch)   */
   EVOAMD_K_ROW_LSE = 3,        /* free energy / posterior normalisers when vary_kn did not leave them behind              */
   EVOAMD_K_VARY_KN = 4,
-  EVOAMD_K_STATS = 5,          /* bsc_stats_kernel / sssc_stats_kernel (|s| <= 2)                                          */
+  EVOAMD_K_STATS = 5,          /* bsc_stats_wave_kernel / sssc_stats_wave_kernel (|s| <= 2) + pair_bins_reduce_kernel      */
   EVOAMD_K_STATS_OVERFLOW = 6, /* ES3C statistics of the states with |s| > 2                                              */
   EVOAMD_K_GEMM = 7,           /* f64 MFMA contractions                                     */
   EVOAMD_K_EVOLVE = 8,
   EVOAMD_K_MISC = 9,
   EVOAMD_K_MSTEP_DEVICE = 10,  /* device Theta update (inverse, GEMMs, precompute) */
   EVOAMD_K_LPJ_PASS = 11,      /* whole pass over the resident K^n: main kernel + every overflow level (one span) */
-  EVOAMD_K_STATS_PASS = 12,    /* whole statistics pass: scatter + overflow levels + column sums + finish, GEMM aside */
+  EVOAMD_K_STATS_PASS = 12,    /* whole statistics pass: scatter + overflow levels + bin reduce + finish, GEMM aside */
   EVOAMD_K_COUNT = 13
 };
 /* on = bit mask of kernel classes to time (bit k = class k; -1 = all, 0 = off).  Each timed span
