@@ -1187,6 +1187,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   if (!c->bsc_direct) {
     int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D);  // G = W^T W
     if (r) return r;
+    extract_diag_kernel<<<cdiv(c->H, 256), 256, 0, c->stream>>>(c->G, c->H, c->diag);
     if (c->have_data) {
       r = launch_B(c);  // B = Y W
       if (r) return r;
@@ -1363,7 +1364,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
       const unsigned g2 = cdiv(total, 512);
 #define GRAM2(TAG, HWT)                                                                                      \
   bsc_lpj_gram2_kernel<TAG, HWT><<<g2, 512, lds, c->stream>>>(b.states, b.counts, bmat, b.yy, c->G, b.N, b.C, c->H, \
-                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32)
+                                                              c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32, c->diag)
 #define GRAM2_HW(TAG)                    \
   switch (c->HW) {                       \
     case 1: GRAM2(TAG, 1); break;        \
@@ -1384,7 +1385,7 @@ static int launch_bsc_lpj(evoamd_ctx *c, const Batch &b) {
     }
 #define GRAM_LAUNCH(TAG)                                                                                       \
   bsc_lpj_gram_kernel<TAG><<<grid, 256, 0, c->stream>>>(b.states, b.counts, bmat, b.yy, c->G, b.N, b.C, b.shared, \
-                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32)
+                                                        c->H, c->HW, c->dpar, b.out, b.ldo, b.col0, b.flags, c->err, dg, bf32, c->diag)
     if (b.tag == 0)
       GRAM_LAUNCH(0);
     else
@@ -2572,6 +2573,7 @@ static int refresh_after_update(evoamd_ctx *c) {
   } else if (!c->bsc_direct) {
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
     if (r) return r;
+    extract_diag_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->G, H, c->diag);
     r = launch_B(c);
     if (r) return r;
     c->B_valid = true;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const void *__restrict__ Bm_,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int shared, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32) {
+    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32, const double *__restrict__ Gd) {
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
   // float32 mode: B = Y W is stored in float (b_f32); the arithmetic stays double
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void bsc_lpj_gram_kernel(
           if (i < kd) {
             const double *Gh = G + (i64)idx[i] * H;
             s1 += Bn[idx[i]];
-            s3 += Gh[idx[i]];
+            s3 += Gd[idx[i]];  // diag(G) as a vector (bsc_lpj_gram2_kernel)
 #pragma unroll
             for (int j = i + 1; j < DIG_SLOTS; j++)
               if (j < kd) s2 += Gh[idx[j]];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
     const u64 *__restrict__ states, const int *__restrict__ counts, const void *__restrict__ Bm,
     const double *__restrict__ yy, const double *__restrict__ G, i64 N, int C, int H, int HW,
     const double *__restrict__ dpar, double *__restrict__ lpj_out, int ldo, int col0, unsigned *__restrict__ flags,
-    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32) {
+    int *__restrict__ err, const u64 *__restrict__ dig, int b_f32, const double *__restrict__ Gd) {
   extern __shared__ double Bs[];
   const double pre1 = dpar[DP_PRE1], pil_bar = dpar[DP_PILBAR];
   const i64 total = N * (i64)C;
@@ -290,7 +290,9 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
       if (i < k) {
         const double *Gh = G + (i64)idx[i] * H;
         s1 += Bn[idx[i]];
-        s3 += Gh[idx[i]];
+        // the diagonal from its own H-vector (same bits as G[h][h]): a table that stays in the vector L1, where the
+        // H x H matrix (8 MB at H = 1024) is an L2 / MALL gather -- and most states need nothing but diagonals
+        s3 += Gd[idx[i]];
 #pragma unroll
         for (int j = i + 1; j < BSC_KR; j++)
           if (j < k) s2 += Gh[idx[j]];
@@ -323,6 +325,12 @@ __global__ __launch_bounds__(512) void bsc_lpj_gram2_kernel(
     atomicOr(&flags[n], fl);
     atomicOr(&err[1], 1);
   }
+}
+
+// d[h] = M[h][h]
+__global__ __launch_bounds__(256) void extract_diag_kernel(const double *__restrict__ M, int H, double *__restrict__ d) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h < H) d[h] = M[(i64)h * H + h];
 }
 
 // Incomplete data: Y <- reliable ? Y : 0 (the reference's missing entries are NaN,
