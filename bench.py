@@ -47,6 +47,8 @@ CONFIGS = {  # BASELINE.json "configs": the whole job (N_total is split over the
     "c3": dict(algo="ebsc", D=64, H=256, S=128, N=50000, name="EBSC 8x8 patches D=64 H=256 S=128 N=50k f64"),
     "c4": dict(algo="es3c", D=256, H=512, S=200, N=100000, name="ES3C D=256 H=512 S=200 N=100k f64 (north-star shape)"),
     "c4shard": dict(algo="es3c", D=256, H=512, S=200, N=12500, name="ES3C D=256 H=512 S=200 N=12.5k (one eighth of c4) f64"),
+    "c4half": dict(algo="es3c", D=256, H=512, S=200, N=50000, name="ES3C D=256 H=512 S=200 N=50k (half of c4) f64"),
+    "c4quarter": dict(algo="es3c", D=256, H=512, S=200, N=25000, name="ES3C D=256 H=512 S=200 N=25k (a quarter of c4) f64"),
     "c5": dict(algo="ebsc", D=256, H=1024, S=256, N=200000, name="EBSC D=256 H=1024 S=256 N=200k (f64; the reference has no f32)"),
     "c5shard": dict(algo="ebsc", D=256, H=1024, S=256, N=25000, name="EBSC D=256 H=1024 S=256 N=25k (one eighth of c5) f64"),
     "c5f32": dict(algo="ebsc", D=256, H=1024, S=256, N=200000, f32=True,
