@@ -366,9 +366,13 @@ def free_port():
     return port
 
 
-def launch_ranks(n, argv, worker=None, timeout_s=None):
-    """Start `n` ranks of this script (or of `worker`, a command list, for the CPU test of this logic), wait,
-    return (rc, rank-0 stdout).  A non-zero exit of any rank is propagated; the others are then terminated."""
+def launch_ranks(n, argv, worker=None, timeout_s=None, poll_s=0.05, grace_s=5.0):
+    """Start `n` ranks of this script (or of `worker`, a command list, for the CPU test of this logic) and watch ALL of
+    them: returns (rc, rank-0 stdout).  Like `mpirun`, the job dies with its first failing rank -- the first child that
+    exits non-zero gets the others terminated (killed after `grace_s`) and its code returned at once, so a rank that
+    dies before or inside an RCCL collective cannot leave rank 0 (and this parent) blocked.  Rank 0's stdout is drained
+    by a thread so that a full pipe never stalls it.  The parent never touches the GPU."""
+    import threading
     port = free_port()
     nonce = "%d_%d" % (os.getpid(), int(time.time() * 1e3))
     procs = []
@@ -379,22 +383,41 @@ def launch_ranks(n, argv, worker=None, timeout_s=None):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = (worker or [sys.executable, os.path.abspath(__file__)]) + list(argv)
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, rc = b"", 0
-    t0 = time.time()
+    chunks = []
+
+    def drain():
+        for line in iter(procs[0].stdout.readline, b""):
+            chunks.append(line)
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    rc, t0 = 0, time.time()
     try:
-        out0, _ = procs[0].communicate(timeout=timeout_s)
-        rc = procs[0].returncode
-        for p in procs[1:]:
-            left = None if timeout_s is None else max(1.0, timeout_s - (time.time() - t0))
-            p.wait(timeout=left)
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if timeout_s is not None and time.time() - t0 > timeout_s:
+                rc = 124
+                break
+            time.sleep(poll_s)
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-    return rc, out0.decode(errors="replace")
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t1 = time.time()
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.1, grace_s - (time.time() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=2.0)
+    return rc, b"".join(chunks).decode(errors="replace")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -161,6 +161,9 @@ struct evoamd_ctx {
   size_t gemm_ws_n = 0;
   int pair_bins = 1;
   int gemm_streamk = 1;  // option "gemm_streamk": long-K 128-tile contraction as one resident-sized stream-K grid
+  int sk_spare = 0;  // option "sk_spare": workgroups per XCD the FORKED stream-K contraction leaves unlaunched, so that the
+                     // H x H elimination chain on the main stream finds free CU slots beside it (a persistent grid of
+                     // 2 workgroups per CU otherwise holds every slot until the product is done)
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
   double *census = nullptr;  // 4 doubles at the head of acc_base: overflow census of the earlier blocks of a chunked statistics pass
@@ -405,8 +408,14 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   evoamd_ctx *c = new evoamd_ctx();
   c->device = device;
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  {
+    // the main stream carries the latency-bound chains (Theta update, small launches), stream2 the forked MFMA
+    // contraction: the dispatcher serves the higher priority first whenever a CU slot is free
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo));
+  }
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
@@ -550,6 +559,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "sk_spare") == 0) {
+    if (value < 0 || value > 32) return fail(EVOAMD_E_INVALID, "sk_spare: 0 .. 32 workgroups per XCD");
+    c->sk_spare = value;
     return 0;
   }
   if (strcmp(name, "stats_chunks") == 0) {
@@ -1113,7 +1127,9 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
       real -= ts * (ts - 1) / 2;
     }
     const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
+    // forked beside the Theta-update chain (stats_compute): leave sk_spare slots per XCD to the chain's kernels
+    const int spare = (c->stream == c->stream2) ? c->sk_spare : 0;
+    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8 - spare);
     int segmax = 0;
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, real, &segmax) : nullptr;
     gemm_tn128_sk_f64<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0,

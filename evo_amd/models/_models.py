@@ -120,6 +120,7 @@ class Model:
         self._had_masks = False
         self._yrec_token = None
         self._resident = False   # K^n on the device is authoritative (sync_host=False only)
+        self._kn_uploads = 0     # how often _prepare() has uploaded my_suff_stat["ss"]
         self._acc = None         # statistics computed by E_step for the M_step of the same step()
         self._n_steps = 0
 
@@ -203,6 +204,7 @@ class Model:
         if upload_states and (self.sync_host or not self._resident):
             eng.upload_states(my_suff_stat["ss"])
             self._resident = True
+            self._kn_uploads += 1  # the lpj rows on the device no longer belong to this K^n
         return eng
 
     def _engine_matches(self):
@@ -600,9 +602,12 @@ class Model:
         ``model_params`` and the caller's K^n / lpj; adds my_data["y_reconstructed"] (_models.py:614-665).
         The reference loops over datapoints calling modelmean(); here the statistics pass writes E_q[s]
         (EBSC) / E_q[s o z] (ES3C) per datapoint and ONE f64 MFMA product with W^T gives every estimate."""
+        # _prepare() uploads K^n and sets _resident when the device copy was stale (first call, invalidate(), a new
+        # geometry): the lpj rows on the device are stale in exactly those cases, so decide BEFORE it runs
+        uploads = self._kn_uploads
         eng = self._prepare(my_suff_stat, my_data)
         self.E_step_precompute(model_params, my_suff_stat, my_data)
-        if self.sync_host or not self._resident:
+        if self.sync_host or self._kn_uploads != uploads:
             eng.upload_lpj(my_suff_stat["lpj"])
         if self._incomplete:
             eng.set_option("reconstruct_in_stats", 1)

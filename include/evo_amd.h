@@ -106,7 +106,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "gemm_workspace" (0/1, default 1): the stream-K workgroups store their partial tiles to a workspace and a second kernel
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
- * (measurement aid: tools/gemm_sweep.sh). */
+ * (measurement aid: tools/gemm_sweep.sh).
+ * "sk_spare" (0 .. 32): workgroups per XCD that the stream-K contraction does not launch while it runs on the second
+ * stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free CU slots. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */

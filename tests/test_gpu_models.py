@@ -737,6 +737,42 @@ def test_public_reconstruct_and_modelmean(engine, algo):
 
 
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_reconstruct_first_call_without_host_sync(engine, algo):
+    """reconstruct() of a sync_host=False model whose K^n is NOT yet resident (first call, after
+    invalidate(), after a reconfigure) must upload the caller's lpj together with K^n -- the statistics pass would
+    otherwise weight the states with whatever the device's lpj buffer holds."""
+    from evo_amd.models import BSC, SSSC
+    g = load_golden("recon_%s.npz" % algo)
+    D, H, S = int(g["D"]), int(g["H"]), int(g["S"])
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    Y, x = g["Y"], g["x"]
+    cls = BSC if algo == "ebsc" else SSSC
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in keys}
+    for k in ("pi", "sigma", "sigma2"):
+        if k in theta:
+            theta[k] = np.float64(theta[k])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool), "x": x}
+    np.random.seed(1000 + int(g["seed"]))
+    cls(D, H, S, engine=engine).E_step(theta, suff, my_data)  # the caller's K^n / lpj (host arrays)
+    want = g["t0_y_reconstructed"]
+    # poison the device's lpj rows: a different model's pass on the same engine geometry
+    other = dict(suff)
+    other["lpj"] = suff["lpj"] - 50.0 * np.arange(suff["lpj"].shape[1])[None, :]
+    other["ss"] = suff["ss"].copy()
+    d2 = {"y": Y, "x_infr": my_data["x_infr"], "x": x}
+    cls(D, H, S, engine=engine).reconstruct(d2, other, theta)
+    assert not np.allclose(d2["y_reconstructed"], want, rtol=1e-6, atol=1e-9)
+    model = cls(D, H, S, engine=engine, rng="device", sync_host=False)
+    for attempt in range(2):  # first call, then after invalidate()
+        d3 = {"y": Y, "x_infr": my_data["x_infr"], "x": x}
+        model.reconstruct(d3, suff, theta)
+        np.testing.assert_allclose(d3["y_reconstructed"], want, rtol=1e-8, atol=1e-9 * max(1.0, float(np.abs(want).max())))
+        cls(D, H, S, engine=engine).reconstruct(d2, other, theta)  # poison again
+        model.invalidate()
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 def test_device_mstep_absorbs_singular_update(engine, algo):
     """A latent that occurs in no state of any K^n makes the M-step's H x H system exactly singular.  The
     reference absorbs it (lstsq min-norm solution, bsc.py:237; inv -> LinAlgError -> pinv + noise,

@@ -297,6 +297,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line == {"n_gpus": 3, "argv": ["--steps", "2"]}
     rc, _ = bench.launch_ranks(2, ["--fail"], worker=[sys.executable, str(stub)], timeout_s=60)
     assert rc == 3
+    # a rank > 0 dies while rank 0 sits in a collective (here: sleeps "forever"): like mpirun, the launcher must kill the
+    # job at once and return the dead rank's code -- not wait for rank 0 (VERDICT r02 missing #5)
+    hang = tmp_path / "hang.py"
+    hang.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "if r == 2: time.sleep(0.3); sys.exit(7)\n"
+        "print('rank0 partial line' if r == 0 else '', flush=True)\n"
+        "time.sleep(600)\n")
+    import time
+    t0 = time.time()
+    rc, out = bench.launch_ranks(3, [], worker=[sys.executable, str(hang)], timeout_s=120)
+    assert rc == 7 and time.time() - t0 < 30.0
+    assert "rank0 partial line" in out
+    # and a rank killed by a signal (OOM killer: negative return code) is a failure too
+    sig = tmp_path / "sig.py"
+    sig.write_text(
+        "import os, signal, time\n"
+        "if os.environ['RANK'] == '1': os.kill(os.getpid(), signal.SIGKILL)\n"
+        "time.sleep(600)\n")
+    rc, _ = bench.launch_ranks(2, [], worker=[sys.executable, str(sig)], timeout_s=120)
+    assert rc == -9
     # the bare command line goes through the same function and never touches the GPU in the parent
     env = dict(os.environ, EVO_AMD_BENCH_WORKER=str(stub))
     env.pop("WORLD_SIZE", None)
