@@ -21,6 +21,7 @@
 #include "kernels_evolve.hpp"
 #include "kernels_mstep.hpp"
 #include "kernels_sssc.hpp"
+#include "kernels_sssc_quad.hpp"
 
 // ---------------------------------------------------------------------------------------
 // error handling
@@ -267,6 +268,17 @@ struct evoamd_ctx {
   i64 ovf_n = 0;
   double *Es = nullptr;  // BSC: (N,H); SSSC: columns D..D+H of c->Y (Ez follows)
   int *list1 = nullptr, *list2 = nullptr, *list3 = nullptr, *list_n = nullptr, *err = nullptr;
+  // ES3C census lists (kernels_sssc_quad.hpp): the resident states with 3..4 / 5..8 / > 8 active latents, built by ONE
+  // pass over the digests whenever K^n has changed (kn_gen) and shared by the statistics pass and the next pass over
+  // K^n; clist = 3 lists of LIST_SHARDS x list_cap(N S) entries, clist_n = their shard counters (4 x LIST_SHARDS, like
+  // list_n); ovf_rec = one record per resident state (only the listed ones are ever touched)
+  int *clist = nullptr, *clist_n = nullptr;
+  size_t clist_words = 0;
+  OvfRec *ovf_rec = nullptr;
+  size_t ovf_rec_n = 0;
+  unsigned long long kn_gen = 1, census_gen = 0;
+  int census_opt = 1;   // option "census_lists": 0 = round-2 level chains everywhere
+  int census_skip = 0;  // levels that passes over the CURRENT census did not launch (checked when it is rebuilt)
   size_t list_words = 0;  // capacity of each overflow list (ints)
   // scratch for single / shared evaluations
   double *tmp_y = nullptr, *tmp_lpj = nullptr;
@@ -460,7 +472,8 @@ static void free_all(evoamd_ctx *c) {
                   c->pies,   c->tmpA,    c->tmpB,    c->tmpC,    c->gjwork,  c->colpart,
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
-                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf};
+                  c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf,
+                  c->clist, c->clist_n, c->ovf_rec};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -559,6 +572,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "census_lists") == 0) {  // takes effect at the next evoamd_configure
+    c->census_opt = value != 0;
     return 0;
   }
   if (strcmp(name, "sk_spare") == 0) {
@@ -745,6 +762,20 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     int rl = ensure_lists(c, (i64)N * SC);
     if (rl) return rl;
     ALLOC(c->list_n, 4 * LIST_SHARDS);
+    if (c->clist) (void)hipFree(c->clist);
+    if (c->clist_n) (void)hipFree(c->clist_n);
+    if (c->ovf_rec) (void)hipFree(c->ovf_rec);
+    c->clist = c->clist_n = nullptr;
+    c->ovf_rec = nullptr;
+    c->clist_words = c->ovf_rec_n = 0;
+    if (c->census_opt && N * (i64)S > 0) {
+      c->clist_words = list_cap((i64)N * S) * LIST_SHARDS;
+      ALLOC(c->clist, 3 * c->clist_words);
+      ALLOC(c->clist_n, 4 * LIST_SHARDS);
+      HIP_TRY(hipMemsetAsync(c->clist_n, 0, 4 * LIST_SHARDS * sizeof(int), c->stream));
+      c->ovf_rec_n = (size_t)N * S;
+      ALLOC(c->ovf_rec, c->ovf_rec_n);
+    }
   }
   {
     // pair bins of the statistics pass: 2 rf folded rows x H columns per LDS tile
@@ -818,6 +849,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->pays_agreed = -1;
   c->pending_skip = 0;
   c->gen++;
+  c->kn_gen++;
+  c->census_gen = 0;
+  c->census_skip = 0;
   c->have_data = c->have_params = c->have_cand = c->rows_fresh = false;
   if (c->tmpWt) (void)hipFree(c->tmpWt);  // sized by (H, D): rebuilt on demand
   c->tmpWt = nullptr;
@@ -911,7 +945,10 @@ static int pack_to_device(evoamd_ctx *c, const uint8_t *host_bool, i64 nstates, 
   }
   HIP_TRY(hipMemcpyAsync(c->stage, host_bool, bytes, hipMemcpyHostToDevice, c->stream));
   pack_states_kernel<<<cdiv(nstates * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, nstates, c->H, c->HW);
-  if (dst == c->states) c->gen++;
+  if (dst == c->states) {
+    c->gen++;
+    c->kn_gen++;
+  }
   u64 *dg = dst == c->states ? c->dig : dst == c->cand ? c->cand_dig : nullptr;
   if (dg) digest_kernel<<<cdiv(nstates, 256), 256, 0, c->stream>>>(dst, dg, nstates, c->HW);
   HIP_TRY(hipGetLastError());
@@ -959,11 +996,12 @@ extern "C" int evoamd_upload_states_packed(evoamd_ctx *c, const uint8_t *packed,
   }
   HIP_TRY(hipMemcpyAsync(c->stage, packed, bytes, hipMemcpyHostToDevice, c->stream));
   u64 *dst = c->states + (size_t)n0 * c->S * c->HW;
-  words_from_packbits_kernel<<<cdiv(ns * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, ns, PB, c->HW);
+  words_from_packbits_kernel<<<cdiv(ns * c->HW, 256), 256, 0, c->stream>>>(c->stage, dst, ns, PB, c->HW, c->H);
   if (c->dig) digest_kernel<<<cdiv(ns, 256), 256, 0, c->stream>>>(dst, c->dig + (size_t)n0 * c->S, ns, c->HW);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->gen++;
+  c->kn_gen++;
   c->need_known = false;
   return 0;
 }
@@ -1521,6 +1559,33 @@ static int zero_lists(evoamd_ctx *c) {
 
 static int skip_mask(const bool need[3]) { return (need[0] ? 0 : 1) | (need[1] ? 0 : 2) | (need[2] ? 0 : 4); }
 
+// Census mode (kernels_sssc_quad.hpp): ES3C on complete data with digests -- the resident states above two active latents
+// come from lists built once per K^n instead of being appended by the main kernels.
+static bool census_mode(const evoamd_ctx *c) {
+  return c->model == EVOAMD_MODEL_SSSC && c->clist && c->clist_n && c->ovf_rec && c->use_digest && c->dig && !c->mask_infr;
+}
+
+static int ensure_census(evoamd_ctx *c) {
+  if (c->census_gen == c->kn_gen) return 0;
+  const i64 total = c->N * (i64)c->S;
+  // a level that no pass over the OLD census launched must have had an empty list; then fresh counters
+  check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
+  c->census_skip = 0;
+  unsigned grid = cdiv(total, CENSUS_T * CENSUS_PPT);
+  if (grid > (unsigned)(8 * c->n_cu)) grid = (unsigned)(8 * c->n_cu);
+  SpanGuard g(c, KID_MISC);
+  census_kernel<<<grid, CENSUS_T, 0, c->stream>>>(c->dig, total, c->clist, (i64)c->clist_words, c->clist_n, (int)list_cap(total));
+  HIP_TRY(hipGetLastError());
+  DBG_SYNC(c, "census");
+  c->census_gen = c->kn_gen;
+  return 0;
+}
+
+// grid of a quad level (16 states per wave, 64 per workgroup) from the expected number of listed states
+static unsigned quad_grid(const evoamd_ctx *c, int level, int tag, i64 total, unsigned cap) {
+  return level_grid(c, level, tag, total * 4, cap, 64);
+}
+
 #define MAIN_LPJ_LDS_MAX (48 * 1024)  // three 512-thread workgroups (3072 pairs) per CU at the limit
 
 template <int TAG>
@@ -1547,6 +1612,53 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
   const ListOut o1 = {c->list1, c->list_n + 0 * LIST_SHARDS, cap}, o2 = {c->list2, c->list_n + 1 * LIST_SHARDS, cap},
                 o3 = {c->list3, c->list_n + 2 * LIST_SHARDS, cap};
   const ListIn i1 = {o1.items, o1.counts, cap}, i2 = {o2.items, o2.counts, cap}, i3 = {o3.items, o3.counts, cap};
+  const ListOut none_o = {nullptr, nullptr, 0};
+  // pass over the resident K^n with census lists: the main kernel appends nothing, the quad levels read the lists
+  const bool census = TAG == 0 && a.states == c->states && !a.shared && census_mode(c) && (a.H % 2) == 0 &&
+                      ((size_t)(1024 / a.C + 2) * a.H + (a.H <= 512 ? (size_t)4 * a.H : 0)) * sizeof(double) <= MAIN_LPJ_LDS_MAX;
+  if (census) {
+    r = ensure_census(c);
+    if (r) return r;
+    c->census_skip |= skip_mask(need);
+    const int ccap = (int)list_cap(total);
+    const ListIn cA = {c->clist, c->clist_n, ccap}, cB = {c->clist + c->clist_words, c->clist_n + LIST_SHARDS, ccap},
+                 cC = {c->clist + 2 * c->clist_words, c->clist_n + 2 * LIST_SHARDS, ccap};
+    {
+      SpanGuard g(c, kid_main);
+      const int rows_cap = 1024 / a.C + 2;
+      const int stage_dg = a.H <= 512;
+      const size_t lds = ((size_t)rows_cap * a.H + (stage_dg ? (size_t)4 * a.H : 0)) * sizeof(double);
+      const int grid = (int)cdiv(total, 1024);
+      REQUIRE(lds <= MAIN_LPJ_LDS_MAX, "ES3C lpj: H too large for the staged B rows");
+#define MAIN_NOAPP(HWT) sssc_main_lpj_kernel<TAG, 512, HWT, 2, false><<<grid, 512, lds, c->stream>>>(a, none_o, rows_cap, stage_dg)
+      switch (a.HW) {
+        case 1: MAIN_NOAPP(1); break;
+        case 2: MAIN_NOAPP(2); break;
+        case 4: MAIN_NOAPP(4); break;
+        case 8: MAIN_NOAPP(8); break;
+        case 16: MAIN_NOAPP(16); break;
+        default: MAIN_NOAPP(0); break;
+      }
+#undef MAIN_NOAPP
+      HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "sssc lpj main (census)");
+    }
+    if (need[0] || need[1] || need[2]) {
+      SpanGuard g(c, KID_LPJ_OVF);
+      if (need[0])
+        sssc_quad_kernel<1, 0, TAG><<<quad_grid(c, 0, TAG, total, 2048), 256, 0, c->stream>>>(a, cA, none_o, o3, PairBins{}, nullptr);
+      DBG_SYNC(c, "sssc lpj quad level 3..4");
+      if (need[1])
+        sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, cB, none_o, o3, PairBins{}, nullptr);
+      DBG_SYNC(c, "sssc lpj quad level 5..8");
+      // the pivoting wavefront kernel: resident states above eight latents, then what the quads passed on
+      sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+          a, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_o, SSSC_KCAP, i3);
+      HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "sssc lpj census levels");
+    }
+    return 0;
+  }
   c->pending_skip |= skip_mask(need);
   {
     SpanGuard g(c, kid_main);
@@ -1851,6 +1963,7 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
   REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
   HIP_TRY(hipSetDevice(c->device));
   c->gen++;
+  c->kn_gen++;
   {
     SpanGuard g(c, KID_VARY_KN);
 #define VK_LAUNCH(SPL, CPL)                                                                                   \
@@ -2096,6 +2209,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   int nchunks = 1;
   if (!masked && !gemm_timed && c->overlap_gemm != 0 && c->stats_chunks > 1 && (gemm_flops >= 8e9 || c->overlap_gemm == 2))
     nchunks = std::min<int>(c->stats_chunks, nblk);
+  const bool census = census_mode(c) && !masked;
+  if (census) nchunks = 1;  // the census lists cover the whole shard
   const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
   nchunks = (int)cdiv(N, rows_per_chunk);
   const bool second_stream = fork_gemm || nchunks > 1;
@@ -2270,6 +2385,28 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         census_lists_kernel<<<1, 256, 0, c->stream>>>(c->list_n, LIST_SHARDS, skip_mask(need), c->err, c->census);
         HIP_TRY(hipGetLastError());
       }
+      const int ccap = (int)list_cap(total);
+      const ListIn cA = {c->clist, c->clist_n, ccap}, cB = {c->clist + c->clist_words, c->clist_n + LIST_SHARDS, ccap},
+                   cC = {c->clist + 2 * c->clist_words, c->clist_n + 2 * LIST_SHARDS, ccap};
+      if (census) {
+        // the quad levels FIRST: records of the listed states (read back by the wave-per-datapoint kernel), their
+        // diagonal second moments into the column-sum slices, their pairs into the bins (regions shared by workgroup index)
+        r = ensure_census(c);
+        if (r) return r;
+        if (need[0] || need[1]) {
+          SpanGuard g(c, KID_STATS_OVF);
+          const int tg = c->cand_from_device ? 1 : 2;
+          const unsigned gcap = pb.ent ? (unsigned)std::min(2048, pb.nwg) : 2048u;
+          const size_t dl = (size_t)H * sizeof(double);
+          // (the bins' region counters are zero here: pair_bins_reduce_kernel clears what it reads)
+          if (need[0])
+            sssc_quad_kernel<1, 1, 2><<<quad_grid(c, 0, tg, total, gcap), 256, dl, c->stream>>>(sc, cA, none_out, o3, pb, c->ovf_rec);
+          if (need[1])
+            sssc_quad_kernel<2, 1, 2><<<quad_grid(c, 1, tg, total, gcap), 256, dl, c->stream>>>(sc, cB, none_out, o3, pb, c->ovf_rec);
+          HIP_TRY(hipGetLastError());
+          DBG_SYNC(c, "sssc stats quad levels");
+        }
+      }
       {
         // one wave per datapoint, persistent workgroups: W x 2 H doubles of rows + 3 H of column accumulators in LDS
         int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) <= 150 * 1024 ? 4 : 1;
@@ -2292,7 +2429,14 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         // doubles the kernel's critical path at small N), a persistent grid-stride loop beyond
         int sgrid = (int)std::min<i64>(cdiv(nc, Wv), (i64)c->n_cu * per_cu * 4);
         if (pb.ent && sgrid > pb.nwg) sgrid = pb.nwg;  // one private region per producer workgroup and bin
-#define STATS_WAVE(HWT) sssc_stats_wave_kernel<HWT, 4><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage)
+#define STATS_WAVE(HWT)                                                                                  \
+  do {                                                                                                   \
+    if (census)                                                                                          \
+      sssc_stats_wave_kernel<HWT, 4, true><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage, c->ovf_rec); \
+    else                                                                                                 \
+      sssc_stats_wave_kernel<HWT, 4><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage);                  \
+  } while (0)
+        REQUIRE(!census || Wv == 4, "census lists need the 4-wave statistics kernel (option stats_waves)");
         if (Wv == 1) {
           sssc_stats_wave_kernel<0, 1><<<sgrid, 64, lds, c->stream>>>(sc, o1, pb, stage);
         } else if (Wv == 8) {
@@ -2315,7 +2459,16 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats main");
       }
-      if (need[0] || need[1] || need[2]) {
+      if (census) {
+        if (need[0] || need[1] || need[2]) {  // resident states above eight latents + what the quads passed on (atomics)
+          SpanGuard g(c, KID_STATS_OVF);
+          const int tg = c->cand_from_device ? 1 : 2;
+          sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+              sc, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_out, SSSC_KCAP, i3);
+          HIP_TRY(hipGetLastError());
+          DBG_SYNC(c, "sssc stats wavefront level (census)");
+        }
+      } else if (need[0] || need[1] || need[2]) {
         SpanGuard g(c, KID_STATS_OVF);
         const int tg = c->cand_from_device ? 1 : 2;  // how much is known about the final K^n
         const size_t cs_lds = sc.cs ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
@@ -2425,8 +2578,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   {
     SpanGuard g(c, KID_MISC);
     tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
-                                          c->model == EVOAMD_MODEL_SSSC ? c->list_n : nullptr, LIST_SHARDS, skipped,
-                                          c->census);
+                                          c->model == EVOAMD_MODEL_SSSC ? (census ? c->clist_n : c->list_n) : nullptr,
+                                          LIST_SHARDS, skipped, c->census, census ? 1 : 0);
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "stats contraction + tail");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;

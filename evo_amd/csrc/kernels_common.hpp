@@ -41,8 +41,10 @@ __global__ void check_lists_kernel(int *__restrict__ list_n, int n_list, int ski
 }
 
 // np.packbits rows (nstates, PB = ceil(H/8) bytes, latent h in byte h/8 at bit 7-(h%8)) <-> device words.
+// Bits at positions >= H of the last byte (np.packbits pads with zeros; a caller's buffer may not) are dropped: every
+// kernel downstream takes popcounts and latent indices from these words.
 __global__ __launch_bounds__(256) void words_from_packbits_kernel(const uint8_t *__restrict__ in, u64 *__restrict__ out,
-                                                                  i64 nstates, int PB, int HW) {
+                                                                  i64 nstates, int PB, int HW, int H) {
   const i64 idx = (i64)blockIdx.x * 256 + threadIdx.x;
   if (idx >= nstates * HW) return;
   const i64 st = idx / HW;
@@ -52,6 +54,8 @@ __global__ __launch_bounds__(256) void words_from_packbits_kernel(const uint8_t 
   if (nb > 8) nb = 8;
   u64 v = 0;
   for (int b = 0; b < nb; b++) v |= (u64)p[b] << (56 - 8 * b);
+  const int valid = H - 64 * w;  // latents this word holds
+  if (valid < 64) v &= valid > 0 ? ~0ull << (64 - valid) : 0ull;
   out[idx] = v;
 }
 __global__ __launch_bounds__(256) void packbits_from_words_kernel(const u64 *__restrict__ in, uint8_t *__restrict__ out,
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(256) void gemm_nn_naive_f32(const float *__restrict
 __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, double N, double *__restrict__ dpar,
                                                    unsigned *__restrict__ flags, i64 nflags3, i64 nper,
                                                    int *__restrict__ err, int *__restrict__ list_n, int nshards,
-                                                   int skipped_mask, const double *__restrict__ census) {
+                                                   int skipped_mask, const double *__restrict__ census,
+                                                   int census_lists = 0) {
   __shared__ int cnt[3];
   __shared__ int lvl[3];
   const int t = threadIdx.x;
@@ -330,7 +335,9 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
     }
   }
   __syncthreads();
-  if (list_n)
+  // census_lists: list_n are the counters of the census lists (3..4 / 5..8 / > 8 active latents; kernels_sssc_quad.hpp),
+  // which the next pass over K^n reads again: not cleared here
+  if (list_n && !census_lists)
     for (int i = t; i < 4 * nshards; i += 256) list_n[i] = 0;
   if (t == 0) {
     tail[0] = dpar[DP_FS];
@@ -345,9 +352,15 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
     dpar[DP_ECNT1] = 0.0;
     if (list_n) {
       // census: what the earlier chunks of a chunked statistics pass counted (census_lists_kernel)
-      dpar[DP_NGT2] = (double)lvl[0] + (census ? census[0] : 0.0);
-      dpar[DP_NGT4] = (double)lvl[1] + (census ? census[1] : 0.0);
-      dpar[DP_NGT8] = (double)lvl[2] + (census ? census[2] : 0.0);
+      if (census_lists) {  // disjoint classes -> "more than 2 / 4 / 8"
+        dpar[DP_NGT2] = (double)lvl[0] + (double)lvl[1] + (double)lvl[2];
+        dpar[DP_NGT4] = (double)lvl[1] + (double)lvl[2];
+        dpar[DP_NGT8] = (double)lvl[2];
+      } else {
+        dpar[DP_NGT2] = (double)lvl[0] + (census ? census[0] : 0.0);
+        dpar[DP_NGT4] = (double)lvl[1] + (census ? census[1] : 0.0);
+        dpar[DP_NGT8] = (double)lvl[2] + (census ? census[2] : 0.0);
+      }
       // level j+1 consumes list j; if it was skipped its list must be empty
       int lost = 0;
       for (int j = 0; j < 3; j++)

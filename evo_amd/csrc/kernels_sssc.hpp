@@ -38,6 +38,16 @@ struct __attribute__((aligned(64))) PairEntry {
 __device__ __forceinline__ bool pair_singular_L(double L) { return L == __builtin_inf(); }
 __device__ __forceinline__ bool pair_singular_lam(double l00) { return !(fabs(l00) <= 1.7976931348623157e308); }
 
+// What a listed state (3..8 active latents; kernels_sssc_quad.hpp) adds to the rows of its datapoint: slot n S + c of
+// a (N S) array, written by the quad kernels and read back by the lane of the wave-per-datapoint kernel that owns the state.
+struct __attribute__((aligned(16))) OvfRec {
+  unsigned short idx[8];  // active latents, ascending (first k valid)
+  double qn;              // posterior weight q_ns / sum_s q_ns (0: the state adds nothing through this record)
+  double pad;
+  double z[8];            // qn * kappa_i
+};
+static_assert(sizeof(OvfRec) == 96, "OvfRec is six 16-byte loads");
+
 #define CS_SLICES 16
 struct SsscArgs {
   const u64 *states;     // (shared ? 1 : N) x C x HW
@@ -593,7 +603,9 @@ __device__ __forceinline__ void append_end(const ListOut &lo, int shard, const i
 // p).  With one pair per thread the c2 launch is 1.22 "rounds" of resident threads (640k pairs on
 // 256 x 2048 slots) and its tail round costs as much as the full one; two pairs per thread make it a
 // single round with twice the loads in flight per wave.
-template <int TAG, int BS, int HWT, int PPT>
+// APPEND = false (pass over the resident K^n with census lists, kernels_sssc_quad.hpp): states above two active latents
+// are simply left out -- the census lists name them already.
+template <int TAG, int BS, int HWT, int PPT, bool APPEND = true>
 __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut lo, int rows_cap, int stage_dg) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double smem[];
@@ -668,7 +680,10 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
     pe[p] = a.PT[pair ? (i64)idx0[p] * a.H + idx1[p] : 0];  // idx0 < idx1
   }
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
-  append_begin<BS, PPT>(lo, shard, tv, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
+  if (APPEND)
+    append_begin<BS, PPT>(lo, shard, tv, over, ovf_buf, ovf_ctl);  // its barriers also publish the staged tables
+  else
+    lds_barrier();
   const double4 *D1t = stage_dg ? DGs : a.D1;
   const double s = a.s2inv;
 #pragma unroll
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
       }
     }
   }
-  append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
+  if (APPEND) append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
 }
 
 // Main statistics pass over the resident K^n (sssc.py:553-611), states with |A| <= 2 (the others go to the
@@ -732,8 +747,12 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
 // coalesced load per wave and datapoint) are staged in LDS when `stage` is set and the gathers become LDS reads.
 // Dynamic LDS: W x 2 H doubles (Es / Ez row of each wave's datapoint) + 3 H doubles (accumulators)
 //              [+ W x H doubles (B rows) + H double4 (D1) when stage].
-template <int HWT, int W>
-__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage) {
+// CEN (census mode, kernels_sssc_quad.hpp): no overflow list is built; the quad kernels ran BEFORE this kernel and left
+// one record per state with 3..8 active latents (rec[n S + c]) and their entries in the pair bins (gcnt): a lane that
+// owns such a state adds the record to its wave's LDS rows, so no kernel adds to the [Es | Ez] rows with global atomics.
+template <int HWT, int W, bool CEN = false>
+__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage,
+                                                                                const OvfRec *__restrict__ rec = nullptr) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double wrows[];
   __shared__ int bcnt[PB_MAX_BINS];
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
   if (HWT > 0 || stage)
     for (int i = threadIdx.x; i < H; i += 64 * W) d1s[i] = a.D1[i];
   if (binned)
-    for (int i = threadIdx.x; i < pb.nb; i += 64 * W) bcnt[i] = 0;
+    for (int i = threadIdx.x; i < pb.nb; i += 64 * W) bcnt[i] = CEN ? pb.gcnt[(size_t)i * pb.nwg + blockIdx.x] : 0;
   __syncthreads();
   const int shard = (int)(blockIdx.x & (LIST_SHARDS - 1));
   const double s = a.s2inv;
@@ -868,15 +887,31 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
 #pragma unroll
       for (int u = 0; u < RG; u++) {
         over[u] = live[u] && k[u] > 2;
-        const u64 om = __ballot(over[u]);
-        my_off[u] = n_over + __popcll(om & ((1ull << lane) - 1ull));
-        n_over += __popcll(om);
+        my_off[u] = 0;
+        if (!CEN) {
+          const u64 om = __ballot(over[u]);
+          my_off[u] = n_over + __popcll(om & ((1ull << lane) - 1ull));
+          n_over += __popcll(om);
+        }
       }
-      const bool o_direct = n_over > OVB;
+      const bool o_direct = !CEN && n_over > OVB;
       int obase = 0;
       if (o_direct) {  // uniform
         if (lane == 0) obase = atomicAdd(&lo.counts[shard], n_over);
         obase = __shfl(obase, 0, 64);
+      }
+      // census mode: the record of this lane's FIRST listed state of the group is requested together with the pair-table
+      // entries (unconditionally: the datapoint's slot 0 where there is none); further ones (rare) after the group
+      int ofirst = -1;
+      bool omore = false;
+      OvfRec orec = {};
+      if (CEN) {
+#pragma unroll
+        for (int u = RG - 1; u >= 0; u--)
+          if (over[u] && k[u] <= 8) {
+            omore = ofirst >= 0;
+            ofirst = u;
+          }
       }
       // phase B: the pair-table entries of the group (harmless entry 0 where unused), then the next datapoint
       bool act[RG], pair[RG];
@@ -886,6 +921,21 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
         act[u] = live[u] && !over[u] && k[u] > 0;
         pair[u] = act[u] && k[u] == 2;
         pe[u] = a.PT[pair[u] ? (i64)idx0[u] * H + idx1[u] : 0];
+      }
+      if (CEN) {
+        const OvfRec *rp = rec + (size_t)(n * a.C) + (ofirst >= 0 ? c0 + 64 * ofirst + lane : 0);
+        const uint4 *r4 = (const uint4 *)rp;
+        uint4 w0 = r4[0], w1 = r4[1], w2 = r4[2], w3 = r4[3], w4 = r4[4], w5 = r4[5];
+        *(uint4 *)orec.idx = w0;
+        orec.qn = __hiloint2double((int)w1.y, (int)w1.x);
+        orec.z[0] = __hiloint2double((int)w2.y, (int)w2.x);
+        orec.z[1] = __hiloint2double((int)w2.w, (int)w2.z);
+        orec.z[2] = __hiloint2double((int)w3.y, (int)w3.x);
+        orec.z[3] = __hiloint2double((int)w3.w, (int)w3.z);
+        orec.z[4] = __hiloint2double((int)w4.y, (int)w4.x);
+        orec.z[5] = __hiloint2double((int)w4.w, (int)w4.z);
+        orec.z[6] = __hiloint2double((int)w5.y, (int)w5.x);
+        orec.z[7] = __hiloint2double((int)w5.w, (int)w5.z);
       }
       if (first) {
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch behind the gathers in the memory queue
@@ -944,7 +994,35 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
           }
         }
       }
-      if (n_over) {  // uniform
+      if (CEN) {
+        // listed states (3..8 active latents): what the quad kernels computed for them, into this datapoint's rows
+        auto add_rec = [&](const OvfRec &r, int kk) {
+          if (r.qn != 0.0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (i < kk) {
+                const int h = (int)r.idx[i];
+                unsafeAtomicAdd(&rowS[h], r.qn);
+                unsafeAtomicAdd(&rowZ[h], r.z[i]);
+              }
+          }
+        };
+        if (ofirst >= 0) {
+          int kk = 0;
+#pragma unroll
+          for (int u = 0; u < RG; u++) kk = (u == ofirst) ? k[u] : kk;
+          add_rec(orec, kk);
+        }
+        if (__ballot(omore) != 0ull) {  // uniform, rare: a lane with a second listed state in this group
+#pragma unroll
+          for (int u = 1; u < RG; u++)
+            if (over[u] && k[u] <= 8 && u != ofirst) {
+              const OvfRec r2 = rec[(size_t)(n * a.C) + c0 + 64 * u + lane];
+              add_rec(r2, k[u]);
+            }
+        }
+      }
+      if (!CEN && n_over) {  // uniform
 #pragma unroll
         for (int u = 0; u < RG; u++)
           if (over[u]) {
@@ -1021,12 +1099,15 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 // T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
 // TAG as in sssc_small_kernel: profilers then list the levels of the pass over K^n (0), of the candidate batch (1)
 // and everything else (2) under different names.
+// li2 (optional): a second list served behind the first (census mode: the resident states above eight latents, then
+// the states the quad kernels could not eliminate without row exchanges).
 template <int MODE, int TAG = 2>
-__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc) {
+__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc, ListIn li2 = ListIn{nullptr, nullptr, 0}) {
   a.s2inv = a.dpar[DP_S2INV];
   // every barrier below orders LDS traffic only (the k x k system lives in LDS): lds_barrier() does not
   // wait for the previous state's global atomics / stores the way __syncthreads() would
   __shared__ int prefix[LIST_SHARDS + 1];
+  __shared__ int prefix2[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   double *Tm = lds;
   double *Pm = Tm + kc * kc;
@@ -1038,9 +1119,10 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
   double *fv = wv + kc;
   int *idx = (int *)(fv + kc);
   const int lane = threadIdx.x;
-  const i64 total = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
+  const i64 total1 = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
+  const i64 total = total1 + (li2.items ? (i64)list_prefix(li2, prefix2) : 0);
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
-    const i64 e = li.items ? (i64)list_fetch(li, prefix, t) : t;
+    const i64 e = t >= total1 ? (i64)list_fetch(li2, prefix2, t - total1) : (li.items ? (i64)list_fetch(li, prefix, t) : t);
     const i64 n = e / a.C;
     const int c = (int)(e - n * a.C);
     if (a.counts && c >= a.counts[n]) continue;  // uniform

@@ -107,6 +107,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "census_lists" (0/1, default 1; read by the next evoamd_configure): ES3C on complete data with digests -- the resident
+ * states with 3..4 / 5..8 / more than 8 active latents are listed by one pass over the digests per K^n (shared by the
+ * statistics pass and the next pass over K^n) and served by the four-lanes-per-state kernels; 0: the round-2 chains
+ * (lists appended by the main kernels, K = 4 / K = 8 register kernels, wavefront kernel).
  * "sk_spare" (0 .. 32): workgroups per XCD that the stream-K contraction does not launch while it runs on the second
  * stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free CU slots. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);

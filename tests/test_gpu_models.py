@@ -263,8 +263,15 @@ def test_state_digest_matches_word_path(engine, algo, H, S):
     F1, ss1, l1, _ = run(1, False)
     F0, ss0, l0, _ = run(0, False)
     np.testing.assert_array_equal(ss1, ss0)
-    np.testing.assert_array_equal(l1, l0)
-    np.testing.assert_array_equal(F1, F0)
+    if algo == "ebsc":
+        np.testing.assert_array_equal(l1, l0)
+        np.testing.assert_array_equal(F1, F0)
+    else:
+        # round 3: with digests the ES3C states above two latents run on the census lists + four-lanes-per-state
+        # kernels (unpivoted Gauss-Jordan per quad), without them on the round-2 register / wavefront kernels (LU
+        # with row exchanges): the same K^n, lpj to rounding
+        np.testing.assert_allclose(l1, l0, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(F1, F0, rtol=1e-13, atol=0)
     F1, _, _, t1 = run(1, True)
     F0, _, _, t0 = run(0, True)
     np.testing.assert_allclose(F1, F0, rtol=1e-9)
