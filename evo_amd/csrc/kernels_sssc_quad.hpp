@@ -114,7 +114,7 @@ __device__ __forceinline__ double sel4(int t, double a0, double a1, double a2, d
 
 // The k x k system of one state on a quad.  t = lane & 3; idx[i] = i-th active latent (0 beyond k), cidx[j] = latent of
 // my column t C + j (0 beyond k); Bn = row n of B = Y W.  Returns lpj in `val` (MODE 0) and, in MODE 1, kappa of every
-// latent (kap_all) and Lam[i][j] = Lam_A[i][t C + j]; hard = a pivot failed |d| >= max |column below| / 4 (or was
+// latent (kap_all) and Lam[i][j] = Lam_A[i][t C + j]; hard = a pivot failed the scaled threshold test (or was
 // 0 / NaN): the caller hands the state to the pivoting kernel.  Register budget (C = 2): the columns of G_A, Psi_A
 // and T (3 x 32) are the peak, while T is formed; sched_barriers keep the unrolled steps from being interleaved
 // (interleaved, the broadcasts of several steps are live at once: 256 registers + scratch).
@@ -201,6 +201,30 @@ __device__ __forceinline__ void quad_solve(const SsscArgs &a, const int t, const
   for (int r = 0; r < K; r++)
 #pragma unroll
     for (int j = 0; j < C; j++) Tc[r][j] = fma(s, Tc[r][j], (r == t * C + j) ? 1.0 : 0.0);
+  // Row equilibration by powers of two (exact).  T = Psi_A (Psi_A^-1 + G_A / sigma2): with per-latent slab variances an
+  // order of magnitude apart the entries below a pivot dwarf it although the elimination (which commutes with row
+  // scaling) is as benign as on the symmetric factor -- an unscaled pivot test sent every fifth state to the pivoting
+  // kernel.  Rows of [T | rhs | Psi_A] scaled to max_j |T[r][j]| in [1/2, 1): the plain threshold test below is then
+  // scaled partial pivoting, x and Lam_A are unchanged, log|det T| gets the exponents back.
+  int esum = 0;
+#pragma unroll
+  for (int r = 0; r < K; r++) {
+    double m = fabs(Tc[r][0]);
+#pragma unroll
+    for (int j = 1; j < C; j++) m = fmax(m, fabs(Tc[r][j]));
+    m = fmax(m, dpp_move<0xB1, 0xF>(m));
+    m = fmax(m, dpp_move<0x4E, 0xF>(m));
+    int ex = 0;
+    (void)frexp(m, &ex);
+    ex = (m > 0.0 && m < 1.7976931348623157e308) ? ex : 0;  // zero / non-finite row: leave it to the pivot test
+    esum += ex;
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+      Tc[r][j] = ldexp(Tc[r][j], -ex);
+      if (MODE == 1) Pc[r][j] = ldexp(Pc[r][j], -ex);
+    }
+    rhs[r] = ldexp(rhs[r], -ex);
+  }
   // Gauss-Jordan in natural order on [T | rhs | Psi_A]; row p is scaled by 1 / pivot as soon as it has been used
   double vq = 0.0;   // lpj: the quadratic form v^T Lam_A v comes out of the elimination as the Schur complement of a
                      // bordered system [T, Psi_A v; v^T, 0] -- v stays distributed over the quad's columns
@@ -255,7 +279,7 @@ __device__ __forceinline__ void quad_solve(const SsscArgs &a, const int t, const
   // rhs = Lam_A v now
   const double quad = -vq;
   if (MODE == 0) {
-    val = -0.5 * (log(fabs(det)) + (rr * s - quad * s * s)) + pb;
+    val = -0.5 * (log(fabs(det)) + (double)esum * 0.6931471805599453094 + (rr * s - quad * s * s)) + pb;
   } else {
     val = 0.0;
 #pragma unroll
@@ -286,7 +310,7 @@ struct StageL {  // lpj mode
 // Everything a state needs after its elimination (entry, weight, latents) waits in LDS: across quad_solve only the
 // solve's own registers are live.
 template <int C, int MODE, int TAG>
-__global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : (MODE == 0 ? 3 : 2))) void sssc_quad_kernel(
+__global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_quad_kernel(
     SsscArgs a, ListIn li, ListOut lo, ListOut hard_out, PairBins pb, OvfRec *__restrict__ rec) {
   constexpr int K = 4 * C;
   a.s2inv = a.dpar[DP_S2INV];

@@ -4,10 +4,12 @@ The reference appends one row per call to an extendable, zlib-compressed HDF5 ar
 (autotable.py:93-131, 232-270): ``tbl.append("F", F)`` grows the array ``/F`` by one row whose shape is the
 value's.  This class keeps that interface and, when PyTables is importable, that on-disk format (same node
 names, atoms, filters), so a file written here reads back with the reference's own tooling.  PyTables is not
-part of this image; without it the rows are buffered and written as ``<stem>.npz`` on ``close()`` (one array
-per table, rows stacked along axis 0) -- same content, NumPy container."""
+part of this image; without it the rows go to ``<stem>.npz`` (one array per table, rows stacked along axis 0; same
+content, NumPy container): a warning names that file once, and the container is rewritten every ``flush_every`` appends
+and on ``close()``, so a run that dies keeps all but its last few epochs."""
 import os
 import sys
+import warnings as _warnings
 
 import numpy as np
 
@@ -18,8 +20,10 @@ except Exception:  # not installed (this image): NumPy container instead
 
 
 class AutoTable:
-    def __init__(self, fname=None, compression_level=1, rwmode="w", warnings=True):
+    def __init__(self, fname=None, compression_level=1, rwmode="w", warnings=True, flush_every=64):
         self.warnings = warnings
+        self.flush_every = int(flush_every)
+        self._pending = 0
         if fname is None:
             fname = self._guess_fname()
         self.fname = fname
@@ -30,6 +34,9 @@ class AutoTable:
         self.h5 = _tables.open_file(fname, rwmode) if _tables is not None else None
         self.backend = "pytables" if self.h5 is not None else "npz"
         self._closed = False
+        if self.h5 is None and warnings:
+            _warnings.warn("PyTables is not installed: tables of %r are written to %r (NumPy container)" %
+                           (self.fname, self.npz_name()), RuntimeWarning, stacklevel=2)
 
     def __enter__(self):
         return self
@@ -53,6 +60,14 @@ class AutoTable:
         if self.h5 is not None:
             self.h5.close()
             return
+        self.flush()
+
+    def flush(self):
+        """NumPy container: (re)write ``<stem>.npz`` with every row appended so far."""
+        if self.h5 is not None:
+            self.h5.flush()
+            return
+        self._pending = 0
         out = {}
         for name, rows in self._rows.items():
             if self.types.get(name) is str:
@@ -111,6 +126,9 @@ class AutoTable:
         if not isinstance(value, str) and rows and (rows[0].shape != value.shape):
             raise TypeError('Wrong shape %s for "%s" field (rows are %s)' % (value.shape, name, rows[0].shape))
         rows.append(value if isinstance(value, str) else np.array(value))
+        self._pending += 1
+        if self.flush_every > 0 and self._pending >= self.flush_every:
+            self.flush()
 
     def assign(self, name, value):
         """Replace table ``name`` by the rows of ``value`` (autotable.py:133-173)."""

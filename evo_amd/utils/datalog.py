@@ -1,68 +1,82 @@
-"""DataLog: route named per-epoch values to handlers on rank 0 (reference: evo/utils/datalog.py).
+"""Per-epoch logging: named values are routed to sinks, on rank 0 only.
+
+What training scripts written for the reference call (examples/bars-test/main.py:150-162) keeps working:
 
     dlog = DataLog(comm)
-    dlog.set_handler(("F", "S_nunique"), TextPrinter)
-    dlog.set_handler("*", StoreToH5, "training.h5")
-    dlog.append_all({"F": F, "W": theta["W"]})      # examples/bars-test/main.py:150-162
+    dlog.set_handler(("F", "S_nunique"), TextPrinter)     # these two names -> stdout
+    dlog.set_handler("*", StoreToH5, "training.h5")       # every name -> one table each, one row per epoch
+    dlog.append_all({"F": F, "W": theta["W"]})
     dlog.close()
 
-Same calls, same rank-0-only behaviour (datalog.py:169-175); StoreToH5 writes through AutoTable (HDF5 via PyTables
-when that is installed, a NumPy container otherwise -- see autotable.py).  Off the timed path."""
-from os.path import isfile
-from time import strftime
+Behaviour kept from evo/utils/datalog.py:137-274: only rank 0 routes or writes anything; a sink registered for "*"
+receives every name; `append_all` hands each sink ONE call with exactly the names it listens to; `ignored(name)` tells a
+caller that nobody listens, so an expensive value need not be computed.  The design is this package's own: a routing
+table (name -> sinks, plus the wildcard sinks) instead of a policy list that is searched per call, and sinks that only
+have to provide `append`.  Off the timed path; StoreToH5 writes through AutoTable (HDF5 when PyTables is installed)."""
+import os
+import time
 
 from .autotable import AutoTable
 from .parallel import SerialComm, pprint
 
+WILDCARD = "*"
+
 
 class DataHandler:
-    """Base class of everything DataLog can hand values to (datalog.py:24-48)."""
+    """A sink.  Subclasses provide `append(name, value)`; the rest has defaults."""
 
-    def register(self, tblname):
-        pass
+    def register(self, names):
+        """Called once with the name(s) the sink was registered for."""
 
-    def append(self, tblname, value):
-        raise NotImplementedError
+    def append(self, name, value):
+        raise NotImplementedError("%s does not implement append()" % type(self).__name__)
 
-    def append_all(self, valdict):
-        for key, val in valdict.items():
-            self.append(key, val)
+    def append_all(self, values):
+        for name in values:
+            self.append(name, values[name])
 
-    def remove(self, tblname):
-        pass
+    def assign(self, name, value):
+        raise NotImplementedError("%s cannot replace a table" % type(self).__name__)
+
+    def remove(self, name):
+        """The sink stops receiving `name`."""
 
     def close(self):
-        pass
+        """Flush and release whatever the sink holds."""
 
 
 class StoreToH5(DataHandler):
+    """Rows into an AutoTable: a file name opens one, an AutoTable is used as it is, and no argument shares one
+    process-wide table between all sinks created that way (what the reference's scripts rely on)."""
+
     default_autotbl = None
 
     def __init__(self, destination=None, warnings=True):
-        """``destination``: file name, an AutoTable, or None (the process-wide default table, datalog.py:51-77)."""
         self.destination = destination
-        if isinstance(destination, AutoTable):
+        if destination is None:
+            if StoreToH5.default_autotbl is None:
+                StoreToH5.default_autotbl = AutoTable(warnings=warnings)
+            self.autotbl = StoreToH5.default_autotbl
+        elif isinstance(destination, AutoTable):
             self.autotbl = destination
-        elif isinstance(destination, str):
-            self.autotbl = AutoTable(destination, warnings=warnings)
-        elif destination is None:
-            self.autotbl = StoreToH5.default_autotbl or AutoTable(warnings=warnings)
+        elif isinstance(destination, (str, os.PathLike)):
+            self.autotbl = AutoTable(os.fspath(destination), warnings=warnings)
         else:
-            raise TypeError("Expects an AutoTable instance or a string as argument")
+            raise TypeError("StoreToH5: destination is a file name, an AutoTable or None, not %r" % type(destination).__name__)
         if StoreToH5.default_autotbl is None:
             StoreToH5.default_autotbl = self.autotbl
 
     def __repr__(self):
-        return "StoreToH5 into file %s" % self.destination
+        return "StoreToH5(%r)" % (self.autotbl.fname,)
 
-    def append(self, tblname, value):
-        self.autotbl.append(tblname, value)
+    def append(self, name, value):
+        self.autotbl.append(name, value)
 
-    def append_all(self, valdict):
-        self.autotbl.append_all(valdict)
+    def append_all(self, values):
+        self.autotbl.append_all(values)
 
-    def assign(self, tblname, value):
-        self.autotbl.assign(tblname, value)
+    def assign(self, name, value):
+        self.autotbl.assign(name, value)
 
     def close(self):
         self.autotbl.close()
@@ -71,112 +85,124 @@ class StoreToH5(DataHandler):
 
 
 class StoreToTxt(DataHandler):
-    def __init__(self, destination=None):
-        """``name = value`` lines into a text file (datalog.py:95-122)."""
-        if destination is None:
-            if isfile("terminal.txt"):
-                raise ValueError("Please enter a file name that does not already exist.")
-            destination = "terminal.txt"
-        self.txt_file = open(destination, "w")
+    """`name = value` lines into a text file (default: terminal.txt, which must not exist yet)."""
 
-    def append(self, tblname, value):
-        self.txt_file.write("%s = %s\n" % (tblname, value))
+    def __init__(self, destination=None):
+        if destination is None:
+            destination = "terminal.txt"
+            if os.path.exists(destination):
+                raise ValueError("StoreToTxt: %s exists already; name another file" % destination)
+        self._fh = open(destination, "w")
+
+    def append(self, name, value):
+        self._fh.write("%s = %s\n" % (name, value))
 
     def close(self):
-        self.txt_file.close()
+        if not self._fh.closed:
+            self._fh.close()
 
 
 class TextPrinter(DataHandler):
-    def append(self, tblname, value):
-        pprint("\t%s = %s " % (tblname, value))
+    """`name = value` on rank 0's stdout."""
 
-    def append_all(self, valdict):
-        for name, val in valdict.items():
-            pprint("\t%s = %s \n" % (name, val), end="")
+    def append(self, name, value):
+        pprint("\t%s = %s " % (name, value))
 
 
 class DataLog:
     def __init__(self, comm=None):
         self.comm = SerialComm() if comm is None else comm
-        self.policy = []  # ordered (table name, handler) pairs
-        self._lookup_cache = {}
+        self._routes = {}  # name -> sinks, in registration order
+        self._wild = []    # sinks registered for every name
+        self._sinks = []   # every sink once, in registration order
 
-    def _lookup(self, tblname):
-        if tblname not in self._lookup_cache:
-            self._lookup_cache[tblname] = [h for name, h in self.policy if name == tblname or name == "*"]
-        return self._lookup_cache[tblname]
+    # ---- routing ----------------------------------------------------------------------------
+    @property
+    def _root(self):
+        return self.comm.rank == 0
 
-    def progress(self, message, completed=None):
-        if self.comm.rank != 0:
-            return
-        if completed is None:
-            print("[%s] %s" % (strftime("%H:%M:%S"), message))
-        else:
-            totlen = 65 - len(message)
-            barlen = int(totlen * completed)
-            print("[%s] %s [%s%s]" % (strftime("%H:%M:%S"), message, "*" * barlen, "-" * (totlen - barlen)))
+    def _targets(self, name):
+        """Sinks of `name`, registration order, wildcard sinks included."""
+        named = self._routes.get(name, ())
+        return [s for s in self._sinks if s in named or s in self._wild]
 
-    def append(self, tblname, value):
-        if self.comm.rank != 0:
-            return
-        for h in self._lookup(tblname):
-            h.append(tblname, value)
+    def ignored(self, name):
+        """Nobody listens to `name` (always True away from rank 0, where nothing was registered)."""
+        return not self._targets(name)
 
-    def assign(self, tblname, value):
-        if self.comm.rank != 0:
-            return
-        for h in self._lookup(tblname):
-            h.assign(tblname, value)
-
-    def append_all(self, valdict):
-        """Every handler gets the sub-dict of the tables it is registered for (datalog.py:183-207)."""
-        if self.comm.rank != 0:
-            return
-        handlers = []
-        for tblname in valdict:
-            for h in self._lookup(tblname):
-                if h not in handlers:
-                    handlers.append(h)
-        for h in handlers:
-            h.append_all({name: val for name, val in valdict.items() if h in self._lookup(name)})
-
-    def ignored(self, tblname):
-        """True when nobody listens to ``tblname``: collecting the value can be skipped (datalog.py:209-226)."""
-        return self._lookup(tblname) == []
-
-    def set_handler(self, tblname, handler_class, *args, **kargs):
-        if self.comm.rank != 0:
+    def set_handler(self, names, handler_class, *args, **kwargs):
+        """Create `handler_class(*args, **kwargs)` and route `names` (a name, an iterable of names, or "*") to it.
+        Returns the sink (None away from rank 0)."""
+        if not self._root:
             return None
         if not (isinstance(handler_class, type) and issubclass(handler_class, DataHandler)):
-            raise TypeError("handler_class must be a subclass of DataHandler ")
-        handler = handler_class(*args, **kargs)
-        handler.register(tblname)
-        if isinstance(tblname, str):
-            self.policy.append((tblname, handler))
-        elif hasattr(tblname, "__iter__"):
-            for t in tblname:
-                self.policy.append((t, handler))
+            raise TypeError("set_handler: %r is not a DataHandler subclass" % (handler_class,))
+        if isinstance(names, str):
+            wanted = [names]
         else:
-            raise TypeError("Table-name must be a string (or a list of strings)")
-        self._lookup_cache = {}
-        return handler
+            try:
+                wanted = [str(n) for n in names]
+            except TypeError:
+                raise TypeError("set_handler: names must be a string or an iterable of strings") from None
+        sink = handler_class(*args, **kwargs)
+        sink.register(names)
+        self._sinks.append(sink)
+        for n in wanted:
+            if n == WILDCARD:
+                self._wild.append(sink)
+            else:
+                self._routes.setdefault(n, []).append(sink)
+        return sink
 
     def remove_handler(self, handler):
-        if self.comm.rank != 0:
+        if not self._root:
             return
-        if not isinstance(handler, DataHandler):
-            raise ValueError("Please provide valid DataHandler object.")
-        self.policy = [(n, h) for n, h in self.policy if h is not handler]
+        if handler not in self._sinks:
+            raise ValueError("remove_handler: not a sink of this DataLog")
+        self._sinks = [s for s in self._sinks if s is not handler]
+        self._wild = [s for s in self._wild if s is not handler]
+        for n in list(self._routes):
+            self._routes[n] = [s for s in self._routes[n] if s is not handler]
+            if not self._routes[n]:
+                del self._routes[n]
         handler.close()
-        self._lookup_cache = {}
+
+    # ---- values -----------------------------------------------------------------------------
+    def append(self, name, value):
+        if self._root:
+            for sink in self._targets(name):
+                sink.append(name, value)
+
+    def assign(self, name, value):
+        if self._root:
+            for sink in self._targets(name):
+                sink.assign(name, value)
+
+    def append_all(self, values):
+        """One call per sink, with the sub-dict of the names it listens to (insertion order kept)."""
+        if not self._root:
+            return
+        per_sink = {}
+        for name, value in values.items():
+            for sink in self._targets(name):
+                per_sink.setdefault(id(sink), (sink, {}))[1][name] = value
+        for sink in self._sinks:
+            if id(sink) in per_sink:
+                sink.append_all(per_sink[id(sink)][1])
+
+    def progress(self, message, completed=None, width=40):
+        """A time-stamped line on rank 0; with `completed` in [0, 1] a bar of `width` cells behind it."""
+        if not self._root:
+            return
+        stamp = time.strftime("%H:%M:%S")
+        if completed is None:
+            print("[%s] %s" % (stamp, message))
+            return
+        done = max(0, min(width, int(round(width * float(completed)))))
+        print("[%s] %s |%s%s| %3.0f%%" % (stamp, message, "#" * done, "." * (width - done), 100.0 * float(completed)))
 
     def close(self):
-        if self.comm.rank != 0:
-            return
-        closed = []
-        for _, handler in self.policy:
-            if handler not in closed:
-                handler.close()
-                closed.append(handler)
-
-
+        if self._root:
+            for sink in self._sinks:
+                sink.close()
+            self._sinks, self._wild, self._routes = [], [], {}

@@ -80,6 +80,64 @@ def test_lpj_sssc_kat(engine):
     _close(out, g["lpj"][1], 1e-11, "single")
 
 
+def test_reconfigure_after_masks_drops_them(engine):
+    """Round-2 abort (gpurun_out/r2_tests1.txt: `Fatal Python error: Aborted` at the first synchronisation after the lpj
+    pass of a shape test that followed the missing-data tests on the shared engine): evoamd_configure kept mask_infr /
+    mask_x / Yrec of the PREVIOUS geometry -- N x D buffers of a smaller shard -- and the next, larger and complete
+    data set ran the masked kernels over them, out of bounds.  (The same commit also added a dynamic-LDS attribute for
+    two new instantiations; a missing attribute is a launch error code, not a process abort, and the attribution run
+    of the isolated test passed: the order of the tests was the trigger.)  Masks on a small geometry, then a larger
+    unmasked configure on the same context: the pass must equal the reference values, i.e. run unmasked."""
+    g = load_golden("lpj_sssc.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    rng = np.random.RandomState(2)
+    engine.configure("sssc", 1, D, H, C, 0, 8)
+    engine.upload_data(Y[:1])
+    engine.upload_masks(rng.random_sample((1, D)) < 0.6)
+    assert engine.has_masks
+    engine.upload_states(states[None])
+    engine.set_params_sssc(g["W"], g["pies"], g["mus"], g["Psi"], float(g["sigma2"]))
+    engine.lpj_resident()
+    masked = engine.download_lpj()
+    assert not np.allclose(masked, g["lpj"][:1], rtol=1e-6)  # the holes do change the values
+    reps = 400  # large enough that rows of a stale 1 x D mask would be far out of bounds
+    engine.configure("sssc", N * reps, D, H, C, 0, 8)
+    assert not engine.has_masks
+    engine.upload_data(np.tile(Y, (reps, 1)))
+    engine.upload_states(np.tile(states[None], (N * reps, 1, 1)))
+    engine.set_params_sssc(g["W"], g["pies"], g["mus"], g["Psi"], float(g["sigma2"]))
+    engine.lpj_resident()
+    engine.synchronize()
+    _close(engine.download_lpj(), np.tile(g["lpj"], (reps, 1)), 1e-11, "unmasked pass after a masked geometry")
+
+
+def test_lpj_sssc_dense_candidates(engine):
+    """States with up to 24 active latents as a CANDIDATE batch (kernel TAG 1): the level chain of the candidates
+    ends in sssc_big_kernel<0, 1> at SSSC_KCAP (98 KB of dynamic LDS -- the instantiation whose missing
+    MaxDynamicSharedMemorySize attribute was the second change of the round-2 fix); test_lpj_sssc_kat runs the same
+    states as resident K^n (TAG 0) and as a shared set (TAG 2)."""
+    g = load_golden("lpj_sssc.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    k = states.sum(axis=1)
+    assert (k > 8).any() and k.max() <= 64
+    engine.configure("sssc", N, D, H, 4, 0, C)
+    engine.upload_data(Y)
+    engine.upload_states(np.tile(states[None, :4], (N, 1, 1)))
+    engine.set_params_sssc(g["W"], g["pies"], g["mus"], g["Psi"], float(g["sigma2"]))
+    counts = np.array([C, C - 5, C][:N], dtype=np.int32)  # ragged
+    got = engine.lpj_candidates(np.tile(states[None], (N, 1, 1)), counts)
+    for n in range(N):
+        _close(got[n, :counts[n]], g["lpj"][n, :counts[n]], 1e-11, "candidates of datapoint %d" % n)
+
+
 def test_vary_kn_kat(engine):
     g = load_golden("vary_kn.npz")
     for i in range(int(g["n_cases"])):

@@ -328,6 +328,124 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 2
 
 
+class _FakeNode:
+    """What AutoTable needs of a PyTables EArray / VLArray."""
+
+    def __init__(self, atom, shape):
+        self.atom, self.rowshape, self.rows, self.flushed = atom, tuple(shape[1:]) if shape else None, [], 0
+
+    def append(self, v):
+        if self.rowshape is not None:
+            v = np.asarray(v)
+            if v.shape[1:] != self.rowshape or v.dtype != self.atom.dtype:
+                raise ValueError("row shape / dtype mismatch")
+            self.rows.extend(list(v))
+        else:
+            self.rows.append(v)
+
+    def flush(self):
+        self.flushed += 1
+
+
+class _FakeTables:
+    """A stand-in for the `tables` module: the calls evo_amd.utils.autotable makes on PyTables, recorded."""
+
+    class Atom:
+        def __init__(self, dtype):
+            self.dtype = dtype
+
+        @staticmethod
+        def from_dtype(dtype):
+            if dtype.kind not in "fiub":
+                raise TypeError("no atom for %s" % dtype)
+            return _FakeTables.Atom(dtype)
+
+    class VLStringAtom:
+        dtype = None
+
+    class Filters:
+        def __init__(self, complevel, complib, shuffle):
+            self.complevel, self.complib, self.shuffle = complevel, complib, shuffle
+
+    class File:
+        def __init__(self, fname, mode):
+            self.fname, self.mode, self.root, self.nodes, self.closed, self.filters = fname, mode, object(), {}, False, {}
+
+        def create_earray(self, where, name, atom, shape, filters=None):
+            assert where is self.root and shape[0] == 0
+            self.nodes[name] = _FakeNode(atom, shape)
+            self.filters[name] = filters
+            return self.nodes[name]
+
+        def create_vlarray(self, where, name, atom, filters=None):
+            self.nodes[name] = _FakeNode(atom, None)
+            return self.nodes[name]
+
+        def remove_node(self, where, name):
+            del self.nodes[name]
+
+        def flush(self):
+            pass
+
+        def close(self):
+            self.closed = True
+
+    opened = []
+
+    @classmethod
+    def open_file(cls, fname, mode):
+        f = cls.File(fname, mode)
+        cls.opened.append(f)
+        return f
+
+
+def test_autotable_pytables_branch_with_a_fake_module(tmp_path, monkeypatch):
+    """PyTables is not in this image, so the HDF5 branch of AutoTable (the reference's on-disk format: one
+    zlib-compressed extendable array per name, one row per append -- evo/utils/autotable.py:93-131, 232-270) never ran.
+    A minimal stand-in module records the calls: node per name, atom from the value's dtype, row shape (0,) + value
+    shape, filters zlib / shuffle, strings through a VLArray, assign() = drop the node and append the rows, close()."""
+    from evo_amd.utils import autotable
+    monkeypatch.setattr(autotable, "_tables", _FakeTables)
+    _FakeTables.opened = []
+    tbl = autotable.AutoTable(str(tmp_path / "t.h5"), compression_level=3)
+    assert tbl.backend == "pytables" and _FakeTables.opened[0].mode == "w"
+    h5 = _FakeTables.opened[0]
+    W = np.arange(6.0).reshape(2, 3)
+    for e in range(3):
+        tbl.append_all({"F": -1.0 * e, "W": W + e, "n": np.int64(e)})
+    tbl.append("note", "hello")
+    assert sorted(h5.nodes) == ["F", "W", "n", "note"]
+    assert h5.nodes["W"].rowshape == (2, 3) and h5.nodes["W"].atom.dtype == np.float64 and len(h5.nodes["W"].rows) == 3
+    assert h5.nodes["n"].atom.dtype == np.int64 and h5.nodes["F"].rowshape == ()
+    f = h5.filters["W"]
+    assert (f.complevel, f.complib, f.shuffle) == (3, "zlib", True)
+    assert h5.nodes["note"].rows == [b"hello"] and h5.nodes["F"].flushed == 3
+    np.testing.assert_array_equal(np.array(h5.nodes["F"].rows), [0.0, -1.0, -2.0])
+    with pytest.raises(TypeError):
+        tbl.append("W", np.zeros((3, 3)))          # wrong row shape
+    with pytest.raises(TypeError):
+        tbl.append("obj", np.array([object()]))    # no atom for this dtype
+    tbl.assign("F", np.array([5.0, 6.0]))
+    np.testing.assert_array_equal(np.array(h5.nodes["F"].rows), [5.0, 6.0])
+    tbl.close()
+    assert h5.closed and not os.path.exists(tmp_path / "t.npz")
+
+
+def test_autotable_numpy_container_flushes_and_warns(tmp_path):
+    """Without PyTables: a warning names the .npz the rows really go to, and the container is rewritten every
+    `flush_every` appends (everything used to sit in RAM until close())."""
+    from evo_amd.utils import autotable
+    if autotable._tables is not None:
+        pytest.skip("PyTables is installed")
+    with pytest.warns(RuntimeWarning, match="t.npz"):
+        tbl = autotable.AutoTable(str(tmp_path / "t.h5"), flush_every=4)
+    for e in range(5):
+        tbl.append("F", float(e))
+    np.testing.assert_array_equal(np.load(tmp_path / "t.npz")["F"], [0.0, 1.0, 2.0, 3.0])  # flushed after 4 rows
+    tbl.close()
+    np.testing.assert_array_equal(np.load(tmp_path / "t.npz")["F"], [0.0, 1.0, 2.0, 3.0, 4.0])
+
+
 def test_bench_host_cores_respects_cgroup_quota():
     import bench
     n = bench.host_cores()
@@ -360,6 +478,7 @@ def test_standard_init_incomplete_data_matches_reference():
         np.testing.assert_allclose(th[k], g["t0_in_%s" % k], rtol=1e-12, atol=1e-13, err_msg=k)
 
 
+@pytest.mark.filterwarnings("ignore:PyTables is not installed")
 def test_datalog_routes_like_the_reference(tmp_path, capsys):
     """DataLog / TextPrinter / StoreToTxt / StoreToH5 (evo/utils/datalog.py:137-274, autotable.py:93-173): per-table
     routing incl. the '*' wildcard, append_all handing every handler its own sub-dict, ignored(), one row per append.
