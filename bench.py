@@ -431,6 +431,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-mstep", action="store_true", help="Theta update with host NumPy (reference formulas)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--eager-theta", action="store_true",
+                    help="step() copies Theta^new to the host every iteration (3 MB over PCIe + a host copy) like the reference's "
+                         "return value; default: LazyTheta, downloaded when it is read (the timed loop never reads it)")
     ap.add_argument("--dense-states", action="store_true",
                     help="SURVEY 8d stress variant: K^n initialised with p_init_Kn = 8/H (mean |s| = 8)")
     ap.add_argument("--inprocess-init", action="store_true",
@@ -485,7 +488,7 @@ def main():
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
     kw = {"dtype": np.float32} if cfg.get("f32") else {}
     model = cls(cfg["D"], cfg["H"], cfg["S"], comm=comm, rng="device", sync_host=False, engine=eng, seed=17,
-                device_mstep=not args.host_mstep, **kw)
+                device_mstep=not args.host_mstep, lazy_theta=not args.eager_theta, **kw)
     np.random.seed(99)
     theta = model.check_params(model.standard_init(my_data))  # data moments all-reduced, W noise broadcast from rank 0
     suff = ea_suff(cfg)
@@ -583,6 +586,8 @@ def main():
                        "ea": "fit/randflip 10 parents x 1 child x 1 gen",
                        "states": "p_init_Kn=8/H (dense stress variant)" if args.dense_states else "p_init_Kn=1/H (init_states default)",
                        "rng": "device", "mstep": "host" if args.host_mstep else "device", "parallelism": "dp%d" % world,
+                       "theta": "eager (host copy every iteration)" if args.eager_theta else
+                                "lazy view (resident on the device; downloaded when read, never in the timed loop)",
                        "sharding": "np.array_split over N (evo/utils/parallel.py:102-112), one packed RCCL all-reduce per iteration",
                        "free_energy_last": F, "S_nunique_last": nu, "S_sub_last": nsub, "setup_s": round(t_setup, 1),
                        "kernel_ms": kernel_ms,

@@ -140,6 +140,13 @@ struct evoamd_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool gemm_forked = false;
+  // Theta^new reaches the host through the copy engine (third stream) while the kernels of the refresh and of the
+  // prefetched pass run: the mailbox kernel then carries the 32-word header only (it used to write the 3 MB of Theta
+  // into pinned memory itself: 67 us in front of everything queued behind it).  Option "theta_copy_engine" = 0: old form.
+  hipStream_t stream_copy = nullptr;
+  hipEvent_t ev_theta = nullptr, ev_theta_done = nullptr;
+  int theta_copy_engine = 0;  // measured (c4 / c4shard, interleaved A/B): no gain -- the host then waits for the copy
+                              // instead, and at N / 8 it returns too late to keep the queue filled (1.30 vs 1.25 ms)
   double rel_frac = -1.0;  // EBSC incomplete data: sum(x_infr) / N over all ranks (evoamd_set_reliable_fraction)
   bool ar_gemm_pending = false;  // with a communicator: the contraction's block of acc is all-reduced at the join
   int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
@@ -430,6 +437,9 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   }
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_theta, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_theta_done, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
 
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -497,6 +507,9 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   free_all(c);
   (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
+  if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
+  if (c->ev_theta_done) (void)hipEventDestroy(c->ev_theta_done);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 16; i++)
@@ -572,6 +585,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "theta_copy_engine") == 0) {
+    c->theta_copy_engine = value != 0;
     return 0;
   }
   if (strcmp(name, "census_lists") == 0) {  // takes effect at the next evoamd_configure
@@ -2855,6 +2872,21 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   const AccLayout a = acc_layout(c);
   const size_t DH = (size_t)c->D * c->H, HH = (size_t)c->H * c->H, H = c->H;
   MailboxSegs segs = {};
+  const bool dma = with_theta && c->theta_copy_engine;
+  if (dma) {
+    // Theta^new is final on the main stream here: the copy engine takes it from there, beside whatever follows
+    double *dst = c->h_theta + MAILBOX_HDR;
+    HIP_TRY(hipEventRecord(c->ev_theta, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream_copy, c->ev_theta, 0));
+    HIP_TRY(hipMemcpyAsync(dst, c->W, DH * sizeof(double), hipMemcpyDeviceToHost, c->stream_copy));
+    if (c->model == EVOAMD_MODEL_SSSC) {
+      HIP_TRY(hipMemcpyAsync(dst + DH, c->Psi, HH * sizeof(double), hipMemcpyDeviceToHost, c->stream_copy));
+      HIP_TRY(hipMemcpyAsync(dst + DH + HH, c->mus, H * sizeof(double), hipMemcpyDeviceToHost, c->stream_copy));
+      HIP_TRY(hipMemcpyAsync(dst + DH + HH + H, c->pies, H * sizeof(double), hipMemcpyDeviceToHost, c->stream_copy));
+    }
+    HIP_TRY(hipEventRecord(c->ev_theta_done, c->stream_copy));
+    with_theta = false;  // the mailbox kernel writes the header only
+  }
   if (with_theta) {
     segs.src[0] = c->W;
     segs.n[0] = (long long)DH;
@@ -2899,6 +2931,7 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (dma) HIP_TRY(hipEventSynchronize(c->ev_theta_done));
   return 0;
 }
 
@@ -2920,6 +2953,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   if (r) return r;
   c->h_theta_fresh = false;
   const bool want_rec = (learn_mask & 32) != 0;
+  const bool theta_home = (learn_mask & 64) != 0;  // the caller fetches Theta^new on demand (evoamd_get_params_*)
   learn_mask &= 31;
   if (want_rec && !c->yhat_valid) {  // under the Theta the E-step used, i.e. before the update
     r = compute_reconstruction(c);   // (incomplete data: the statistics pass formed it already)
@@ -2934,7 +2968,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   if (r) return r;
   // accumulator tail (8) and the scalar block (16) are adjacent in device memory and in the mailbox;
   // the reference's step() hands Theta^new back, so it rides along
-  r = mailbox_roundtrip(c, learn_mask != 0, /*prefetch=*/true, /*refresh=*/learn_mask != 0);
+  r = mailbox_roundtrip(c, learn_mask != 0 && !theta_home, /*prefetch=*/true, /*refresh=*/learn_mask != 0);
   if (r) return r;
   const double *h = c->h_theta + 8;
   if (learn_mask && h[8 + DP_STATUS] == 3.0) {
@@ -2946,7 +2980,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     r = update_params_device(c, learn_mask, /*force_pivot=*/true, /*defer_refresh=*/true);
     if (r) return r;
-    r = mailbox_roundtrip(c, true, /*prefetch=*/true, /*refresh=*/true);
+    r = mailbox_roundtrip(c, !theta_home, /*prefetch=*/true, /*refresh=*/true);
     if (r) return r;
   }
   memcpy(tail_out, h, 8 * sizeof(double));
@@ -2955,7 +2989,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   r = mailbox_errors(c);
   if (r) return r;
   note_levels(c, c->h_dpar);
-  c->h_theta_fresh = learn_mask != 0 && c->h_dpar[DP_STATUS] == 0.0;
+  c->h_theta_fresh = learn_mask != 0 && !theta_home && c->h_dpar[DP_STATUS] == 0.0;
   if (c->h_dpar[DP_STATUS] != 0.0) {
     dpar_out[DP_STATUS] = c->h_dpar[DP_STATUS];  // 1 singular, 2 non-finite: the caller may finish the step on the host
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));

@@ -243,10 +243,11 @@ class Engine:
     DPAR = {"pre1": 0, "pil_bar": 1, "sigma2_inv": 2, "ljc": 3, "pi": 4, "sigma": 5, "sigma2": 6, "status": 7,
             "ljc_prev": 8, "n_gt2": 12, "n_gt4": 13, "n_gt8": 14}
 
-    def mstep_device(self, to_learn, reconstruct=False):
+    def mstep_device(self, to_learn, reconstruct=False, theta_to_host=True):
         """Statistics + Theta update on the device.  Returns (tail dict, scalar-parameter dict).
-        reconstruct: also form the data estimate under the OLD Theta (fetch it with reconstruct())."""
-        mask = 32 if reconstruct else 0
+        reconstruct: also form the data estimate under the OLD Theta (fetch it with reconstruct()).
+        theta_to_host=False: Theta^new is not copied into the host mailbox (get_params_* fetches it on demand)."""
+        mask = (32 if reconstruct else 0) | (0 if theta_to_host else 64)
         for name in to_learn:
             mask |= self.LEARN_BITS[name]
         tail = np.zeros(8)
@@ -254,7 +255,7 @@ class Engine:
         rc = self.lib.evoamd_mstep_device(self._h, mask, dptr(tail), dptr(dpar))
         d = {k: dpar[i] for k, i in self.DPAR.items()}
         # ljc of the Theta the E-step ran with: the update kernels move it to ljc_prev
-        d["ljc_estep"] = d["ljc_prev"] if mask else d["ljc"]
+        d["ljc_estep"] = d["ljc_prev"] if (mask & 31) else d["ljc"]
         if rc == -6 and d["status"] in (1.0, 2.0):  # EVOAMD_E_SINGULAR from the Theta update: exactly singular H x H
             # system, or one so ill-conditioned that the update went non-finite (tail / dpar were delivered)
             raise SingularUpdate(self.lib.evoamd_last_error().decode(), dict(zip(TAIL, tail)), d)

@@ -70,11 +70,95 @@ def _reduce_array(comm, a):
     return comm.allreduce(a)  # mpi4py pickle path sums ndarrays element-wise
 
 
+class LazyTheta(dict):
+    """The parameter dict step() hands back when ``lazy_theta=True``: same keys as the reference's, but the arrays
+    (W, Psi, mus, pies and what is derived from them) stay on the device until somebody looks at them -- a training
+    loop that only carries theta from one step() into the next never moves them over PCIe, a loop that logs W every
+    epoch pays one download per epoch.  Scalars (sigma2 / sigma, pi, ljc ...) are always current.  Any read access
+    materialises the arrays; passing the object back into step() does not."""
+
+    def __init__(self, scalars, loader):
+        super().__init__(scalars)
+        self._loader = loader
+
+    def _stale(self, scalars, loader):
+        """New Theta on the device: keep the scalars, forget the arrays."""
+        dict.clear(self)
+        dict.update(self, scalars)
+        self._loader = loader
+
+    def _load(self):
+        loader, self._loader = self._loader, None
+        if loader is not None:
+            dict.update(self, loader())
+
+    @property
+    def materialised(self):
+        return self._loader is None
+
+    def __getitem__(self, key):
+        if self._loader is not None and dict.__contains__(self, key):
+            return dict.__getitem__(self, key)  # a scalar: current without a download
+        self._load()
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        self._load()
+        return dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._load()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._load()
+        return dict.__len__(self)
+
+    def __repr__(self):
+        return "LazyTheta(%s)" % ("pending" if self._loader is not None else dict.__repr__(self))
+
+    def get(self, key, default=None):
+        self._load()
+        return dict.get(self, key, default)
+
+    def keys(self):
+        self._load()
+        return dict.keys(self)
+
+    def items(self):
+        self._load()
+        return dict.items(self)
+
+    def values(self):
+        self._load()
+        return dict.values(self)
+
+    def copy(self):
+        self._load()
+        return dict(dict.items(self))
+
+    def pop(self, *a):
+        self._load()
+        return dict.pop(self, *a)
+
+    def __setitem__(self, key, value):
+        self._load()
+        dict.__setitem__(self, key, value)
+
+    def update(self, *a, **kw):
+        self._load()
+        dict.update(self, *a, **kw)
+
+    def setdefault(self, key, default=None):
+        self._load()
+        return dict.setdefault(self, key, default)
+
+
 class Model:
     model_name = None  # "bsc" | "sssc"
 
     def __init__(self, D, H, S, to_learn=("W", "pi", "sigma"), comm=None, rng="reference", sync_host=True,
-                 device=None, engine=None, seed=0, device_mstep=False, dtype=np.float64):
+                 device=None, engine=None, seed=0, device_mstep=False, dtype=np.float64, lazy_theta=False):
         """``D, H, S, to_learn, comm`` as in the reference (_models.py:20-56).  ``comm`` may be an
         mpi4py communicator or one of evo_amd.utils.parallel; None means one rank."""
         if rng not in ("reference", "device"):
@@ -90,6 +174,11 @@ class Model:
         # use Gauss-Jordan instead of LAPACK, so Theta agrees with the host formulas to ~1e-12 but
         # not bit for bit -- keep it off for rng="reference" parity runs.
         self.device_mstep = bool(device_mstep)
+        # lazy_theta (device_mstep only): step() returns a LazyTheta whose arrays are downloaded when they are read --
+        # the reference's step() returns Theta^new every epoch, which here is 3 MB over PCIe plus a 3 MB host copy per
+        # iteration whether or not the caller looks at it.  Off by default: the returned object is then the caller's
+        # own dict, mutated in place like the reference does.
+        self.lazy_theta = bool(lazy_theta)
         # dtype=np.float32 (EBSC only): the data, B = Y W and the E_q[s] rows are kept in float and the two long
         # contractions run on the f32 matrix cores; lpj arithmetic, selection, sums and Theta stay float64.  The reference
         # is float64-only -- this is BASELINE.json configs[4]'s "float32"; agreement with the float64 path ~1e-6 in lpj / F.
@@ -226,6 +315,10 @@ class Model:
         """Host copy of the parameters resident on the device + the derived keys of the reference."""
         raise NotImplementedError
 
+    def _scalar_params(self, dpar):
+        """The scalar entries of _pull_params(dpar), from the scalar block alone (LazyTheta keeps them current)."""
+        raise NotImplementedError
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         raise NotImplementedError
 
@@ -300,8 +393,9 @@ class Model:
         if self._incomplete and do_reconstruction:
             # y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211): formed inside the statistics pass
             eng.set_option("reconstruct_in_stats", 1)
+        lazy = self.lazy_theta and len(self.to_learn) > 0
         try:
-            tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction)
+            tail, dpar = eng.mstep_device(self.to_learn, reconstruct=do_reconstruction, theta_to_host=not lazy)
         except _engine.SingularUpdate as e:
             return self._step_device_singular(model_params, my_suff_stat, my_data, do_reconstruction, e.tail, e.dpar)
         if do_reconstruction:
@@ -313,7 +407,16 @@ class Model:
         my_suff_stat["reset_lpj_isnan"] = int(tail["reset_isnan"])
         my_suff_stat["reset_lpj_smaller_eps_lpj"] = int(tail["reset_smaller_eps"])
         my_suff_stat["reset_lpj_isinf"] = int(tail["reset_isinf"])
-        model_params.update(self._pull_params(dpar))
+        self.last_dpar = dpar
+        if lazy:
+            scalars = self._scalar_params(dpar)
+            loader = (lambda: self._pull_params(self.last_dpar))
+            if isinstance(model_params, LazyTheta):
+                model_params._stale(scalars, loader)
+            else:
+                model_params = LazyTheta(scalars, loader)
+        else:
+            model_params.update(self._pull_params(dpar))
         self._dev_theta = model_params
         self.last_dpar = dpar  # scalar block of the update (engine.Engine.DPAR): n_gt2 / n_gt4 / n_gt8 = overflow census of K^n
         N = tail["N"]

@@ -38,6 +38,10 @@ class BSC(Model):
         th.update(piH=th["pi"] * self.H, pre1=dpar["pre1"], pil_bar=dpar["pil_bar"], ljc=dpar["ljc"])
         return th
 
+    def _scalar_params(self, dpar):
+        return {"pi": np.float64(dpar["pi"]), "sigma": np.float64(dpar["sigma"]), "piH": dpar["pi"] * self.H,
+                "pre1": dpar["pre1"], "pil_bar": dpar["pil_bar"], "ljc": dpar["ljc"]}
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         """State-independent terms (bsc.py:99-125, complete data) stored into ``model_params``
         under the reference's keys, then Theta is pushed to the device."""

@@ -105,6 +105,9 @@ class SSSC(Model):
                   sigma2_inv=np.float64(dpar["sigma2_inv"]), ljc=dpar["ljc"])
         return th
 
+    def _scalar_params(self, dpar):
+        return {"sigma2": np.float64(dpar["sigma2"]), "sigma2_inv": np.float64(dpar["sigma2_inv"]), "ljc": dpar["ljc"]}
+
     def E_step_precompute(self, model_params, my_suff_stat, my_data):
         """State-independent terms (sssc.py:328-366, complete data): ljc, piH, pil_bar, sigma2_inv
         (through long double like the reference), stored under the reference's keys."""

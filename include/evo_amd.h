@@ -107,6 +107,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "theta_copy_engine" (0/1, default 0; measured without gain): evoamd_mstep_device downloads Theta^new with asynchronous copies on a third
+ * stream (copy engine) beside the kernels queued behind the update; 0: the mailbox kernel writes Theta into the pinned
+ * host buffer itself, in front of them.
  * "census_lists" (0/1, default 1; read by the next evoamd_configure): ES3C on complete data with digests -- the resident
  * states with 3..4 / 5..8 / more than 8 active latents are listed by one pass over the digests per K^n (shared by the
  * statistics pass and the next pass over K^n) and served by the four-lanes-per-state kernels; 0: the round-2 chains
@@ -228,7 +231,10 @@ int evoamd_stats(evoamd_ctx *ctx, double *acc_out);
  * all-reduce) but leaves them on the device, then evaluates the Theta update (bsc.py:226-277 /
  * sssc.py:687-770), the clamps of check_params (_models.py:101-159) and E_step_precompute on the
  * GPU and installs the result as the context's current parameters.  learn_mask bits: 1 W, 2 pies
- * (BSC: pi), 4 mus, 8 sigma2 (BSC: sigma), 16 Psi; 0 = statistics only.  tail_out[8] = accumulator
+ * (BSC: pi), 4 mus, 8 sigma2 (BSC: sigma), 16 Psi; 0 = statistics only; 32 = also form the data estimate under the OLD
+ * Theta (evoamd_reconstruct); 64 = Theta^new stays on the device (otherwise it rides along into pinned host memory,
+ * where evoamd_get_params_* finds it: what step() of the reference hands back) -- the caller fetches it with
+ * evoamd_get_params_* when it looks at it (evo_amd.models: lazy_theta=True).  tail_out[8] = accumulator
  * tail, dpar_out[16] = scalar block of the NEW Theta (kernels_mstep.hpp: DP_*; [8] = ljc of the Theta
  * the E-step used when learn_mask != 0, else [3] is).  The H x H systems (Gram-type moment matrices) are inverted by
  * block Gauss-Jordan with the 16 / 32-column diagonal blocks as pivots (options "inverse_spd", "inverse_block"); a

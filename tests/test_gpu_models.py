@@ -780,6 +780,46 @@ def test_reconstruct_first_call_without_host_sync(engine, algo):
 
 
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_lazy_theta_is_the_same_theta(engine, algo):
+    """lazy_theta=True: step() hands back a LazyTheta whose arrays stay on the device until they are read.  Same
+    seeds, same device RNG, same kernels: F of every step and Theta after three steps equal the eager run (to the 1e-16
+    of the atomic sums);
+    the scalars are readable without a download, the arrays materialise on first access, and a Theta handed back
+    into step() is recognised without being read."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.models._models import LazyTheta
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(4)
+    D, H, S, N = 20, 24, 12, 300
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+    out = []
+    for lazy in (False, True):
+        np.random.seed(9)
+        model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=5, device_mstep=True, lazy_theta=lazy)
+        theta = model.check_params(model.standard_init(my_data))
+        suff = init_states(N, S, H, "fit", "randflip", 4, 1, 1)
+        Fs = []
+        for it in range(3):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            Fs.append(F)
+            if lazy:
+                assert isinstance(theta, LazyTheta) and not theta.materialised
+                assert np.isfinite(theta["sigma" if algo == "ebsc" else "sigma2"]) and not theta.materialised
+        if lazy:
+            assert theta is model._dev_theta
+            W = theta["W"]  # first array access: one download
+            assert theta.materialised and W.shape == (D, H)
+        out.append((Fs, {k: np.array(v) for k, v in theta.items()}))
+    # (sums through atomics / LDS tiles are reproducible to ~1e-16 only, DESIGN section 4: not bit for bit)
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-12)
+    assert set(out[0][1]) == set(out[1][1])
+    for k in out[0][1]:
+        np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 def test_device_mstep_absorbs_singular_update(engine, algo):
     """A latent that occurs in no state of any K^n makes the M-step's H x H system exactly singular.  The
     reference absorbs it (lstsq min-norm solution, bsc.py:237; inv -> LinAlgError -> pinv + noise,
