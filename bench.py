@@ -115,10 +115,9 @@ def cpu_model():
 def pass_kernels(cfg):
     """Kernels of the pass over all N x S resident states, as rocprofv3 names them (TAG 0 = the pass over K^n)."""
     hw = (cfg["H"] + 63) // 64
-    if cfg["algo"] == "es3c":
-        return ["void sssc_main_lpj_kernel<0, 512, %d, 2>" % (hw if hw in (1, 2, 4, 8, 16) else 0),
-                "void sssc_small_kernel<4, 0, 0, 256>", "void sssc_small_kernel<8, 0, 0, 256>",
-                "void sssc_big_kernel<0, 0>"]
+    if cfg["algo"] == "es3c":  # census lists (round 3): main kernel (|s| <= 2), quad levels 3..4 / 5..8, wavefront kernel
+        return ["void sssc_main_lpj_kernel<0, 512, %d, 2, false>" % (hw if hw in (1, 2, 4, 8, 16) else 0), "census_kernel",
+                "void sssc_quad_kernel<1, 0, 0>", "void sssc_quad_kernel<2, 0, 0>", "void sssc_big_kernel<0, 0>"]
     return ["void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)]
 
 
@@ -126,8 +125,8 @@ def stats_kernels(cfg):
     hw = (cfg["H"] + 63) // 64
     hwt = hw if hw in (1, 2, 4, 8, 16) else 0
     if cfg["algo"] == "es3c":
-        return ["void sssc_stats_wave_kernel<%d, 4>" % hwt, "pair_bins_reduce_kernel", "void sssc_small_kernel<4, 1, 2, 256>",
-                "void sssc_small_kernel<8, 1, 2, 256>", "void sssc_big_kernel<1, 2>", "sssc_finish_kernel"]
+        return ["void sssc_stats_wave_kernel<%d, 4, true>" % hwt, "pair_bins_reduce_kernel", "void sssc_quad_kernel<1, 1, 2>",
+                "void sssc_quad_kernel<2, 1, 2>", "void sssc_big_kernel<1, 2>", "sssc_finish_kernel"]
     sr = (cfg["S"] + 63) // 64
     if sr <= 4:  # wave-per-datapoint kernel + pair bins (evo_amd.hip: bsc_wave)
         return ["void bsc_stats_wave_kernel<%d>" % (sr if sr in (1, 2) else 4), "pair_bins_reduce_kernel", "bsc_finish_kernel"]
@@ -140,11 +139,16 @@ def pmc_traffic(config, kernels):
     --pmc FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  A pass is
     one launch of the first kernel of the list; the conditional overflow levels count with their own launch
     frequency.  None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_%s_pmc_traffic.json" % config)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except Exception:
+    d = None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, config))
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            break
+        except Exception:
+            continue
+    if d is None:
         return None
 
     def find(k):
@@ -174,12 +178,20 @@ def layout_bytes_lpj(cfg, N):
     return N * (cfg["H"] * (4 if cfg.get("f32") else 8) + cfg["S"] * (8 + 8))
 
 
-def gemm_flops_per_iteration(cfg, N):
+def gemm_flops_per_iteration(cfg, N, executed=False):
     """Dense f64 contractions of one EM iteration in steady state (the launches timed under
-    kernel class "gemm_f64"): the K = N statistics contraction, G = W^T W and B = Y W."""
+    kernel class "gemm_f64"): the K = N statistics contraction, G = W^T W and B = Y W.
+    executed=True: what the kernels really multiply -- the symmetric block Ez^T Ez of the ES3C contraction runs its
+    upper 128 x 128 tiles only (H = 512: 10 of 16), and G = W^T W likewise where the tile kernel serves it."""
     D, H = cfg["D"], cfg["H"]
     if cfg["algo"] == "es3c":
-        return 2.0 * N * (D + 2 * H) * H + 2.0 * D * H * H + 2.0 * N * D * H
+        nominal = 2.0 * N * (D + 2 * H) * H + 2.0 * D * H * H + 2.0 * N * D * H
+        if not executed:
+            return nominal
+        T = 128
+        ts = (H + T - 1) // T
+        sym_done = ts * (ts + 1) / 2.0 / (ts * ts) if (D + H) % T == 0 else 1.0  # fraction of the Ez^T Ez tiles computed
+        return 2.0 * N * (D + H) * H + sym_done * 2.0 * N * H * H + 2.0 * D * H * H + 2.0 * N * D * H
     return 2.0 * N * H * D + 2.0 * D * H * H + 2.0 * N * D * H
 
 
@@ -531,7 +543,8 @@ def main():
     barrier()
     kernel_ms = {}
     for name in ("lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse", "vary_kn", "stats", "stats_overflow",
-                 "gemm_f64", "evolve", "misc", "mstep_device", "lpj_pass", "stats_pass"):
+                 "gemm_f64", "evolve", "misc", "mstep_device", "lpj_pass", "stats_pass", "lpj_k3_4", "lpj_k5_8", "lpj_k9plus",
+                 "stats_k3_4", "stats_k5_8", "stats_k9plus"):
         avg, n = eng.kernel_time_ms(name)
         if n:
             kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_iteration": n / prof_iters}
@@ -572,6 +585,31 @@ def main():
             r_lpj["frac_basis"] = "layout bytes (algorithmic-byte pricing exceeds the roof for this layout)"
         r_st = roof(st_ms, st_n, stats_kernels(cfg), "whole statistics pass over the resident K^n (scatter kernel + overflow "
                     "levels + column sums + finish; the MFMA contraction is priced under `mfma`)")
+        tr = r_st.get("traffic")
+        if tr is not None and tr < alg_bytes:
+            # the digest layout moves fewer bytes than SURVEY 8d prices (H = 1024: 8-byte digests for 128-byte bit words):
+            # a fraction of algorithmic bytes then flatters the kernel -- the headline fraction prices the measured traffic
+            r_st["frac_algorithmic_bytes_over_roof"] = r_st["frac"]
+            r_st["frac"] = (tr / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if st_ms > 0 else 0.0
+            r_st["frac_basis"] = "measured HBM traffic (below the algorithmic bytes of SURVEY 8d for this layout)"
+        # states above two active latents, level by level (census of the last statistics pass) and what the levels cost
+        lv = {}
+        if all(k in ld for k in ("n_gt2", "n_gt4", "n_gt8")):
+            cnt = {"k3_4": ld["n_gt2"] - ld["n_gt4"], "k5_8": ld["n_gt4"] - ld["n_gt8"], "k9plus": ld["n_gt8"]}
+            for name, n_states in cnt.items():
+                e = {"states": n_states, "fraction_of_K": n_states / (float(n_loc) * cfg["S"])}
+                for pas in ("lpj", "stats"):
+                    km = kernel_ms.get("%s_%s" % (pas, name))
+                    if km:
+                        e["%s_ms_per_pass" % pas] = km["avg_ms"] * km["launches_per_iteration"]
+                lv[name] = e
+        above2 = {}
+        for pas, span in (("lpj", "lpj_pass"), ("stats", "stats_pass")):
+            tot = kernel_ms.get(span)
+            if tot and lv:
+                t_lv = sum(e.get("%s_ms_per_pass" % pas, 0.0) for e in lv.values())
+                above2[pas] = {"ms_levels": t_lv, "ms_pass": tot["avg_ms"] * tot["launches_per_iteration"],
+                               "fraction_of_pass_above_k2": t_lv / max(1e-12, tot["avg_ms"] * tot["launches_per_iteration"])}
         out = {
             "metric": "E-step candidate-state evals/sec (NxS), full EM iteration", "value": evals / dt,
             "unit": "state evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -593,21 +631,28 @@ def main():
                        "kernel_ms": kernel_ms,
                        "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_iters},
             "roofline": r_lpj, "roofline_stats": r_st,
+            "levels": {"by_active_latents": lv, "above_two_latents": above2,
+                       "note": "ES3C states by number of active latents (census lists, one pass over the digests per K^n): "
+                               "per-level HIP-event times from the instrumented iterations after the timed region"},
         }
         g = kernel_ms.get("gemm_f64")
         if g:
             t_ms = g["avg_ms"] * g["launches_per_iteration"]
-            fl = gemm_flops_per_iteration(cfg, n_loc)
+            fl_nom = gemm_flops_per_iteration(cfg, n_loc)
+            fl = gemm_flops_per_iteration(cfg, n_loc, executed=True)
             f32 = bool(cfg.get("f32"))
             peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
             out["mfma"] = {"kernels": ("gemm_tn128_sk_f32 / gemm_tn128_store_f32 (v_mfma_f32_16x16x4_f32)" if f32 else
                                        "gemm_tn128_sk_f64 / gemm_tn128_rows_f64 / gemm_tn_f64 / gemm_nn_f64 (v_mfma_f64_16x16x4_f64)"),
                            "flops_per_iteration": fl,
-                           "flops_note": "nominal 2 M N K of every product (the symmetric block of the ES3C contraction "
-                                         "runs its upper tiles only: 34 of 40 tiles at H = 512)",
+                           "flops_note": "EXECUTED flops: 2 M N K of every product, the symmetric block of the ES3C contraction "
+                                         "counted with the upper tiles it really runs (34 of 40 tiles at H = 512); "
+                                         "`frac_nominal` prices all tiles",
                            "ms_per_iteration": t_ms,
                            "achieved": fl / (t_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                           "frac": fl / (t_ms * 1e-3) / 1e12 / peak}
+                           "frac": fl / (t_ms * 1e-3) / 1e12 / peak,
+                           "flops_per_iteration_nominal": fl_nom,
+                           "frac_nominal": fl_nom / (t_ms * 1e-3) / 1e12 / peak}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -19,7 +19,8 @@ MODEL_BSC, MODEL_SSSC = 0, 1
 KERNEL_IDS = {
     "lpj_resident": 0, "lpj_candidates": 1, "lpj_overflow": 2, "row_lse": 3, "vary_kn": 4,
     "stats": 5, "stats_overflow": 6, "gemm_f64": 7, "evolve": 8, "misc": 9, "mstep_device": 10,
-    "lpj_pass": 11, "stats_pass": 12,
+    "lpj_pass": 11, "stats_pass": 12, "lpj_k3_4": 13, "lpj_k5_8": 14, "lpj_k9plus": 15,
+    "stats_k3_4": 16, "stats_k5_8": 17, "stats_k9plus": 18,
 }
 
 _c_dp = ctypes.POINTER(ctypes.c_double)

@@ -124,6 +124,12 @@ enum {  // internal kernel ids (see evoamd_kernel_name)
   KID_MSTEP,
   KID_LPJ_PASS,    // the whole pass over the resident K^n: main kernel + every overflow level it spawns
   KID_STATS_PASS,  // the whole statistics pass: scatter kernels + overflow levels + column sums + finish (no GEMM)
+  KID_LPJ_K34,     // census levels of the pass over K^n: states with 3..4 / 5..8 / more than 8 active latents
+  KID_LPJ_K58,
+  KID_LPJ_K9P,
+  KID_STATS_K34,   // ... and of the statistics pass
+  KID_STATS_K58,
+  KID_STATS_K9P,
   KID_COUNT
 };
 
@@ -1662,13 +1668,18 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     }
     if (need[0] || need[1] || need[2]) {
       SpanGuard g(c, KID_LPJ_OVF);
-      if (need[0])
+      if (need[0]) {
+        SpanGuard gl(c, KID_LPJ_K34);
         sssc_quad_kernel<1, 0, TAG><<<quad_grid(c, 0, TAG, total, 2048), 256, 0, c->stream>>>(a, cA, none_o, o3, PairBins{}, nullptr);
+      }
       DBG_SYNC(c, "sssc lpj quad level 3..4");
-      if (need[1])
+      if (need[1]) {
+        SpanGuard gl(c, KID_LPJ_K58);
         sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, cB, none_o, o3, PairBins{}, nullptr);
+      }
       DBG_SYNC(c, "sssc lpj quad level 5..8");
       // the pivoting wavefront kernel: resident states above eight latents, then what the quads passed on
+      SpanGuard gl(c, KID_LPJ_K9P);
       sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
           a, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_o, SSSC_KCAP, i3);
       HIP_TRY(hipGetLastError());
@@ -2416,10 +2427,14 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           const unsigned gcap = pb.ent ? (unsigned)std::min(2048, pb.nwg) : 2048u;
           const size_t dl = (size_t)H * sizeof(double);
           // (the bins' region counters are zero here: pair_bins_reduce_kernel clears what it reads)
-          if (need[0])
+          if (need[0]) {
+            SpanGuard gl(c, KID_STATS_K34);
             sssc_quad_kernel<1, 1, 2><<<quad_grid(c, 0, tg, total, gcap), 256, dl, c->stream>>>(sc, cA, none_out, o3, pb, c->ovf_rec);
-          if (need[1])
+          }
+          if (need[1]) {
+            SpanGuard gl(c, KID_STATS_K58);
             sssc_quad_kernel<2, 1, 2><<<quad_grid(c, 1, tg, total, gcap), 256, dl, c->stream>>>(sc, cB, none_out, o3, pb, c->ovf_rec);
+          }
           HIP_TRY(hipGetLastError());
           DBG_SYNC(c, "sssc stats quad levels");
         }
@@ -2480,6 +2495,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         if (need[0] || need[1] || need[2]) {  // resident states above eight latents + what the quads passed on (atomics)
           SpanGuard g(c, KID_STATS_OVF);
           const int tg = c->cand_from_device ? 1 : 2;
+          SpanGuard gl(c, KID_STATS_K9P);
           sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
               sc, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_out, SSSC_KCAP, i3);
           HIP_TRY(hipGetLastError());
@@ -3233,6 +3249,7 @@ extern "C" int evoamd_kernel_time_ms(evoamd_ctx *c, int kid, double *avg_ms, int
 extern "C" const char *evoamd_kernel_name(int kid) {
   static const char *names[KID_COUNT] = {"lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse",  "vary_kn",
                                          "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc", "mstep_device",
-                                         "lpj_pass",     "stats_pass"};
+                                         "lpj_pass",     "stats_pass",     "lpj_k3_4",     "lpj_k5_8", "lpj_k9plus",
+                                         "stats_k3_4",   "stats_k5_8",     "stats_k9plus"};
   return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }

@@ -326,7 +326,13 @@ enum {
   EVOAMD_K_MSTEP_DEVICE = 10,  /* device Theta update (inverse, GEMMs, precompute) */
   EVOAMD_K_LPJ_PASS = 11,      /* whole pass over the resident K^n: main kernel + every overflow level (one span) */
   EVOAMD_K_STATS_PASS = 12,    /* whole statistics pass: scatter + overflow levels + bin reduce + finish, GEMM aside */
-  EVOAMD_K_COUNT = 13
+  EVOAMD_K_LPJ_K3_4 = 13,      /* ES3C census levels of the pass over K^n: states with 3..4 active latents (sssc_quad_kernel<1>), */
+  EVOAMD_K_LPJ_K5_8 = 14,      /* 5..8 (sssc_quad_kernel<2>),                                                                    */
+  EVOAMD_K_LPJ_K9PLUS = 15,    /* more than 8, or handed on by a quad kernel (pivoting wavefront kernel)                          */
+  EVOAMD_K_STATS_K3_4 = 16,    /* the same levels of the statistics pass */
+  EVOAMD_K_STATS_K5_8 = 17,
+  EVOAMD_K_STATS_K9PLUS = 18,
+  EVOAMD_K_COUNT = 19
 };
 /* on = bit mask of kernel classes to time (bit k = class k; -1 = all, 0 = off).  Each timed span
  * records two HIP events on the compute stream, which costs about 10 us of stream time per span:

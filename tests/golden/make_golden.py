@@ -506,6 +506,9 @@ SHAPES = {  # name: (algo, D, H, S, N, seed, ea) -- BASELINE.json configs[1..4] 
     "c3": ("ebsc", 64, 256, 128, 1024, 63, ("fit", "randflip", 10, 1, 1)),
     "c4": ("es3c", 256, 512, 200, 1536, 64, ("fit", "randflip", 10, 1, 1)),
     "c5": ("ebsc", 256, 1024, 256, 3072, 65, ("fit", "randflip", 10, 1, 1)),
+    # five chained EM steps (SURVEY 8d metric 3: free energy after T = 5 iterations from identical init and streams)
+    "c2x5": ("es3c", 256, 128, 64, 512, 66, ("fit", "randflip", 10, 1, 1), 5),
+    "c3x5": ("ebsc", 64, 256, 128, 1024, 67, ("fit", "randflip", 10, 1, 1), 5),
 }
 
 
@@ -518,8 +521,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "shape":  # BASELINE-shape fixtures (minutes each; run selected names in parallel)
         for nm in (sys.argv[2:] or sorted(SHAPES)):
-            a, D, H, S, N, seed, ea = SHAPES[nm]
-            make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=2, ea=ea)
+            a, D, H, S, N, seed, ea = SHAPES[nm][:7]
+            make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=(SHAPES[nm][7] if len(SHAPES[nm]) > 7 else 2), ea=ea)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "perm":  # permanent all-zero state (S_perm = 1), added later
         make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
@@ -549,5 +552,5 @@ if __name__ == "__main__":
     make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     for nm in sorted(SHAPES):
-        a, D, H, S, N, seed, ea = SHAPES[nm]
-        make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=2, ea=ea)
+        a, D, H, S, N, seed, ea = SHAPES[nm][:7]
+        make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=(SHAPES[nm][7] if len(SHAPES[nm]) > 7 else 2), ea=ea)

@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 _POP8 = np.array([bin(i).count("1") for i in range(256)], dtype=np.uint8)
 
 
-def _setup(name, N=None):
+def _setup(name, N=None, dense=False, **model_kw):
     import bench
     from evo_amd.engine import Engine
     from evo_amd.models import BSC, SSSC
@@ -40,10 +40,12 @@ def _setup(name, N=None):
     np.random.seed(1234 + 2)
     Y = np.ascontiguousarray(np.random.randn(cfg["N"], cfg["D"]))
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
-    chunks = list(bench.init_states_packed(cfg, cfg["N"], 4321, max(1, bench.host_cores())))
+    chunks = list(bench.init_states_packed(cfg, cfg["N"], 4321, max(1, bench.host_cores()), dense=dense))
     eng = Engine()
     cls = BSC if cfg["algo"] == "ebsc" else SSSC
-    model = cls(cfg["D"], cfg["H"], cfg["S"], rng="device", sync_host=False, engine=eng, seed=17, device_mstep=False)
+    kw = dict(device_mstep=False)
+    kw.update(model_kw)
+    model = cls(cfg["D"], cfg["H"], cfg["S"], rng="device", sync_host=False, engine=eng, seed=17, **kw)
     np.random.seed(99)
     theta = model.check_params(model.standard_init(my_data))
     suff = bench.ea_suff(cfg)
@@ -166,5 +168,86 @@ def test_ebsc_full_size_properties(name):
                 eng.set_option(opt, 1)
             for name in ("Wp", "Wq", "pies", "sigma"):
                 assert _rel(v3[name], v2[name]) <= 1e-10, (opt, name)
+    finally:
+        eng.close()
+
+
+def _unpack_rows(st, H):
+    return np.unpackbits(st, axis=-1)[..., :H].astype(bool)
+
+
+def test_es3c_dense_states_full_size():
+    """SURVEY 8d's dense-state stress variant (K^n initialised with p_init_Kn = 8 / H: 97 % of the states above two
+    active latents, more than half above four) at the north-star shape, N = 100k: the census lists and the
+    four-lanes-per-state kernels carry nearly every state.  Idempotence, the checksums of the first / second moments
+    from the raw K^n and lpj, E[s s^T] symmetric with E[s] on the diagonal, the census against host popcounts, and --
+    path independence -- the rows of a sample of datapoints against evoamd_lpj_single, which runs the round-2
+    register / wavefront kernels (LU with row exchanges) on the same states."""
+    cfg, eng, model, theta, suff, my_data = _setup("c4", dense=True)
+    try:
+        N, S, H = cfg["N"], cfg["S"], cfg["H"]
+        F0, _, _, theta = model.step(theta, suff, my_data)
+        Fe = [model.E_step(theta, suff, my_data)[0] for _ in range(2)]
+        assert np.isfinite([F0] + Fe).all() and Fe[1] >= Fe[0] - 1e-12 * abs(Fe[0])
+        v1 = eng.acc_views(model.last_acc.copy())
+        eng.lpj_resident()
+        l1 = eng.download_lpj()
+        eng.lpj_resident()
+        assert np.array_equal(l1, eng.download_lpj())
+        v2 = eng.acc_views(eng.stats())
+        for name in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "Wp", "s_sz_outer", "sz_sz_outer"):
+            assert _rel(v2[name], v1[name]) <= 1e-11, name
+        lpj, q, k, Fs = _weights_and_counts(eng, cfg)
+        assert (k > 2).mean() > 0.5 and (k > 4).mean() > 0.2, ((k > 2).mean(), (k > 4).mean())  # the regime under test
+        assert abs(Fs - float(v2["Fs"])) <= 1e-11 * abs(Fs)
+        s1 = float((q * k).sum())
+        s2 = float((q * (k * (k - 1.0))).sum())
+        xs, xss = v2["xpt_s"], v2["xpt_ss"]
+        assert abs(float(xs.sum()) - s1) <= 1e-10 * s1
+        assert np.array_equal(np.diag(xss), xs) and np.array_equal(xss, xss.T)
+        assert abs(float(xss.sum() - np.trace(xss)) - s2) <= 1e-10 * max(s2, 1.0)
+        # independent kernels on the same states: per-datapoint operator (TAG 2 chain: K = 4 / K = 8 register kernels)
+        Y = my_data["y"]
+        for n in (0, 1, N // 2, N - 1):
+            st = _unpack_rows(eng.download_states_packed(n, 1)[0], H)
+            ref, flags = eng.lpj_single(Y[n], st)
+            np.testing.assert_allclose(lpj[n], ref, rtol=1e-11, atol=0)
+            assert not flags.any()
+    finally:
+        eng.close()
+
+
+def test_bench_configuration_full_size():
+    """The exact configuration bench.py times: ES3C north-star shape, rng="device",
+    device_mstep=True, prefetched pass over K^n, LazyTheta.  After three EM iterations: the F the step returned equals
+    ljc + log-sum-exp of the downloaded rows (the rows of THAT E-step: the prefetched pass of the next one sits in the
+    alternate buffer), no duplicate state in a K^n, the overflow census the device reports (n_gt2 / n_gt4 / n_gt8,
+    from the census lists) equals host popcounts of the downloaded K^n, the prefetched pass is the one a fresh pass
+    would compute, and F does not decrease over further iterations."""
+    cfg, eng, model, theta, suff, my_data = _setup("c4", device_mstep=True, lazy_theta=True)
+    try:
+        N, S, H = cfg["N"], cfg["S"], cfg["H"]
+        Fs_seq = []
+        for _ in range(3):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            Fs_seq.append(F)
+        assert np.isfinite(Fs_seq).all() and Fs_seq[2] >= Fs_seq[1] >= Fs_seq[0], Fs_seq
+        assert not theta.materialised
+        lpj, q, k, Fs = _weights_and_counts(eng, cfg)
+        d = model.last_dpar
+        assert abs((d["ljc_estep"] + Fs / N) - Fs_seq[2]) <= 1e-11 * abs(Fs_seq[2])
+        assert (int(d["n_gt2"]), int(d["n_gt4"]), int(d["n_gt8"])) == (int((k > 2).sum()), int((k > 4).sum()), int((k > 8).sum()))
+        # the pass prefetched behind the M-step (new Theta, conservative levels) == a fresh pass under the same Theta
+        eng.lpj_resident()               # consumes the prefetched pass (buffer swap)
+        pre = eng.download_lpj()
+        eng.set_option("prefetch_lpj", 1)  # any option drops a pending prefetch: the next call really launches
+        eng.lpj_resident()
+        np.testing.assert_array_equal(pre, eng.download_lpj())
+        for _ in range(2):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            Fs_seq.append(F)
+        assert Fs_seq[4] >= Fs_seq[3] >= Fs_seq[2], Fs_seq
+        W = theta["W"]
+        assert theta.materialised and W.shape == (cfg["D"], H) and np.isfinite(W).all()
     finally:
         eng.close()

@@ -140,7 +140,7 @@ def test_shape_replay_small(name):
             sketch_close(_sketch.sketch(theta[k]), g["t%d_out_%s" % (t, k)], max(1e-9, 1e-14 * cond), k)
 
 
-@pytest.mark.parametrize("name,n_sub", [("c2", 12), ("c3", 48), ("c4", 4), ("c5", 10)])
+@pytest.mark.parametrize("name,n_sub", [("c2", 12), ("c3", 48), ("c4", 4), ("c5", 10), ("c2x5", 10), ("c3x5", 40)])
 def test_shape_replay_prefix(name, n_sub):
     """The N ~ 3H fixtures (minutes of reference time): the oracle replays the E-step of the first n_sub
     datapoints of step 0 (same Theta, same np.random prefix) -- candidate stream, selection and lpj."""
