@@ -169,6 +169,7 @@ struct evoamd_ctx {
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
   int bins_min = 256;  // option "pair_bins_min": pair bins from this many resident states (x 1024) on
+  int bins_nwg = 2048;  // option "pair_bins_nwg" (read by evoamd_configure): producer workgroups = private regions per bin
   int bsc_wave_opt = 1;  // option "bsc_stats_wave": EBSC statistics on the wave-per-datapoint kernel (0: round-1 kernel)
   int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
   double *gemm_ws = nullptr;  // partial tiles of the stream-K contractions (gemm_sk_reduce_kernel adds them to C)
@@ -577,6 +578,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->b_tn_opt = value;
     return 0;
   }
+  if (strcmp(name, "pair_bins_nwg") == 0) {
+    if (value < 256 || value > 2048 || (value % 256) != 0) return fail(EVOAMD_E_INVALID, "pair_bins_nwg: 256 .. 2048, multiple of 256");
+    c->bins_nwg = value;
+    return 0;
+  }
   if (strcmp(name, "pair_bins_min") == 0) {
     c->bins_min = value;
     return 0;
@@ -813,7 +819,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       pb.nb = (int)cdiv(nfold, pb.rf);
       // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
       // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
-      pb.nwg = 2048;
+      pb.nwg = c->bins_nwg;
       pb.cap = (int)std::max<i64>(64, 3 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
       // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
@@ -1712,7 +1718,24 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "sssc lpj main");
   }
-  if (need[0] || need[1] || need[2]) {
+  if (c->census_opt && (need[0] || need[1] || need[2])) {
+    // on-the-fly chains (candidate batches, shared / transient sets): list 1 -> 3..4 latents -> list 2 -> 5..8 latents
+    // (four-lanes-per-state kernel) -> list 3 = the pivoting wavefront kernel, which also takes the states the quads
+    // pass on and therefore always runs behind them
+    SpanGuard g(c, KID_LPJ_OVF);
+    // (3..4 latents of a chain: the K = 4 thread-per-state register kernel -- 58 us against 77 us of the quad kernel
+    // on the ~400k listed candidates of the north-star shape; its lists are long enough to fill whole waves)
+    if (need[0])
+      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{});
+    DBG_SYNC(c, "sssc lpj chain 3..4");
+    if (need[1]) sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, i2, o3, o3, PairBins{}, nullptr);
+    DBG_SYNC(c, "sssc lpj chain 5..8");
+    sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+        a, i3, none_o, SSSC_KCAP);
+    c->pending_skip &= ~4;  // list 3 has been served
+    HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "sssc lpj chain wavefront level");
+  } else if (need[0] || need[1] || need[2]) {
     SpanGuard g(c, KID_LPJ_OVF);
     // the levels carry the pass's TAG in their names, so a kernel trace separates the pass over K^n from the
     // candidate batch level by level
@@ -2315,7 +2338,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         bsc_pb = PairBins{};
         if (c->pbins.ent && (c->pair_bins == 2 || (c->pair_bins == 1 && N * (i64)c->S >= (i64)c->bins_min * 1024))) bsc_pb = c->pbins;
         int sgrid = (int)std::min<i64>(cdiv(nc, 4), (i64)c->n_cu * per_cu * 2);
-        if (sgrid > 2048) sgrid = 2048;  // pb.nwg, and the size of the sigma partials
+        if (sgrid > 2048) sgrid = 2048;  // the size of the sigma partials
+        if (bsc_pb.ent && sgrid > bsc_pb.nwg) sgrid = bsc_pb.nwg;  // one private region per producer workgroup and bin
         bsc_grid = sgrid;
         void *EsP = c->f32 ? (void *)c->Esf : (void *)c->Es;
         double *csb = c->acc_base + 4;

@@ -100,6 +100,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "b_transposed" (0/1/2, default 1; read by the next evoamd_configure): from N = 8192 datapoints, H = 768 and D = 128 on
  * (2: from H = 128, D = 32 on) the context keeps Y^T as well and computes B = Y W with the 128 x 128 tile kernel; 0: always
  * the row-major 64 x 64 tile product.
+ * "pair_bins_nwg" (256 .. 2048 in steps of 256, default 2048; read by the next evoamd_configure): producer workgroups of
+ * the statistics pass = private regions per pair bin (fewer, longer regions for the reduce pass to read).
  * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
  * "bsc_stats_wave" (0/1, default 1): EBSC statistics on the wave-per-datapoint kernel (next datapoint prefetched, Wq pairs
  * through the pair bins, column sums in the kernel); 0: the one-shot kernel + column-sum pass.
