@@ -292,6 +292,9 @@ struct evoamd_ctx {
   size_t ovf_rec_n = 0;
   unsigned long long kn_gen = 1, census_gen = 0;
   int census_opt = 1;   // option "census_lists": 0 = round-2 level chains everywhere
+  int stats_flat = 0;   // option "stats_flat": census mode, states with <= 2 latents on the thread-per-state kernel instead of
+                        // the wave-per-datapoint one.  Measured (c4, steady state): 504-539 vs 584 us for the kernel, but the
+                        // quad levels then share 256 bin regions instead of 2048 (107 vs 69 us) and N / 8 shards lose: off
   int census_skip = 0;  // levels that passes over the CURRENT census did not launch (checked when it is rebuilt)
   size_t list_words = 0;  // capacity of each overflow list (ints)
   // scratch for single / shared evaluations
@@ -449,6 +452,7 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipEventCreateWithFlags(&c->ev_theta_done, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
 
+  HIP_TRY(hipFuncSetAttribute((const void *)sssc_stats_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               112 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -597,6 +601,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "stats_flat") == 0) {
+    c->stats_flat = value != 0;
     return 0;
   }
   if (strcmp(name, "theta_copy_engine") == 0) {
@@ -2440,6 +2448,22 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       const int ccap = (int)list_cap(total);
       const ListIn cA = {c->clist, c->clist_n, ccap}, cB = {c->clist + c->clist_words, c->clist_n + LIST_SHARDS, ccap},
                    cC = {c->clist + 2 * c->clist_words, c->clist_n + 2 * LIST_SHARDS, ccap};
+      // census mode, thread-per-state form of the main kernel: G datapoints per 1024-thread workgroup and round
+      int flatG = 0;
+      size_t flat_lds = 0;
+      if (census && c->stats_flat && c->S <= FLAT_T && (H % 2) == 0 && (D % 2) == 0 && sc.Ez == sc.Es + H && c->stats_waves == 0) {
+        flatG = FLAT_T / c->S;
+        const int gmax = (int)(((size_t)140 * 1024 / sizeof(double) - (size_t)7 * H) / ((size_t)4 * H + 4));
+        if (flatG > gmax) flatG = gmax;
+        if (flatG > 4 * FLAT_T / H) flatG = 4 * FLAT_T / H;  // the round's B rows: at most two 16-byte pieces per thread
+        if (flatG >= 1) flat_lds = ((size_t)H * (4 * flatG + 7) + 4 * flatG) * sizeof(double);
+      }
+      if (flatG >= 1 && pb.ent) {
+        // one resident workgroup per CU produces: the bins' entry space re-cut into n_cu regions per bin
+        const i64 per_bin = (i64)pb.nwg * pb.cap;
+        pb.nwg = std::min(pb.nwg, c->n_cu);
+        pb.cap = (int)std::min<i64>(per_bin / pb.nwg, 1 << 30);
+      }
       if (census) {
         // the quad levels FIRST: records of the listed states (read back by the wave-per-datapoint kernel), their
         // diagonal second moments into the column-sum slices, their pairs into the bins (regions shared by workgroup index)
@@ -2463,7 +2487,14 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           DBG_SYNC(c, "sssc stats quad levels");
         }
       }
-      {
+      if (flatG >= 1) {
+        SpanGuard g(c, KID_STATS);
+        int fgrid = (int)std::min<i64>(cdiv(nc, flatG), (i64)c->n_cu);
+        if (pb.ent && fgrid > pb.nwg) fgrid = pb.nwg;
+        sssc_stats_flat_kernel<<<fgrid, FLAT_T, flat_lds, c->stream>>>(sc, pb, c->ovf_rec, flatG);
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "sssc stats main (flat)");
+      } else {
         // one wave per datapoint, persistent workgroups: W x 2 H doubles of rows + 3 H of column accumulators in LDS
         int Wv = (size_t)(4 * 2 + 3) * H * sizeof(double) <= 150 * 1024 ? 4 : 1;
         // (8 / 16 waves per workgroup were measured: c4 8 waves -4 %, 16 waves 2x slower; c2 16 waves 112 vs 74 us)

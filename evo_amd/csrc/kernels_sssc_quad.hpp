@@ -544,3 +544,245 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
       if (cs_diag[h] != 0.0) unsafeAtomicAdd(&sl[h], cs_diag[h]);
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// Statistics of the states with at most two active latents, census mode, "flat" form: the (n, state) pairs in natural
+// order, ONE THREAD per state, 1024-thread workgroups that own G = floor(1024 / S) consecutive datapoints per round
+// (S = 200: 1000 of 1024 threads busy).  The wave-per-datapoint kernel (kernels_sssc.hpp) walks a datapoint in four
+// rounds of 64 lanes of which the last holds 8 states (22 % of its issue slots idle), at two waves per SIMD because
+// every wave keeps a prefetched datapoint in registers.  Here a thread keeps one state, so a CU holds 16 waves (4 per
+// SIMD); the rows of the round's G datapoints live in LDS next to their B rows (double-buffered).  A round is
+//   phase A  weights, kappa, first moments (LDS atomics into the datapoint's rows), pair second moments (bins), records
+//   -- barrier --
+//   phase B  rows out to [Es | Ez] (16-byte stores), added to the workgroup's column sums and zeroed again; the next
+//            round's B rows and row statistics into the other LDS buffer
+//   -- barrier --
+// and everything a thread needs of its NEXT state is in flight a whole round ahead: digest + lpj are requested in
+// phase B two rounds before, pair-table entry and record at the start of phase A one round before (first version:
+// requested and waited for inside the round -- 54 % of the wave cycles in s_waitcnt / s_barrier, the kernel no faster
+// than the wave-per-datapoint one).  The barriers order LDS traffic only (lds_barrier: no wait for the outstanding
+// global loads / stores / atomics).  Same arithmetic per state as sssc_stats_wave_kernel<.., true>.
+// Dynamic LDS: H (4 G + 7) + 4 G doubles.
+// ---------------------------------------------------------------------------------------
+#define FLAT_T 1024
+struct FlatGather {  // what phase A reads of a state besides digest and lpj
+  PairEntry pe;
+  double rq, z0, z1, z2, z3;  // head of the state's record (census lists: 3..8 active latents)
+};
+__global__ __launch_bounds__(FLAT_T) void sssc_stats_flat_kernel(SsscArgs a, PairBins pb, const OvfRec *__restrict__ rec,
+                                                                   int G) {
+  a.s2inv = a.dpar[DP_S2INV];
+  extern __shared__ double fl[];
+  __shared__ int bcnt[PB_MAX_BINS];
+  const int H = a.H, S = a.C, tid = threadIdx.x;
+  double *rows = fl;                               // [G][2][H]: E_q[s] | E_q[s z] of each datapoint of the round
+  double *Bs0 = rows + (size_t)2 * G * H;          // [2][G][H]
+  double4 *D1s = (double4 *)(Bs0 + (size_t)2 * G * H);  // [H]   (offset 4 G H doubles: 32-byte aligned, H even)
+  double *accS = (double *)(D1s + H), *accD = accS + 2 * H;  // accS | accZ | accD
+  double *rstat0 = accD + H;                       // [2][G][2]: row maximum, row sum + tiny
+  const bool binned = pb.ent != nullptr;
+  const double s = a.s2inv;
+  const float rS = 1.0f / (float)S;
+  // thread -> (datapoint of the round, state): t = dp S + c
+  int dp = (int)(((float)tid + 0.5f) * rS);
+  if (dp * S > tid) dp--;
+  if ((dp + 1) * S <= tid) dp++;
+  const int c = tid - dp * S;
+  const bool slot = tid < G * S;  // this thread holds a state when its datapoint exists
+  const i64 g_stride = (i64)gridDim.x * G;
+  auto n_in = [&](i64 g0) {  // datapoints of the round that starts at g0
+    const i64 left = a.N - g0;
+    return (int)(left < (i64)G ? (left > 0 ? left : 0) : (i64)G);
+  };
+  // every request is unconditional (clamped addresses): a load under a branch makes the compiler wait for everything
+  // outstanding at the next use of anything loaded earlier
+  auto request_state = [&](i64 g0, u64 &dg, double &l) {
+    const bool live = slot && dp < n_in(g0);
+    const i64 n = live ? g0 + dp : 0;
+    dg = a.dig[n * S + (live ? c : 0)];
+    l = a.lpj_in[n * a.ldo + a.col0 + (live ? c : 0)];
+  };
+  auto request_gather = [&](i64 g0, u64 dg, FlatGather &g) {
+    const bool live = slot && dp < n_in(g0);
+    const int k = live ? dig_k(dg) : 0;
+    g.pe = a.PT[k == 2 ? (i64)dig_idx(dg, 0) * H + dig_idx(dg, 1) : 0];
+    const i64 e = (k > 2 && k <= 8) ? (g0 + dp) * S + c : 0;
+    const double2 *r2 = (const double2 *)(rec + e);  // {idx[8]} {qn, pad} {z0, z1} {z2, z3} {z4, z5} {z6, z7}
+    const double2 q2 = r2[1], za = r2[2], zb = r2[3];
+    g.rq = q2.x;
+    g.z0 = za.x;
+    g.z1 = za.y;
+    g.z2 = zb.x;
+    g.z3 = zb.y;
+  };
+  // The round's B rows (ng x H doubles, contiguous) go from global memory straight into LDS (global_load_lds_dwordx4: a
+  // wave-instruction lands 64 x 16 bytes behind a wave-uniform LDS base, no registers in between -- held in registers
+  // across a phase they were spilled, i.e. waited for, right behind their loads).  The data is in LDS once the issuing
+  // wave's vmcnt has covered the load; other waves read it behind the next barrier.
+  auto dma_rows = [&](i64 g0, int par) {
+    const int ng = n_in(g0);
+    const double2 *src = (const double2 *)(a.Bm + (ng > 0 ? g0 : 0) * H);
+    double2 *dst = (double2 *)(Bs0 + (size_t)par * G * H);
+    const int lim = ng * H / 2, nb2 = G * H / 2;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int i = tid + u * FLAT_T;
+      if (i < nb2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (i < lim ? i : 0)),
+                                         (__attribute__((address_space(3))) void *)(dst + (i & ~63)), 16, 0, 0);
+    }
+  };
+  auto request_stat = [&](i64 g0, double &rmax, double &rsum) {
+    const i64 nr = (tid < n_in(g0)) ? g0 + tid : 0;
+    rmax = a.rowmax[nr];
+    rsum = a.rowsum[nr];
+  };
+  auto store_stat = [&](int par, double rmax, double rsum, int ng) {
+    if (tid < ng) {
+      rstat0[(size_t)par * 2 * G + 2 * tid] = rmax;
+      rstat0[(size_t)par * 2 * G + 2 * tid + 1] = rsum + EVO_F64_TINY;
+    }
+  };
+  // ---- prologue: tables, zeroed rows, the first round's inputs (waited for once), the second round's state requested
+  for (int i = tid; i < 3 * H; i += FLAT_T) accS[i] = 0.0;
+  for (int i = tid; i < H; i += FLAT_T) D1s[i] = a.D1[i];
+  for (int i = tid; i < G * H; i += FLAT_T) ((double2 *)rows)[i] = make_double2(0.0, 0.0);
+  if (binned)
+    for (int i = tid; i < pb.nb; i += FLAT_T) bcnt[i] = pb.gcnt[(size_t)i * pb.nwg + blockIdx.x];
+  const i64 g_first = (i64)blockIdx.x * G;
+  u64 dg_cur, dg_nxt;
+  double l_cur, l_nxt;
+  FlatGather gc;
+  {
+    double rmax, rsum;
+    dma_rows(g_first, 0);
+    request_stat(g_first, rmax, rsum);
+    request_state(g_first, dg_cur, l_cur);
+    store_stat(0, rmax, rsum, n_in(g_first));
+    request_gather(g_first, dg_cur, gc);
+    request_state(g_first + g_stride, dg_nxt, l_nxt);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the B rows is in LDS
+  lds_barrier();
+  int par = 0;
+  for (i64 g0 = g_first; g0 < a.N; g0 += g_stride, par ^= 1) {
+    const int ng = n_in(g0);
+    const bool live = slot && dp < ng;
+    // ---- phase A.  First the NEXT round's pair-table entry / record (its digest arrived during the last round) ...
+    dma_rows(g0 + g_stride, par ^ 1);  // (the buffer the round before this one read: every wave left it two barriers ago)
+    FlatGather gn;
+    request_gather(g0 + g_stride, dg_nxt, gn);
+    u64 dg_nn;
+    double l_nn;
+    request_state(g0 + 2 * g_stride, dg_nn, l_nn);  // ... and the digest / lpj of the round after that
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then this round's states
+    const int k = live ? dig_k(dg_cur) : 0;
+    const int idx0 = dig_idx(dg_cur, 0), idx1 = dig_idx(dg_cur, 1);
+    double *rowS = rows + (size_t)(live ? dp : 0) * 2 * H, *rowZ = rowS + H;
+    const double *Bn = Bs0 + ((size_t)par * G + (live ? dp : 0)) * H;
+    const double *rst = rstat0 + (size_t)par * 2 * G;
+    if (k == 1 || k == 2) {
+      const bool pair = k == 2;
+      const double q = exp(l_cur + (0.0 - rst[2 * dp]));
+      if (q != 0.0) {
+        const double qn = q / rst[2 * dp + 1];
+        const double4 d0 = D1s[idx0];  // mu, L1, G_hh, Lam
+        const double b0 = Bn[idx0];
+        double g01 = 0.0, l00 = d0.w, l01 = 0.0, l10 = 0.0, l11 = 0.0, mu1 = 0.0, g11 = 0.0, bb1 = 0.0;
+        if (pair) {
+          const double4 d1 = D1s[idx1];
+          g01 = gc.pe.g01;
+          l00 = gc.pe.l00;
+          l01 = gc.pe.l01;
+          l10 = gc.pe.l10;
+          l11 = gc.pe.l11;
+          mu1 = d1.x;
+          g11 = d1.z;
+          bb1 = Bn[idx1];
+          if (pair_singular_lam(gc.pe.l00)) atomicOr(a.err, 2);
+        }
+        const double mu0 = d0.x;
+        const double v0 = b0 - d0.z * mu0 - g01 * mu1;
+        const double v1 = bb1 - g01 * mu0 - g11 * mu1;
+        const double k0 = s * (l00 * v0 + l01 * v1) + mu0;  // kappa = Lam v / sigma2 + mu  (sssc.py:574-575)
+        const double k1 = s * (l10 * v0 + l11 * v1) + mu1;
+        unsafeAtomicAdd(&rowS[idx0], qn);
+        unsafeAtomicAdd(&rowZ[idx0], qn * k0);
+        unsafeAtomicAdd(&accD[idx0], qn * (l00 + k0 * k0));
+        if (pair) {
+          unsafeAtomicAdd(&rowS[idx1], qn);
+          unsafeAtomicAdd(&rowZ[idx1], qn * k1);
+          unsafeAtomicAdd(&accD[idx1], qn * (l11 + k1 * k1));
+          const double pv = qn * (l01 + k0 * k1), pw = qn * (l10 + k1 * k0);
+          if (!(binned && pb_append(pb, bcnt, blockIdx.x, H, idx0, idx1, qn, pv, pw))) {
+            const i64 o01 = (i64)idx0 * H + idx1;
+            unsafeAtomicAdd(&a.xss_o[o01], qn);
+            unsafeAtomicAdd(&a.xszsz_o[o01], pv);
+            unsafeAtomicAdd(&a.xszsz_o[(i64)idx1 * H + idx0], pw);
+          }
+        }
+      }
+    } else if (k > 2 && k <= 8 && gc.rq != 0.0) {  // what the quad kernels computed for this state (digest: its first four latents)
+      const int h2 = dig_idx(dg_cur, 2), h3 = dig_idx(dg_cur, 3);
+      unsafeAtomicAdd(&rowS[idx0], gc.rq);
+      unsafeAtomicAdd(&rowZ[idx0], gc.z0);
+      unsafeAtomicAdd(&rowS[idx1], gc.rq);
+      unsafeAtomicAdd(&rowZ[idx1], gc.z1);
+      unsafeAtomicAdd(&rowS[h2], gc.rq);
+      unsafeAtomicAdd(&rowZ[h2], gc.z2);
+      if (k > 3) {
+        unsafeAtomicAdd(&rowS[h3], gc.rq);
+        unsafeAtomicAdd(&rowZ[h3], gc.z3);
+      }
+      if (k > 4) {  // 5..8 active latents (rare in a sparse K^n): the second half of the record, fetched here
+        const OvfRec *rp = rec + ((g0 + dp) * S + c);
+        const uint4 w0 = *(const uint4 *)rp->idx;
+        const double2 zc = ((const double2 *)rp)[4], zd = ((const double2 *)rp)[5];
+        const int hh[4] = {(int)(w0.z & 0xFFFFu), (int)(w0.z >> 16), (int)(w0.w & 0xFFFFu), (int)(w0.w >> 16)};
+        const double zz[4] = {zc.x, zc.y, zd.x, zd.y};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (4 + i < k) {
+            unsafeAtomicAdd(&rowS[hh[i]], gc.rq);
+            unsafeAtomicAdd(&rowZ[hh[i]], zz[i]);
+          }
+      }
+    }
+    lds_barrier();
+    // ---- phase B: [Es | Ez] rows of the round (adjacent in the [Y | Es | Ez | Ed] matrix) out, into the column sums, zeroed
+    // (the next round's row statistics: requested first, stored to the other LDS buffer last)
+    double rmax_n, rsum_n;
+    request_stat(g0 + g_stride, rmax_n, rsum_n);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      double2 *rows2 = (double2 *)rows;
+      for (int i = tid; i < ng * H; i += FLAT_T) {  // piece i = columns 2 j, 2 j + 1 of row r ([E_q[s] | E_q[s z]], 2 H wide)
+        const int r = i / H, j = i - r * H;
+        const double2 v = rows2[i];
+        ((double2 *)(a.Es + (g0 + r) * a.ldE))[j] = v;
+        if (v.x != 0.0) unsafeAtomicAdd(&accS[2 * j], v.x);
+        if (v.y != 0.0) unsafeAtomicAdd(&accS[2 * j + 1], v.y);
+        rows2[i] = make_double2(0.0, 0.0);
+      }
+    }
+    store_stat(par ^ 1, rmax_n, rsum_n, n_in(g0 + g_stride));
+    dg_cur = dg_nxt;
+    l_cur = l_nxt;
+    gc = gn;
+    dg_nxt = dg_nn;
+    l_nxt = l_nn;
+    // everything requested in phase A has had the whole round to land: the B rows of the next round must be in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  }
+  __syncthreads();
+  double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * H;
+  for (int h = tid; h < 3 * H; h += FLAT_T)
+    if (accS[h] != 0.0) unsafeAtomicAdd(&sl[h], accS[h]);
+  if (binned)
+    for (int i = tid; i < pb.nb; i += FLAT_T) {
+      const int cnt = bcnt[i];
+      pb.gcnt[(size_t)i * pb.nwg + blockIdx.x] = cnt < pb.cap ? cnt : pb.cap;
+    }
+}

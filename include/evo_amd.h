@@ -109,6 +109,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "stats_flat" (0/1, default 0: measured a few per cent at N = 100k, a loss at N / 8): with census lists, the ES3C statistics of the states with at most two active latents run
+ * on the thread-per-state kernel (1024-thread workgroups owning floor(1024 / S) datapoints per round, 16 waves per CU);
+ * 0: the wave-per-datapoint kernel.
  * "theta_copy_engine" (0/1, default 0; measured without gain): evoamd_mstep_device downloads Theta^new with asynchronous copies on a third
  * stream (copy engine) beside the kernels queued behind the update; 0: the mailbox kernel writes Theta into the pinned
  * host buffer itself, in front of them.

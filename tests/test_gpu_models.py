@@ -809,6 +809,32 @@ def test_reconstruct_first_call_without_host_sync(engine, algo):
         model.invalidate()
 
 
+def test_stats_flat_kernel_matches_wave_kernel(engine):
+    """Option "stats_flat": the thread-per-state form of the ES3C statistics kernel (LDS-DMA staged B rows, two-phase
+    rounds; off by default) against the wave-per-datapoint kernel on a reference fixture: every accumulator equal."""
+    from evo_amd.models import SSSC
+    g = load_golden("step_es3c_mid.npz")
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    Y = g["Y"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    accs = []
+    for flat in (0, 1):
+        engine.set_option("stats_flat", flat)
+        try:
+            model = SSSC(D, H, S, engine=engine)
+            theta = {k: np.array(g["t0_in_%s" % k]) for k in SSSC_KEYS}
+            theta["sigma2"] = np.float64(theta["sigma2"])
+            suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+            np.random.seed(1000 + int(g["seed"]))
+            model.E_step(theta, suff, my_data, _keep_acc=True)
+            accs.append(dict(engine.acc_views(model.last_acc.copy())))
+        finally:
+            engine.set_option("stats_flat", 0)
+    for nm in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp"):
+        np.testing.assert_allclose(accs[1][nm], accs[0][nm], rtol=1e-11, atol=1e-13, err_msg=nm)
+        np.testing.assert_allclose(accs[0][nm], g["t0_sum_%s" % nm], rtol=1e-9, atol=1e-12, err_msg=nm)
+
+
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 def test_lazy_theta_is_the_same_theta(engine, algo):
     """lazy_theta=True: step() hands back a LazyTheta whose arrays stay on the device until they are read.  Same
