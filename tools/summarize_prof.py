@@ -32,6 +32,22 @@ def main(out):
                                                                float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
                                                                float(r["Percentage"])))
         print()
+        tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+        bl = os.path.join(out, "bench_trace.json")
+        try:
+            import json
+            d = json.loads(open(bl).read().strip().splitlines()[-1])
+            iters = d["config"]["em_iterations_timed"] + d["warmup"] * d["config"]["em_iterations_per_step"] + 5
+            wall = d["config"]["ms_per_em_iteration"]
+            k = d["config"]["kernel_ms"]
+            print("Sum of all kernel durations / EM iterations of the run (%d): **%.3f ms per iteration**; wall clock of the same "
+                  "run's timed region: **%.3f ms per iteration** (the forked contraction overlaps the Theta-update chain, the "
+                  "chain's first kernel counts its queueing).  HIP-event spans of the same run (bench.py, whole passes over "
+                  "its timed iterations): lpj pass %.3f ms, statistics pass %.3f ms.\n"
+                  % (iters, tot_ns / 1e6 / iters, wall, d["roofline"]["avg_launch_ms"], d["roofline_stats"]["avg_launch_ms"]))
+            del k
+        except Exception as e:  # no bench line: only the table
+            print("(no bench line next to the trace: %s)\n" % e)
         print("Note: a kernel's duration runs from its dispatch to its end.  The H x H elimination chain (gjs32_first_kernel, "
               "then gjs32_step_kernel) is launched on the main stream while the persistent stream-K contraction "
               "(gemm_tn128_sk_f64) holds every CU slot on the second stream: the first kernel of the chain waits for a slot "
