@@ -116,7 +116,7 @@ def pass_kernels(cfg):
     """Kernels of the pass over all N x S resident states, as rocprofv3 names them (TAG 0 = the pass over K^n)."""
     hw = (cfg["H"] + 63) // 64
     if cfg["algo"] == "es3c":  # census lists (round 3): main kernel (|s| <= 2), quad levels 3..4 / 5..8, wavefront kernel
-        return ["void sssc_main_lpj_kernel<0, 512, %d, 2, false>" % (hw if hw in (1, 2, 4, 8, 16) else 0), "census_kernel",
+        return ["void sssc_main_lpj_kernel<0, 512, %d, 2, false>" % (hw if hw in (1, 2, 4, 8, 16) else 0),
                 "void sssc_quad_kernel<1, 0, 0>", "void sssc_quad_kernel<2, 0, 0>", "void sssc_big_kernel<0, 0>"]
     return ["void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)]
 
@@ -125,7 +125,8 @@ def stats_kernels(cfg):
     hw = (cfg["H"] + 63) // 64
     hwt = hw if hw in (1, 2, 4, 8, 16) else 0
     if cfg["algo"] == "es3c":
-        return ["void sssc_stats_wave_kernel<%d, 4, true>" % hwt, "pair_bins_reduce_kernel", "void sssc_quad_kernel<1, 1, 2>",
+        # (the census of a new K^n runs at the head of the first pass that needs it: the statistics pass behind vary_Kn)
+        return ["void sssc_stats_wave_kernel<%d, 4, true>" % hwt, "census_kernel", "pair_bins_reduce_kernel", "void sssc_quad_kernel<1, 1, 2>",
                 "void sssc_quad_kernel<2, 1, 2>", "void sssc_big_kernel<1, 2>", "sssc_finish_kernel"]
     sr = (cfg["S"] + 63) // 64
     if sr <= 4:  # wave-per-datapoint kernel + pair bins (evo_amd.hip: bsc_wave)
@@ -493,6 +494,8 @@ def main():
     from evo_amd.models import BSC, SSSC
 
     eng = Engine()  # LOCAL_RANK selects the GPU
+    if args.dense_states:  # 10..28 pairs of second moments per state instead of <= 1: room for them in the pair bins (7.7 GB)
+        eng.set_option("pair_bins_scale", 12)
     for kv in args.option:
         name, _, val = kv.partition("=")
         eng.set_option(name, int(val))
@@ -563,7 +566,8 @@ def main():
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(args.config, kernels),
                     "traffic_note": "HBM bytes per pass, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, read "
-                                    "side corrected for gfx950, summed over the kernels of the span; profiles/r02_*",
+                                    "side corrected for gfx950 (2 x FETCH_SIZE: an upper bound for kernels whose loads are 8 bytes per lane), "
+                                    "summed over the kernels of the span; profiles/r03_* (r02_* where a config was not re-profiled)",
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "algorithmic_bytes_note": "SURVEY 8d: N_rank x (D*8 + S*(ceil(H/8) + 8)), states priced bit-packed",
                     "avg_launch_ms": ms, "launches_timed": launches}

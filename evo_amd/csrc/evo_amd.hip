@@ -169,6 +169,9 @@ struct evoamd_ctx {
   int stats_waves = 0;  // option "stats_waves" (measurement): waves per workgroup of the ES3C statistics kernel, 0 = 4
   PairBins pbins = {};
   int bins_min = 256;  // option "pair_bins_min": pair bins from this many resident states (x 1024) on
+ int bins_scale = 3;  // option "pair_bins_scale" (read by evoamd_configure): entry capacity of the pair bins in units of N x S
+                       // (3: every resident state a pair, with a margin of three -- a sparse K^n; a K^n of 5..8 latents per
+                       // state leaves 10..28 pairs per state: the dense bench asks for 12 = 7.7 GB at the north-star shape)
   int bins_nwg = 2048;  // option "pair_bins_nwg" (read by evoamd_configure): producer workgroups = private regions per bin
   int bsc_wave_opt = 1;  // option "bsc_stats_wave": EBSC statistics on the wave-per-datapoint kernel (0: round-1 kernel)
   int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
@@ -582,6 +585,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->b_tn_opt = value;
     return 0;
   }
+  if (strcmp(name, "pair_bins_scale") == 0) {
+    if (value < 1 || value > 64) return fail(EVOAMD_E_INVALID, "pair_bins_scale: 1 .. 64");
+    c->bins_scale = value;
+    return 0;
+  }
   if (strcmp(name, "pair_bins_nwg") == 0) {
     if (value < 256 || value > 2048 || (value % 256) != 0) return fail(EVOAMD_E_INVALID, "pair_bins_nwg: 256 .. 2048, multiple of 256");
     c->bins_nwg = value;
@@ -828,7 +836,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
       // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
       pb.nwg = c->bins_nwg;
-      pb.cap = (int)std::max<i64>(64, 3 * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
+      pb.cap = (int)std::max<i64>(64, (i64)c->bins_scale * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
       // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
       // rest, the statistics kernels use their global-atomic paths
@@ -1692,10 +1700,17 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
         sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, cB, none_o, o3, PairBins{}, nullptr);
       }
       DBG_SYNC(c, "sssc lpj quad level 5..8");
-      // the pivoting wavefront kernel: resident states above eight latents, then what the quads passed on
+      // the pivoting wavefront kernel: resident states above eight latents, then what the quads passed on -- sized for
+      // 16 latents (6.8 KB of LDS per state: ~20 workgroups per CU; at the full 64 it is 98 KB, ONE per CU, and a dense
+      // K^n(0) with 40 % of its states above eight latents took 0.5 s in it), the few states beyond go on to list 2
       SpanGuard gl(c, KID_LPJ_K9P);
-      sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-          a, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_o, SSSC_KCAP, i3);
+      sssc_big_kernel<0, TAG><<<std::max(256u, level_grid(c, 2, TAG, total * 256, 8192, 1)), 64, big_lds(16), c->stream>>>(
+          a, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, o2, 16, i3);
+      if (need[2])
+        sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+            a, i2, none_o, SSSC_KCAP);
+      else
+        c->pending_skip |= 2;  // nobody serves list 2: it must be found empty when the counters are cleared
       HIP_TRY(hipGetLastError());
       DBG_SYNC(c, "sssc lpj census levels");
     }
@@ -2551,8 +2566,13 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           SpanGuard g(c, KID_STATS_OVF);
           const int tg = c->cand_from_device ? 1 : 2;
           SpanGuard gl(c, KID_STATS_K9P);
-          sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-              sc, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, none_out, SSSC_KCAP, i3);
+          sssc_big_kernel<1><<<std::max(256u, level_grid(c, 2, tg, total * 256, 8192, 1)), 64, big_lds(16), c->stream>>>(
+              sc, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, o2, 16, i3);
+          if (need[2])
+            sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
+                sc, i2, none_out, SSSC_KCAP);
+          else
+            c->pending_skip |= 2;
           HIP_TRY(hipGetLastError());
           DBG_SYNC(c, "sssc stats wavefront level (census)");
         }

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
         if (C == 1) r->z[4 + t] = 0.0;
       }
       // second moments: kappa and Lam_A of the wave's 16 states go through LDS, then ALL lanes walk the (state, i, c)
-      // slots -- one element of xpt_szsz each (diagonal: into the workgroup's column sums) -- instead of every lane
+      // slots -- the upper-triangle ones carry one element of xpt_szsz AND its mirror (both live in LDS here), the
+      // diagonal ones go into the workgroup's column sums -- instead of every lane
       // executing the unrolled pairs of its own columns (K (K - 1) append bodies with a quarter of the lanes busy)
       if (t == 0 && !emit) st.ks[q] = 0;
 #pragma unroll
@@ -518,14 +519,13 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
           const double vv = w * fma(st.kap[qq][i], kc, st.lam[qq][i][cc]);
           if (i == cc) {
             unsafeAtomicAdd(&cs_diag[hc], vv);
-          } else if (hi < hc) {  // upper triangle (hi, hc): xpt_ss once per unordered pair, with this element
-            if (!(binned && pb_append(pb, bcnt, blockIdx.x, H, hi, hc, w, vv, 0.0))) {
+          } else if (i < cc) {  // latents ascend: (hi, hc) is an upper-triangle element; its mirror rides in the same entry
+            const double vl = w * fma(kc, st.kap[qq][i], st.lam[qq][cc][i]);
+            if (!(binned && pb_append(pb, bcnt, blockIdx.x, H, hi, hc, w, vv, vl))) {
               unsafeAtomicAdd(&a.xss_o[(i64)hi * H + hc], w);
               unsafeAtomicAdd(&a.xszsz_o[(i64)hi * H + hc], vv);
+              unsafeAtomicAdd(&a.xszsz_o[(i64)hc * H + hi], vl);
             }
-          } else {  // lower triangle: element (hi, hc) is the mirror of (hc, hi)
-            if (!(binned && pb_append(pb, bcnt, blockIdx.x, H, hc, hi, 0.0, 0.0, vv)))
-              unsafeAtomicAdd(&a.xszsz_o[(i64)hi * H + hc], vv);
           }
         }
       }

@@ -100,6 +100,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "b_transposed" (0/1/2, default 1; read by the next evoamd_configure): from N = 8192 datapoints, H = 768 and D = 128 on
  * (2: from H = 128, D = 32 on) the context keeps Y^T as well and computes B = Y W with the 128 x 128 tile kernel; 0: always
  * the row-major 64 x 64 tile product.
+ * "pair_bins_scale" (1 .. 64, default 3; read by the next evoamd_configure): entry capacity of the pair bins in units of
+ * N x S entries of 32 bytes (a K^n of mostly 5..8 active latents needs ~12; entries beyond the capacity fall back to atomics).
  * "pair_bins_nwg" (256 .. 2048 in steps of 256, default 2048; read by the next evoamd_configure): producer workgroups of
  * the statistics pass = private regions per pair bin (fewer, longer regions for the reduce pass to read).
  * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
