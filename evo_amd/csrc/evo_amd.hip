@@ -836,12 +836,13 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
       // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
       pb.nwg = c->bins_nwg;
+      pb.nsh = (i64)N * S >= (i64)8 << 20 ? PB_NSH_MAX : 4;
       pb.cap = (int)std::max<i64>(64, (i64)c->bins_scale * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
       // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
       // rest, the statistics kernels use their global-atomic paths
       const bool got = hipMalloc((void **)&pb.ent, ne * sizeof(double4)) == hipSuccess &&
-                       hipMalloc((void **)&pb.part, (size_t)pb.nb * PB_NSH * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
+                       hipMalloc((void **)&pb.part, (size_t)pb.nb * PB_NSH_MAX * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
                        hipMalloc((void **)&pb.gcnt, (size_t)pb.nb * pb.nwg * sizeof(int)) == hipSuccess;
       if (got) {
         HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
@@ -2377,7 +2378,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "bsc stats (wave)");
         if (bsc_pb.ent) {
-          pair_bins_reduce_kernel<<<bsc_pb.nb * PB_NSH, PB_RTHREADS, (size_t)3 * 2 * bsc_pb.rf * H * sizeof(double), c->stream>>>(
+          pair_bins_reduce_kernel<<<bsc_pb.nb * bsc_pb.nsh, PB_RTHREADS, (size_t)3 * 2 * bsc_pb.rf * H * sizeof(double), c->stream>>>(
               bsc_pb, H, 0);
           HIP_TRY(hipGetLastError());
         }
@@ -2604,7 +2605,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       }
       if (pb.ent) {  // the entries of the main kernel and of the register-kernel levels: one tile pass per block
         SpanGuard g(c, KID_STATS);
-        pair_bins_reduce_kernel<<<pb.nb * PB_NSH, PB_RTHREADS, (size_t)3 * 2 * pb.rf * H * sizeof(double), c->stream>>>(pb, H, ci > 0);
+        pair_bins_reduce_kernel<<<pb.nb * pb.nsh, PB_RTHREADS, (size_t)3 * 2 * pb.rf * H * sizeof(double), c->stream>>>(pb, H, ci > 0);
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "pair bins reduce");
       }

@@ -15,7 +15,8 @@
 // ---------------------------------------------------------------------------------------
 #define PB_TILE 4096  // pair slots per LDS tile (x 3 values x 8 bytes = 96 KiB)
 #define PB_MAX_BINS 256
-#define PB_NSH 4      // reduce workgroups per bin
+#define PB_NSH_MAX 8  // reduce workgroups per bin: pb.nsh <= this (bins fill unevenly -- a few popular latents --: more,
+                      // smaller workgroups per bin let the scheduler even it out: 146 -> 116 us at c4; 16: no further gain)
 #define PB_RTHREADS 1024  // threads of a reduce workgroup (the 96 KiB tile leaves one workgroup per CU)
 struct PairBins {
   // nb x nwg private regions of `cap` 32-byte entries (one aligned sector each): {q, q (Lam_01 + kappa_0 kappa_1),
@@ -23,8 +24,9 @@ struct PairBins {
   // key = (tile row << 16) | j in the low bits of the fourth double
   double4 *ent;
   int *gcnt;       // nb x nwg: entries each producer workgroup left in each bin (the reduce kernel zeroes them)
-  double *part;    // nb x PB_NSH reduced tiles of 3 planes x (2 rf H) slots, summed by sssc_finish_kernel
+  double *part;    // nb x nsh reduced tiles of 3 planes x (2 rf H) slots, summed by sssc_finish_kernel
   int cap, nb, rf, nwg;  // rf folded rows per bin: the tile holds 2 rf rows x H columns; nwg producer workgroups
+  int nsh;               // reduce workgroups per bin (4: small shards, 8: from 8 M resident states on)
 };
 __device__ __forceinline__ int pb_fold(int i, int H) { return i < H - 2 - i ? i : H - 2 - i; }
 
@@ -42,26 +44,27 @@ __device__ __forceinline__ bool pb_append(const PairBins &pb, int *bcnt, int wg,
   return true;
 }
 
-// Workgroup (bin, s) reduces the regions that the producer workgroups w = s, s + PB_NSH, ... left in `bin`: LDS tile
+// Workgroup (bin, s) reduces the regions that the producer workgroups w = s, s + nsh, ... left in `bin`: LDS tile
 // <- their entries (ds_add_f64), then the whole tile with plain stores to its own slab of pb.part (accumulate != 0:
-// added to what an earlier block of datapoints left there).  sssc_finish_kernel adds the PB_NSH slabs of a bin in a
+// added to what an earlier block of datapoints left there).  sssc_finish_kernel adds the nsh slabs of a bin in a
 // fixed order: no global atomic anywhere on this route.  One wave per region at a time.  2 rf H <= PB_TILE.
 __global__ __launch_bounds__(PB_RTHREADS) void pair_bins_reduce_kernel(PairBins pb, int H, int accumulate) {
   extern __shared__ double pb_tile[];
   constexpr int NW = PB_RTHREADS / 64;
   __shared__ int pre_sh[NW][65];  // per wave: exclusive prefix of the entry counts of its (up to 64) regions
-  const int bin = blockIdx.x / PB_NSH, sh = blockIdx.x - bin * PB_NSH;
+  const int NSH = pb.nsh;
+  const int bin = blockIdx.x / NSH, sh = blockIdx.x - bin * NSH;
   const int slots = 2 * pb.rf * H;
   double *tq = pb_tile, *tu = pb_tile + slots, *tl = pb_tile + 2 * slots;
   for (int i = threadIdx.x; i < 3 * slots; i += PB_RTHREADS) pb_tile[i] = 0.0;
   lds_barrier();
   const int lane = lane_id(), wave = wave_id_uniform();
-  // A wave serves the regions w = sh + PB_NSH (wave + NW j), j = 0, 1, ...: 64 of them at a time.  Their counts are
+  // A wave serves the regions w = sh + NSH (wave + NW j), j = 0, 1, ...: 64 of them at a time.  Their counts are
   // read with ONE load per lane and turned into a prefix, so that the wave walks ONE flat list of entries with four
   // independent loads in flight per lane (region by region it was a chain of count -> entries round trips, 32 per
   // wave: most of this kernel's time).
-  for (int j0 = 0; sh + PB_NSH * (wave + NW * j0) < pb.nwg; j0 += 64) {
-    const int w = sh + PB_NSH * (wave + NW * (j0 + lane));
+  for (int j0 = 0; sh + NSH * (wave + NW * j0) < pb.nwg; j0 += 64) {
+    const int w = sh + NSH * (wave + NW * (j0 + lane));
     int n = 0;
     if (w < pb.nwg) {
       const size_t reg = (size_t)bin * pb.nwg + w;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(PB_RTHREADS) void pair_bins_reduce_kernel(PairBins 
           else
             hi = mid;
         }
-        const int wr = sh + PB_NSH * (wave + NW * (j0 + lo));
+        const int wr = sh + NSH * (wave + NW * (j0 + lo));
         const size_t at = on[u] ? ((size_t)bin * pb.nwg + wr) * pb.cap + (t - pre_sh[wave][lo]) : 0;
         v[u] = pb.ent[at];
       }
@@ -121,9 +124,9 @@ __device__ __forceinline__ void pb_collect(const PairBins &pb, int H, int i, int
   const int f = pb_fold(i, H), bin = f / pb.rf;
   const int slots = 2 * pb.rf * H;
   const int slot = (2 * (f - bin * pb.rf) + (i != f ? 1 : 0)) * H + j;
-  const double *p = pb.part + (size_t)bin * PB_NSH * 3 * slots + slot;
+  const double *p = pb.part + (size_t)bin * pb.nsh * 3 * slots + slot;
   bq = bu = bl = 0.0;
-  for (int sh = 0; sh < PB_NSH; sh++, p += 3 * slots) {
+  for (int sh = 0; sh < pb.nsh; sh++, p += 3 * slots) {
     bq += p[0];
     bu += p[slots];
     bl += p[2 * slots];

@@ -737,6 +737,14 @@ def test_packed_state_roundtrip(engine):
         engine.upload_states_packed(packed[20:], 20)
         assert np.array_equal(engine.download_states(), ss)
         assert np.array_equal(engine.download_states_packed(5, 7), packed[5:12])
+        if H % 8:
+            # a caller's buffer with non-zero PAD bits (positions >= H of the last byte) must not create
+            # phantom latents: popcounts, digests and latent indices are taken from the words
+            dirty = packed.copy()
+            dirty[..., -1] |= np.uint8((1 << (8 - H % 8)) - 1)
+            engine.upload_states_packed(dirty, 0)
+            assert np.array_equal(engine.download_states_packed(), packed)
+            assert np.array_equal(engine.download_states(), ss)
 
 
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
