@@ -182,6 +182,8 @@ struct evoamd_ctx {
   int sk_spare = 0;  // option "sk_spare": workgroups per XCD the FORKED stream-K contraction leaves unlaunched, so that the
                      // H x H elimination chain on the main stream finds free CU slots beside it (a persistent grid of
                      // 2 workgroups per CU otherwise holds every slot until the product is done)
+  int sssc_prec32 = 0;  // option "sssc_precision" = 32: SSSC(precision=np.float32), see evoamd_set_option in the header
+  int gemm_grouped = 1;  // option "gemm_grouped": grouped split-K instead of stream-K where whole chunks fill the grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
   double *census = nullptr;  // 4 doubles at the head of acc_base: overflow census of the earlier blocks of a chunked statistics pass
@@ -605,6 +607,15 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_workspace") == 0) {
     c->gemm_ws_opt = value;
+    return 0;
+  }
+  if (strcmp(name, "sssc_precision") == 0) {
+    if (value != 64 && value != 32) return fail(EVOAMD_E_INVALID, "sssc_precision: 64 or 32");
+    c->sssc_prec32 = value == 32;
+    return 0;
+  }
+  if (strcmp(name, "gemm_grouped") == 0) {
+    c->gemm_grouped = value != 0;
     return 0;
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
@@ -1216,11 +1227,22 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8 - spare);
     int segmax = 0;
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, real, &segmax) : nullptr;
+    // grouped split-K (gemm_f64.hpp): when whole chunks per tile fill the resident grid (>= 93 % of its slots) and a
+    // chunk is long enough for the pipeline ramp
+    const i64 J = (i64)8 * wpx / real;
+    if (ws && c->gemm_grouped && J >= 2 && real * J * 100 >= (i64)8 * wpx * 93 && K / J >= 256) {
+      const i64 Kc = ((cdiv(K, J) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+      gemm_tn128_gk<double><<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kc, gx, gy,
+                                                                            sym_row0, (int)real, (int)J, ws);
+      gemm_gk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(ws, C, ldc, M, Nc, gx, gy,
+                                                                                               sym_row0, (int)real, (int)J);
+    } else {
     gemm_tn128_sk_f64<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0,
                                                                        (int)real, ws, segmax);
     if (ws)
       gemm_sk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(
           ws, segmax, C, ldc, M, Nc, K, Kx, gx, gy, sym_row0, (int)real, (int)wpx);
+    }
   } else if (big)
     gemm_tn128_f64<<<grid, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, kps, gx, gy, split, sym_row0);
   else if (vec)
@@ -1309,7 +1331,9 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   const int H = c->H, D = c->D;
   // sssc.py:340-353: sigma2 through long double, rounded back to double
   const long double s2 = (long double)sigma2;
-  const double s2inv = (double)(1.0L / s2);
+  // precision = float32 (sssc.py:344-349): 1 / sigma2 and D log sigma2 pass through float32 -- values only, every
+  // product that uses them is still formed in double (a float32 scalar times a float64 array is float64 in NumPy)
+  const double s2inv = c->sssc_prec32 ? (double)(float)(1.0L / s2) : (double)(1.0L / s2);
   double l = 0.0;
   std::vector<double> pb(H);
   {
@@ -1326,7 +1350,12 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
     l += (-log(2 * M_PI) - log(sigma2)) * c->rel_frac / 2.0;
   } else {
     l -= D / 2.0 * log(2 * M_PI);
-    l -= 0.5 * (D * (double)logl(s2));
+    if (c->sssc_prec32) {
+      const float ld = (float)D * (float)logl(s2);  // D * float32: a float32 product
+      l -= (double)(0.5f * ld);
+    } else {
+      l -= 0.5 * (D * (double)logl(s2));
+    }
   }
   c->ljc = l;
   if (ljc) *ljc = l;
@@ -1384,11 +1413,20 @@ static int launch_gemm_tn_f32(evoamd_ctx *c, const float *A, int lda, const floa
     const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
     int segmax = 0;
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, (i64)gx * gy, &segmax) : nullptr;
-    gemm_tn128_sk_f32<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, gx * gy, ws,
-                                                                       segmax);
-    if (ws)
-      gemm_sk_reduce_kernel<<<dim3((unsigned)(gx * gy), GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(
-          ws, segmax, C, ldc, M, Nc, K, Kx, gx, gy, -1, gx * gy, (int)wpx);
+    const i64 real = (i64)gx * gy, J = (i64)8 * wpx / real;
+    if (ws && c->gemm_grouped && J >= 2 && real * J * 100 >= (i64)8 * wpx * 93 && K / J >= 256) {  // see launch_gemm_tn
+      const i64 Kc = ((cdiv(K, J) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+      gemm_tn128_gk<float><<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kc, gx, gy, -1,
+                                                                           (int)real, (int)J, ws);
+      gemm_gk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(ws, C, ldc, M, Nc, gx, gy, -1,
+                                                                                               (int)real, (int)J);
+    } else {
+      gemm_tn128_sk_f32<<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kx, gx, gy, gx * gy,
+                                                                         ws, segmax);
+      if (ws)
+        gemm_sk_reduce_kernel<<<dim3((unsigned)(gx * gy), GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(
+            ws, segmax, C, ldc, M, Nc, K, Kx, gx, gy, -1, gx * gy, (int)wpx);
+    }
   } else {
     gemm_tn_naive_f32<<<cdiv((i64)M * Nc, 256), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K);
   }
@@ -2727,6 +2765,13 @@ extern "C" int evoamd_stats(evoamd_ctx *c, double *acc_out) {
   HIP_TRY(hipMemcpyAsync(c->h_acc, c->acc, ((size_t)c->acc_n + DP_COUNT) * sizeof(double), hipMemcpyDeviceToHost,
                          c->stream));
   r = check_err(c);  // synchronises the stream
+  if (c->sssc_prec32 && c->model == EVOAMD_MODEL_SSSC) {
+    // precision = float32: the reference keeps these sums in float32 arrays (sssc.py:484-498); here they are summed in
+    // double and rounded once -- closer to the exact sums than the reference's own float32 running sums
+    const AccLayout a = acc_layout(c);
+    for (i64 i = 0; i < a.sWp; i++) c->h_acc[i] = (double)(float)c->h_acc[i];
+    for (i64 i = a.s_sz; i < a.y2; i++) c->h_acc[i] = (double)(float)c->h_acc[i];
+  }
   memcpy(acc_out, c->h_acc, (size_t)c->acc_n * sizeof(double));
   if (!r) note_levels(c, c->h_acc + c->acc_n);
   return r;
@@ -2868,6 +2913,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
   c->gen++;
   SpanGuard g(c, KID_MSTEP);
   if (c->model == EVOAMD_MODEL_SSSC) {
+    if (c->sssc_prec32)  // precision = float32: the moment sums as float32 values (evoamd_stats does the same on the host)
+      round_f32_kernel<<<cdiv(a.sWp, 256), 256, 0, c->stream>>>(c->acc, a.sWp);
     // mus / pies first (Psi needs the NEW mus, sssc.py:733), then both H x H inverses in one launch:
     // tmpA <- xpt_szsz (for W, sssc.py:693), tmpB <- xpt_ss + eps I (for Psi, sssc.py:738)
     sssc_mstep_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, c->acc + a.xss,
@@ -2882,6 +2929,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     if (r) return r;
     r = join_fork(c);  // sWp / s_sz / sz_sz come from the contraction
     if (r) return r;
+    if (c->sssc_prec32) round_f32_kernel<<<cdiv(a.y2 - a.s_sz, 256), 256, 0, c->stream>>>(c->acc + a.s_sz, a.y2 - a.s_sz);
     if (learn & L_W)
       launch_gemm_nn_raw(c, c->acc + a.sWp, H, c->tmpA, H, c->W, H, D, H, H);
     if (learn & L_PSI)
@@ -2899,7 +2947,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, masked ? 0 : n_part, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar, masked ? c->rel_frac : -1.0,
-                                                            c->acc + a.tail + 7);
+                                                            c->acc + a.tail + 7, c->sssc_prec32);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   } else {

@@ -451,6 +451,71 @@ __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(const double *__res
   if (row < M && col < Nc) C[(i64)row * ldc + col] += sum;
 }
 
+// Grouped split-K form of the long-K contraction (option "gemm_grouped"): J = floor(resident slots / real tiles) K chunks
+// per tile, ONE segment and one partial tile per workgroup, and the workgroups that work on the SAME K chunk (one per
+// real tile: a "group") sit next to each other in ONE XCD and walk that chunk in step.  Why: the stream-K split above
+// balances perfectly but leaves the 64 workgroups of an XCD at 64 different (tile, k) positions -- no two of them ever
+// read the same rows at the same time, so every 128-column slab of A and B comes from HBM once PER TILE that uses it:
+// measured 3.2 .. 6.5 GB per launch at the north-star shape for 1.02 GB of operands (profiles/r03_c4_pmc_traffic.json:
+// FETCH_SIZE 3.17 GB, the bound [FETCH, 2 x FETCH]), 2 .. 3.6 TB/s beside everything else on the chip.  Here the
+// tiles of a group pull each slab of [Y | Es | Ez] into the XCD's L2 once and share it (the B operand Ez is a column
+// block of the same rows): 164 KB per slab and group instead of 34 x 32 KB.  Slot g = xcd * wpx + (blockIdx.x >> 3) of
+// the resident grid (workgroup i runs on XCD i % 8) -> group g / n_real, real tile g % n_real; slots beyond n_real * J
+// idle (north-star shape: 34 tiles x 15 chunks = 510 of 512).  Partial tile of slot g -> ws slab g;
+// gemm_gk_reduce_kernel adds the J slabs of a tile in chunk order (reproducible).
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn128_gk(
+    const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb, double *__restrict__ C, int ldc, int M, int Nc,
+    i64 K, i64 Kc, int gx, int gy, int sym_row0, int n_real, int J, double *__restrict__ ws) {
+  extern __shared__ double lds128[];
+  T(*As)[GEMM_BK][GEMM_LDS2] = (T(*)[GEMM_BK][GEMM_LDS2])lds128;
+  T(*Bs)[GEMM_BK][GEMM_LDS2] = (T(*)[GEMM_BK][GEMM_LDS2])((T *)lds128 + 2 * GEMM_BK * GEMM_LDS2);
+  const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int g = xcd * wpx + l;
+  if (g >= n_real * J) return;  // uniform
+  const int j = g / n_real, rt = g - j * n_real;
+  int tile = 0, seen = -1;
+  for (int tt = 0; tt < gx * gy; tt++) {  // the rt-th real tile in row-major order
+    const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
+    if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
+    if (++seen == rt) {
+      tile = tt;
+      break;
+    }
+  }
+  const int m0 = (tile / gx) * GEMM_T, n0 = (tile % gx) * GEMM_T;
+  const i64 kbeg = (i64)j * Kc;
+  const i64 kend = (kbeg + Kc < K) ? kbeg + Kc : K;  // an empty chunk (kend <= kbeg) stores a zero tile
+  gemm_tn128_segment<T, double>(A, lda, B, ldb, C, ldc, M, Nc, m0, n0, kbeg, kend, true, As, Bs,
+                                ws + (size_t)g * (GEMM_T * GEMM_T));
+}
+
+// C += the J partial tiles of every real tile, in chunk order: grid (n_real, 128 * 128 / 256).
+__global__ __launch_bounds__(256) void gemm_gk_reduce_kernel(const double *__restrict__ ws, double *__restrict__ C, int ldc,
+                                                             int M, int Nc, int gx, int gy, int sym_row0, int n_real, int J) {
+  __shared__ int tile_sh;
+  const int rt = blockIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;  // element of the tile, row-major
+  if (threadIdx.x == 0) {
+    int tile = 0, seen = -1;
+    for (int tt = 0; tt < gx * gy; tt++) {
+      const int tm = (tt / gx) * GEMM_T, tn = (tt % gx) * GEMM_T;
+      if (sym_row0 >= 0 && tm >= sym_row0 && tm - sym_row0 > tn) continue;
+      if (++seen == rt) {
+        tile = tt;
+        break;
+      }
+    }
+    tile_sh = tile;
+  }
+  __syncthreads();
+  const int tile = tile_sh;
+  const int row = (tile / gx) * GEMM_T + e / GEMM_T, col = (tile % gx) * GEMM_T + e % GEMM_T;
+  double sum = 0.0;
+  for (int j = 0; j < J; j++) sum += ws[((size_t)j * n_real + rt) * (GEMM_T * GEMM_T) + e];
+  if (row < M && col < Nc) C[(i64)row * ldc + col] += sum;
+}
+
 // C (M x Nc) = A^T B with the whole (short) K per tile and plain stores: B = Y W as (Y^T)^T W from the transposed copy of
 // the data, M = N datapoints.  XCD x owns the row tiles x, x + 8, ...: the column tiles of a row tile run on the same
 // XCD back to back, so the 128 columns of Y^T they share are fetched into one L2.

@@ -1243,10 +1243,16 @@ __global__ __launch_bounds__(256) void sssc_trace_partial_kernel(const double *_
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 
+// SSSC(precision = float32): the moment sums the reference holds in float32 arrays, rounded in place
+__global__ __launch_bounds__(256) void round_f32_kernel(double *__restrict__ x, i64 n) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = (double)(float)x[i];
+}
+
 __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     const double *__restrict__ y2, int D, const double *__restrict__ trace_part, int n_part, int H,
     const double *__restrict__ Nptr, int learn, const double *__restrict__ pies, double *__restrict__ pil_bar,
-    double *__restrict__ dpar, double rel_frac, const double *__restrict__ pad) {
+    double *__restrict__ dpar, double rel_frac, const double *__restrict__ pad, int prec32 = 0) {
   // rel_frac >= 0: incomplete data (sssc.py:352-357, 747-755): no trace partials (n_part = 0); *pad = the
   // masked square sum of y_hat, the reliable-entry count times the OLD sigma2 is added
   __shared__ double sh[MS_T];
@@ -1287,10 +1293,12 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     }
     if (s2 < 1e-5) s2 = 1e-5;  // check_params
     dpar[DP_SIGMA2] = s2;
-    dpar[DP_S2INV] = 1.0 / s2;
+    dpar[DP_S2INV] = prec32 ? (double)(float)(1.0 / s2) : 1.0 / s2;  // precision = float32: sssc.py:346-349
     dpar[DP_LJC_PREV] = dpar[DP_LJC];
     if (rel_frac >= 0.0)
       dpar[DP_LJC] = sh[0] + (-log(2 * M_PI) - log(s2)) * rel_frac / 2.0;
+    else if (prec32)
+      dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - (double)(0.5f * ((float)D * (float)log(s2)));
     else
       dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - 0.5 * (D * log(s2));
     if (!(s2 == s2) || isinf(s2)) dpar[DP_STATUS] = 2.0;

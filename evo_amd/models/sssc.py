@@ -12,9 +12,14 @@ class SSSC(Model):
                  to_learn=("W", "pies", "mus", "sigma2", "Psi"), comm=None, **kwargs):
         """Same arguments as the reference (sssc.py:18-27).  ``use_storage`` is accepted and ignored:
         the reference's per-state cache is a pure memo (SURVEY 7 "hard parts"), the kernels
-        recompute the k x k system per (datapoint, state).  ``precision`` must be float64."""
-        if np.dtype(precision) != np.float64:
-            raise NotImplementedError("the reference computes in float64; only float64 is implemented")
+        recompute the k x k system per (datapoint, state).  ``precision`` (sssc.py:49): float64, or float32 --
+        the reference then passes 1/sigma2 and D log sigma2 through float32 (sssc.py:344-349) and keeps the moment sums
+        in float32 arrays (sssc.py:484-498, 556-559) while every product is still formed in float64.  Here the sums are
+        formed in double on the device and rounded to float32 once (library option "sssc_precision"): the results agree
+        with the reference's float32 mode to float32 accuracy.  (With more than one MPI rank the reference's own
+        float32 mode all-reduces its float32 buffers as MPI.DOUBLE, sssc.py:671-685; single rank is what it defines.)"""
+        if np.dtype(precision) not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("precision must be float64 or float32")
         Model.__init__(self, D, H, S, to_learn, comm, **kwargs)
         tol = 1e-5
         self.eps_pjc_sum = np.finfo(np.float64).tiny
@@ -23,7 +28,7 @@ class SSSC(Model):
         self.eps_mus = np.finfo(np.float64).eps
         self.eps_Psi = tol
         self.eps_sigma2 = tol
-        self.dtype_precision = np.float64
+        self.dtype_precision = np.dtype(precision).type
         self.use_storage = use_storage
         self.noise_policy = {  # sssc.py:51-58
             "W": (-np.inf, +np.inf, False, None),
@@ -96,6 +101,7 @@ class SSSC(Model):
     def _push_params(self, model_params):
         n_rel = getattr(self, "_n_reliable", None)  # incomplete data: mean reliable entries per datapoint (sssc.py:352-357)
         self.engine.set_reliable_fraction(None if n_rel is None else n_rel / float(self._n_total))
+        self.engine.set_option("sssc_precision", 32 if self.dtype_precision is np.float32 else 64)
         self.engine.set_params_sssc(model_params["W"], model_params["pies"], model_params["mus"],
                                     model_params["Psi"], float(model_params["sigma2"]))
 
@@ -116,8 +122,8 @@ class SSSC(Model):
         ljc = np.log(1.0 - pies).sum() - D / 2 * np.log(2 * np.pi)
         model_params["piH"] = pies.sum()
         model_params["pil_bar"] = np.log(pies / (1.0 - pies))
-        model_params["sigma2_inv"] = (1.0 / s2).astype(np.float64)
-        model_params["ljc"] = ljc - 0.5 * (D * np.log(s2).astype(np.float64))
+        model_params["sigma2_inv"] = (1.0 / s2).astype(self.dtype_precision)
+        model_params["ljc"] = ljc - 0.5 * (D * np.log(s2).astype(self.dtype_precision))
         xi = my_data["x_infr"]
         self._n_reliable = None
         if not xi.all():  # sssc.py:352-357: the Gaussian normaliser counts the reliable entries
@@ -216,6 +222,17 @@ class SSSC(Model):
                 model_params["sigma2"] = (s2 / N / D) + self.eps_sigma2
         return model_params
 
+    def _precision_views(self, v):
+        """precision = float32: the six moment sums as float32 ARRAYS, like the reference's receive buffers
+        (sssc.py:658-669) -- update_params then follows NumPy's promotion exactly as the reference's lines do (float32
+        H x H inverses, a float32 pies array).  The library has already rounded the values (option "sssc_precision")."""
+        if self.dtype_precision is not np.float32:
+            return v
+        v = dict(v)
+        for key in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer"):
+            v[key] = np.asarray(v[key]).astype(np.float32)
+        return v
+
     def EM_step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """Fused E- and M-step (sssc.py:419-813).  Returns (F, S_nunique, S_sub, Theta_new); F uses
         the ljc of the Theta the E-step ran with (sssc.py:472,780)."""
@@ -234,7 +251,7 @@ class SSSC(Model):
                 parallel.pprint("no %s = %i" % (label, int(v[key])), self.comm)
         if len(self.to_learn) > 0:
             with small_blas(self.H):
-                model_params = self.update_params(model_params, v, float(v["N"]))
+                model_params = self.update_params(model_params, self._precision_views(v), float(v["N"]))
         return F, S_nunique, S_sub, model_params
 
     def M_step(self, model_params, my_suff_stat, my_data, _from_step=False):
@@ -242,4 +259,4 @@ class SSSC(Model):
         acc = self._stats_for_mstep(model_params, my_suff_stat, my_data, _from_step)
         v = self.engine.acc_views(acc)
         with small_blas(self.H):
-            return self.update_params(model_params, v, float(v["N"]))
+            return self.update_params(model_params, self._precision_views(v), float(v["N"]))

@@ -109,6 +109,13 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * through the pair bins, column sums in the kernel); 0: the one-shot kernel + column-sum pass.
  * "gemm_workspace" (0/1, default 1): the stream-K workgroups store their partial tiles to a workspace and a second kernel
  * adds them to C in a fixed order; 0: they add to C with f64 atomics (all of them at once, when the runs end).
+ * "sssc_precision" (64 / 32, default 64): SSSC(precision=np.float32) of the reference (evo/models/sssc.py:49, 344-349,
+ * 484-498): 1 / sigma2 and D log sigma2 pass through float32 and the moment sums (xpt_s, xpt_ss, xpt_sz, xpt_szsz,
+ * s_sz_outer, sz_sz_outer) are float32 VALUES; every product and sum is still formed in double on the device and rounded
+ * once (the reference accumulates them in float32 arrays datapoint by datapoint).
+ * "gemm_grouped" (0/1, default 1): long-K contractions whose real tiles fill the resident grid with whole K chunks
+ * (>= 93 % of the slots) run as a grouped split-K -- the workgroups of one K chunk, one per tile, sit in one XCD and share
+ * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
  * "stats_flat" (0/1, default 0: measured a few per cent at N = 100k, a loss at N / 8): with census lists, the ES3C statistics of the states with at most two active latents run

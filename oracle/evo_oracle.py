@@ -618,16 +618,17 @@ def sssc_standard_init(Y, H, to_learn=("W", "pies", "mus", "sigma2", "Psi"), x_i
     return theta
 
 
-def sssc_precompute(theta, D, x_infr=None):
+def sssc_precompute(theta, D, x_infr=None, precision=np.float64):
     """sssc.py:328-366.  sigma2 goes through longdouble like the reference; incomplete data
-    (sssc.py:352-357): the Gaussian normaliser counts the reliable entries."""
+    (sssc.py:352-357): the Gaussian normaliser counts the reliable entries.  precision = the model's
+    dtype_precision (sssc.py:49, 346-349)."""
     pies = theta["pies"]
     s2 = np.asarray(theta["sigma2"]).astype("longdouble")
     theta["ljc"] = np.log(1.0 - pies).sum() - D / 2 * np.log(2 * np.pi)
     theta["piH"] = pies.sum()
     theta["pil_bar"] = np.log(pies / (1.0 - pies))
-    theta["sigma2_inv"] = (1.0 / s2).astype(np.float64)
-    theta["ljc"] -= 0.5 * (D * np.log(s2).astype(np.float64))
+    theta["sigma2_inv"] = (1.0 / s2).astype(precision)
+    theta["ljc"] -= 0.5 * (D * np.log(s2).astype(precision))
     if x_infr is not None and not x_infr.all():
         sum_n_d = x_infr.sum()
         theta["ljc"] = (np.log(1.0 - pies).sum()
@@ -685,7 +686,8 @@ def sssc_lpj_allzero(theta, y, counters, obs=None):
 
 
 def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
-                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True, reconstruct_x=None, x_infr=None):
+                       to_learn=("W", "pies", "mus", "sigma2", "Psi"), evolve=True, reconstruct_x=None, x_infr=None,
+                       precision=np.float64):
     """sssc.py:419-656: the fused per-datapoint loop (E-step + sufficient statistics) on one
     rank.  Returns the dict of per-rank sums the reference all-reduces (sssc.py:671-691,763,
     773-780).  With evolve=False the EA / selection is skipped (statistics of the resident K^n)."""
@@ -695,16 +697,17 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
     incmpl = x_infr is not None and not x_infr.all()
     if incmpl:
         assert not use_storage and reconstruct_x is not None  # the reference needs both (sssc.py:630-633)
-    counters = sssc_precompute(theta, D, x_infr)
+    counters = sssc_precompute(theta, D, x_infr, precision)
     S_perm, incl, Mprime = suff["S_perm"], suff["incl"], suff["Mprime"]
     lpj_all, ss = suff["lpj"], suff["ss"]
     mus = theta["mus"]
     cache = {}
     trace_WW = 0.0   # trace of sum_n outer(W_obs xpt_sz) (sssc.py:640-645,751)
     acc = {
-        "xpt_s": np.zeros(H), "xpt_ss": np.zeros((H, H)), "xpt_sz": np.zeros(H),
-        "xpt_szsz": np.zeros((H, H)), "Wp": np.zeros((D, H)),
-        "s_sz_outer": np.zeros((H, H)), "sz_sz_outer": np.zeros((H, H)),
+        # dtype_precision arrays (sssc.py:484-498); my_Wp is float64 whatever the precision (sssc.py:490)
+        "xpt_s": np.zeros(H, dtype=precision), "xpt_ss": np.zeros((H, H), dtype=precision),
+        "xpt_sz": np.zeros(H, dtype=precision), "xpt_szsz": np.zeros((H, H), dtype=precision), "Wp": np.zeros((D, H)),
+        "s_sz_outer": np.zeros((H, H), dtype=precision), "sz_sz_outer": np.zeros((H, H), dtype=precision),
     }
     n_uniq = n_sub = 0.0
     y_rec = Y.copy() if reconstruct_x is not None else None   # sssc.py:500-507
@@ -728,10 +731,10 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
         # sufficient statistics, sssc.py:553-611
         B = np.minimum(B_MAX - lpj_all[n].max(), B_MAX_SHFT)
         q = np.exp(lpj_all[n] + B)
-        e_s = np.zeros(H)
-        e_ss = np.zeros((H, H))
-        e_sz = np.zeros(H)
-        e_szsz = np.zeros((H, H))
+        e_s = np.zeros(H, dtype=precision)          # sssc.py:556-559
+        e_ss = np.zeros((H, H), dtype=precision)
+        e_sz = np.zeros(H, dtype=precision)
+        e_szsz = np.zeros((H, H), dtype=precision)
         for s in range(S):
             st = cur[s]
             w = q[s + S_perm]
@@ -739,9 +742,13 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
             kappa = np.dot(t["lam_Wt"], (y[obs] if incmpl else y) - t["Wmu"])
             kappa += mus[st]
             second = t["lam"] + np.outer(kappa, kappa)
-            e_sz[st] += kappa * w
-            tmp = np.zeros((H, H))
-            tmp[np.outer(st, st)] = (second * w).flatten()
+            k_tmp = np.array(kappa, dtype=precision)     # sssc.py:580-584: cast, then scaled in that dtype
+            k_tmp *= w
+            e_sz[st] += k_tmp
+            sec_tmp = np.array(second, dtype=precision)  # sssc.py:586-595
+            sec_tmp *= w
+            tmp = np.zeros((H, H), dtype=precision)
+            tmp[np.outer(st, st)] = sec_tmp.flatten()
             e_szsz += tmp
         e_s += (q[S_perm:][:, None] * cur).sum(axis=0)
         e_ss += np.dot(q[S_perm:].T * cur.T, cur)
@@ -834,14 +841,14 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
 
 
 def sssc_step(theta, suff, Y, use_storage=True, to_learn=("W", "pies", "mus", "sigma2", "Psi"),
-              trace=None, reconstruct_x=None, x_infr=None):
+              trace=None, reconstruct_x=None, x_infr=None, precision=np.float64):
     """sssc.py:407-417 + EM_step on one rank.  Returns (F, S_nunique, S_sub, theta, acc).
     F uses the *old* Theta's ljc (sssc.py:472,780)."""
     N, D = Y.shape
     H = theta["W"].shape[1]
     theta = check_params(theta, SSSC_POLICY)
     acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn, reconstruct_x=reconstruct_x,
-                             x_infr=x_infr)
+                             x_infr=x_infr, precision=precision)
     ljc = theta["ljc"]
     theta = sssc_update(theta, acc, N, D, H, to_learn)
     F = ljc + acc["Fs"] / N

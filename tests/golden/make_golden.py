@@ -124,13 +124,14 @@ def run_steps(model, keys, theta, suff, my_data, n_steps, seed0):
 
 
 def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=("fit", "randflip", 10, 1, 1),
-                      bitflip_prob=None, Mprime=None, p_init=None, use_storage=True, permanent=None):
+                      bitflip_prob=None, Mprime=None, p_init=None, use_storage=True, permanent=None,
+                      precision=np.float64):
     np.random.seed(seed)
     if algo == "ebsc":
         model = BSC(D, H, S)
         keys = BSC_KEYS
     else:
-        model = SSSC(D, H, S, use_storage=use_storage)
+        model = SSSC(D, H, S, use_storage=use_storage, precision=precision)
         keys = SSSC_KEYS
     if data == "bars":
         gen = {"W": 10.0 * bars(H), "pi": 2.0 / H, "sigma": 1.0}
@@ -148,6 +149,7 @@ def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=
         "ea_n_generations": np.int64(suff["n_generations"]),
         "ea_bitflip_prob": np.float64(np.nan if bitflip_prob is None else bitflip_prob),
         "ea_Mprime": np.int64(suff["Mprime"]), "use_storage": np.bool_(use_storage),
+        "precision32": np.bool_(np.dtype(precision) == np.float32),
     }
     out.update(run_steps(model, keys, theta, suff, my_data, n_steps, seed0=1000 + seed))
     path = os.path.join(HERE, "step_%s.npz" % name)
@@ -528,6 +530,9 @@ if __name__ == "__main__":
         make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
         make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "prec32":  # SSSC(precision=np.float32) (sssc.py:49), added in round 3
+        make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "recon":  # only the reconstruction fixtures (added later)
         make_recon_fixture("ebsc", "ebsc", 25, 10, 8, 30, seed=21)
         make_recon_fixture("es3c", "es3c", 25, 10, 8, 30, seed=22)
@@ -551,6 +556,7 @@ if __name__ == "__main__":
     make_missing_fixture_es3c()
     make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
+    make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
     for nm in sorted(SHAPES):
         a, D, H, S, N, seed, ea = SHAPES[nm][:7]
         make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=(SHAPES[nm][7] if len(SHAPES[nm]) > 7 else 2), ea=ea)

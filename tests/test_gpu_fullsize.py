@@ -112,7 +112,7 @@ def test_es3c_full_size_properties(name):
         assert np.array_equal(xss, xss.T)
         assert abs(float(xss.sum() - np.trace(xss)) - s2) <= 1e-10 * max(s2, 1.0)
         # --- path independence
-        for opt, val in (("pair_bins", 0), ("gemm_workspace", 0), ("gemm_streamk", 0)):
+        for opt, val in (("pair_bins", 0), ("gemm_workspace", 0), ("gemm_streamk", 0), ("gemm_grouped", 0)):
             eng.set_option(opt, val)
             try:
                 v3 = eng.acc_views(eng.stats())

@@ -388,7 +388,8 @@ def test_lpj_sssc_wide_states(engine, H, S):
 
 
 @pytest.mark.parametrize("K,M,Nc,sym", [(9000, 384, 256, False), (8200, 640, 256, True), (300, 192, 64, True),
-                                        (8192, 258, 256, False), (130, 70, 34, False)])
+                                        (8192, 258, 256, False), (130, 70, 34, False),
+                                        (20000, 1280, 512, True), (16000, 1024, 256, False), (20010, 1152, 512, True)])
 def test_gemm_tn_dispatch(engine, K, M, Nc, sym):
     """C = A^T B through the statistics pass's MFMA dispatch: 64- and 128-tile kernels, split K over
     the XCDs, 16-byte and scalar loaders, upper-tiles-plus-mirror for a trailing X^T X block."""
@@ -408,7 +409,10 @@ def test_gemm_tn_dispatch(engine, K, M, Nc, sym):
         # second call returns the same bits) against the f64 atomic epilogue and against the split-K grid
         C2 = engine.gemm_tn(A, B, M - Nc if sym else -1)
         np.testing.assert_array_equal(C2, C)
-        for opt in ("gemm_workspace", "gemm_streamk"):
+        # (the last three shapes fill the resident grid with whole K chunks per tile: grouped split-K, 34 real tiles x 15
+        # chunks / 16 x 32 / 30 x 17 -- the north-star contraction's and the EBSC c5 contraction's tilings; option
+        # "gemm_grouped" = 0 sends them through stream-K)
+        for opt in ("gemm_workspace", "gemm_streamk", "gemm_grouped"):
             engine.set_option(opt, 0)
             try:
                 Ca = engine.gemm_tn(A, B, M - Nc if sym else -1)

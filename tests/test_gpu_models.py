@@ -114,6 +114,46 @@ def test_trajectory_reference_rng(engine, name):
             np.testing.assert_allclose(theta[k], ref, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ref).max()), err_msg=k)
 
 
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_es3c_precision_float32(engine, device_mstep):
+    """SSSC(precision=np.float32) (sssc.py:49): the reference passes 1/sigma2 and D log sigma2 through float32 and keeps
+    the moment sums in float32 arrays; here the sums are formed in double on the device and rounded once (option
+    "sssc_precision").  Against step_es3c_f32.npz (generated from the reference in that mode), STATED tolerance =
+    float32 accuracy: lpj / F 2e-6 relative (step 2 of the reference takes log(pies) in float32), the recorded sums
+    3e-6, Theta^new 2e-4 (its H x H inverses are float32 LAPACK there), K^n rows >= 95 % identical after two steps
+    (identical after the first: nothing float32 has reached a selection yet)."""
+    from evo_amd.models import SSSC
+    g = load_golden("step_es3c_f32.npz")
+    assert bool(g["precision32"])
+    D, H, S, N = int(g["D"]), int(g["H"]), int(g["S"]), int(g["N"])
+    model = SSSC(D, H, S, use_storage=bool(g["use_storage"]), engine=engine, precision=np.float32,
+                 device_mstep=device_mstep)
+    Y = g["Y"]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    theta = {k: np.array(g["t0_in_%s" % k]) for k in SSSC_KEYS}
+    theta["sigma2"] = np.float64(theta["sigma2"])
+    suff = make_suff(g, unpack_bits(g["t0_ss_in"], H))
+    try:
+        for t in range(int(g["n_steps"])):
+            np.random.seed(1000 + int(g["seed"]) + t)
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            same = (np.packbits(suff["ss"], axis=-1) == g["t%d_ss_out" % t]).all(axis=(1, 2))
+            if t == 0:
+                assert same.all(), "K^n differs after the first step"
+                assert nu == float(g["t0_S_nunique"]) and nsub == float(g["t0_S_sub"])
+            assert same.mean() >= 0.95, same.mean()
+            np.testing.assert_allclose(suff["lpj"][same], g["t%d_lpj_out" % t][same], rtol=2e-6, atol=1e-6)
+            np.testing.assert_allclose(F, float(g["t%d_F" % t]), rtol=2e-6)
+            for k in SSSC_KEYS:
+                ref = g["t%d_out_%s" % (t, k)]
+                np.testing.assert_allclose(np.asarray(theta[k], dtype=np.float64), ref, rtol=2e-4,
+                                           atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg="%s step %d" % (k, t))
+        if not device_mstep:  # dict-bag dtypes of this mode (sssc.py:714: float32 sums / N)
+            assert theta["pies"].dtype == np.float32 and theta["W"].dtype == np.float64
+    finally:
+        engine.set_option("sssc_precision", 64)
+
+
 def test_kat_bars_from_seed(engine):
     """examples/bars-test set-up from seed 42: data generation, standard_init,
     init_states and three EM steps through evo_amd only; F must match the reference's numbers."""

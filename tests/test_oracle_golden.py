@@ -9,7 +9,7 @@ from conftest import load_golden, unpack_bits
 from oracle import evo_oracle as orc
 
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm", "es3c_f32"]
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 
@@ -53,7 +53,13 @@ def test_step_replay(name):
             F, nu, nsub, theta, sums = orc.bsc_step(theta, suff, Y, trace=trace)
             sum_names = ("Wp", "Wq", "pies", "sigma", "Fs")
         else:
-            F, nu, nsub, theta, sums = orc.sssc_step(theta, suff, Y, use_storage=bool(g["use_storage"]), trace=trace)
+            prec = np.float32 if ("precision32" in g and bool(g["precision32"])) else np.float64  # sssc.py:49
+            if prec is np.float32 and t > 0:
+                # the reference's own Theta^new carries pies as a float32 ARRAY in this mode (sssc.py:714: float32 sums / N),
+                # so its next precompute takes the logs in float32; the fixture stores values as float64 (lossless)
+                theta["pies"] = theta["pies"].astype(np.float32)
+            F, nu, nsub, theta, sums = orc.sssc_step(theta, suff, Y, use_storage=bool(g["use_storage"]), trace=trace,
+                                                     precision=prec)
             sum_names = ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "s_sz_outer", "sz_sz_outer", "Wp", "y_outer_diag", "Fs")
         # candidate stream: bit-exact states, lpj to rounding
         counts = np.array([c[1].shape[0] for c in trace])
