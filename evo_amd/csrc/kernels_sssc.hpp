@@ -92,6 +92,49 @@ struct SsscArgs {
 
 #define SSSC_KCAP 64
 
+// What np.linalg.inv raises LinAlgError on for a 2 x 2 matrix: an exactly zero pivot of the LU factorisation with
+// partial pivoting (first entry of largest magnitude in column 0; the entry below it is scaled by the RECIPROCAL of
+// the pivot, as dgetf2 does).  Exact for the structural cases -- a zero row / column, two equal rows, rows in a
+// power-of-two ratio; for entries whose elimination leaves rounding noise LAPACK's answer depends on its kernel too.
+__device__ __forceinline__ bool lu2_exactly_singular(double a00, double a01, double a10, double a11) {
+  const bool swap = fabs(a10) > fabs(a00);
+  const double piv = swap ? a10 : a00, low = swap ? a00 : a10;
+  if (piv == 0.0) return true;
+  const double prow = swap ? a11 : a01, lrow = swap ? a01 : a11;
+  const double l = __dmul_rn(low, __ddiv_rn(1.0, piv));
+  return __dsub_rn(lrow, __dmul_rn(l, prow)) == 0.0;
+}
+// Moore-Penrose inverse of an (exactly or numerically) rank-deficient 2 x 2 matrix: A^T / |A|_F^2 for rank one, 0 for 0
+// (np.linalg.pinv's SVD with rcond = 1e-15 drops the second singular value of such a matrix)
+__device__ __forceinline__ void pinv2_deficient(double a00, double a01, double a10, double a11, double &p00, double &p01,
+                                                double &p10, double &p11) {
+  const double f2 = a00 * a00 + a01 * a01 + a10 * a10 + a11 * a11;
+  const double r = f2 > 0.0 ? 1.0 / f2 : 0.0;
+  p00 = a00 * r;
+  p01 = a10 * r;
+  p10 = a01 * r;
+  p11 = a11 * r;
+}
+
+// Lam of a state whose Psi_A (|A| = 2) is exactly singular, the reference's way (sssc.py:278-301): pinv(Psi_A), then
+// inv(G_A / sigma2 + pinv(Psi_A)) -- pinv of that if it is exactly singular as well.  s = 1 / sigma2.
+__device__ __forceinline__ void pair_lam_singular_psi(double s, double G00, double G01, double G10, double G11, double P00,
+                                                      double P01, double P10, double P11, double &l00, double &l01,
+                                                      double &l10, double &l11) {
+  double q00, q01, q10, q11;
+  pinv2_deficient(P00, P01, P10, P11, q00, q01, q10, q11);
+  const double M00 = s * G00 + q00, M01 = s * G01 + q01, M10 = s * G10 + q10, M11 = s * G11 + q11;
+  if (lu2_exactly_singular(M00, M01, M10, M11)) {
+    pinv2_deficient(M00, M01, M10, M11, l00, l01, l10, l11);
+  } else {
+    const double rm = 1.0 / (M00 * M11 - M01 * M10);
+    l00 = M11 * rm;
+    l01 = -M01 * rm;
+    l10 = -M10 * rm;
+    l11 = M00 * rm;
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void lu_solve_regs(double (&T)[K][K], double (&w)[K], double (*P)[K], bool with_P,
                                               double &logdet, bool &singular) {
@@ -334,6 +377,32 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
 #pragma unroll
       for (int l = 0; l < K; l++) tt += P[i][l] * G[l][j];
       T[i][j] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+    }
+  }
+  if (K == 2 && k >= 1) {
+    // |A| <= 2 without the tables (candidate batches whose rows do not fit the main kernel's LDS, shared sets): the same
+    // exactly-singular-Psi_A semantics as sssc_tables_kernel -- lpj = +inf (-> B_max), Lam / kappa from pinv(Psi_A)
+    const bool sing = k == 1 ? P[0][0] == 0.0 : lu2_exactly_singular(P[0][0], P[0][K - 1], P[K - 1][0], P[K - 1][K - 1]);
+    if (sing) {
+      if (MODE == 0) {
+        val = __builtin_inf();
+      } else {
+        double l00, l01 = 0.0, l10 = 0.0, l11 = 0.0;
+        if (k == 1)
+          l00 = (a.s2inv * G[0][0] != 0.0) ? 1.0 / (a.s2inv * G[0][0]) : 0.0;
+        else
+          pair_lam_singular_psi(a.s2inv, G[0][0], G[0][K - 1], G[K - 1][0], G[K - 1][K - 1], P[0][0], P[0][K - 1], P[K - 1][0],
+                                P[K - 1][K - 1], l00, l01, l10, l11);
+        kap[0] = a.s2inv * (l00 * v[0] + l01 * v[K - 1]) + mu[0];
+        kap[K - 1] = k == 1 ? mu[K - 1] : a.s2inv * (l10 * v[0] + l11 * v[K - 1]) + mu[K - 1];
+        P[0][0] = l00;
+        if (k == 2) {
+          P[0][K - 1] = l01;
+          P[K - 1][0] = l10;
+          P[K - 1][K - 1] = l11;
+        }
+      }
+      return;
     }
   }
   double logdet;
@@ -709,7 +778,8 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
         l01 = pe[p].l01;
         l10 = pe[p].l10;
         l11 = pe[p].l11;
-        if (pair_singular_L(pe[p].L)) atomicOr(a.err, 2);
+        // L = +inf with a finite Lam: Psi_A exactly singular -- the reference's own lpj = +inf -> B_max (tables kernel)
+        if (pair_singular_L(pe[p].L) && pair_singular_lam(pe[p].l00)) atomicOr(a.err, 2);
       }
       const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
       const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
@@ -1400,7 +1470,16 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
     const double g = G[t], p = Psi[t];
     DG[h0] = make_double4(mus[h0], pil_bar[h0], g, p);
     const double T = 1.0 + s * p * g;
-    D1[h0] = make_double4(mus[h0], pil_bar[h0] - 0.5 * log(fabs(T)), g, p / T);
+    double4 d = make_double4(mus[h0], pil_bar[h0] - 0.5 * log(fabs(T)), g, p / T);
+    if (p == 0.0) {
+      // Psi_hh = 0 exactly (only through the per-datapoint operators: check_params floors the diagonal): the reference's
+      // inv(Psi_s) raises, it takes pinv(Psi_s) = 0 and slogdet(Psi_s) = -inf, so C_det = -inf and lpj = +inf, which
+      // lpj_reset_check turns into B_max (sssc.py:278-305, _models.py:594); its statistics use Lam = inv(G_hh / sigma2)
+      // (pinv of that where G_hh = 0 as well)
+      d.y = __builtin_inf();
+      d.w = (s * g != 0.0) ? 1.0 / (s * g) : 0.0;
+    }
+    D1[h0] = d;
     return;
   }
   if (h0 > h1) return;
@@ -1420,6 +1499,13 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
   e.l10 = (T00 * P10 - T10 * P00) * rdet;
   e.l11 = (T00 * P11 - T10 * P01) * rdet;
   e.pad[0] = e.pad[1] = 0.0;  // det == 0: L = +inf and Lam non-finite carry the "singular" mark
+  if (lu2_exactly_singular(P00, P01, P10, P11)) {
+    // Psi_A exactly singular (np.linalg.inv raises): the reference goes on with pinv(Psi_A) and slogdet(Psi_A) = -inf, so
+    // lpj = +inf -> B_max, and its statistics use Lam = inv(G_A / sigma2 + pinv(Psi_A)) (pinv of that if it is singular
+    // too) -- NOT the continuous limit T^-1 Psi_A of the lines above (sssc.py:278-301).  L = +inf with a FINITE Lam.
+    pair_lam_singular_psi(s, G00, G01, G10, G11, P00, P01, P10, P11, e.l00, e.l01, e.l10, e.l11);
+    e.L = __builtin_inf();
+  }
   PT[t] = e;
 }
 

@@ -644,13 +644,19 @@ def sssc_state_terms(theta, state, obs=None):
         obs = np.ones(W.shape[0], dtype=bool)  # complete data; same indexing expression as the reference
     W_s = W[obs, :][:, state]
     Psi_s = Psi[state, :][:, state]
-    Psi_s_inv = np.linalg.inv(Psi_s)
-    logdet_Psi = np.linalg.slogdet(Psi_s)[1]
+    try:
+        Psi_s_inv = np.linalg.inv(Psi_s)
+    except np.linalg.LinAlgError:          # sssc.py:278-283: exactly singular Psi_s
+        Psi_s_inv = np.linalg.pinv(Psi_s)
+    logdet_Psi = np.linalg.slogdet(Psi_s)[1]   # -inf then: C_det = -inf, lpj = +inf -> B_max (lpj_clamp)
     Wmu = np.dot(W_s, mus[state])
     sW = s2i * W_s
     M = np.dot(W_s.T, sW) + Psi_s_inv
     logdet_M = np.linalg.slogdet(M)[1]
-    lam = np.linalg.inv(M)
+    try:
+        lam = np.linalg.inv(M)
+    except np.linalg.LinAlgError:          # sssc.py:295-300
+        lam = np.linalg.pinv(M)
     lam_Wt = np.dot(lam, W_s.T) * s2i
     C_inv = -np.dot(sW, lam_Wt) + s2i * np.eye(int(obs.sum()))
     return {"Wmu": Wmu, "C_det": logdet_M + logdet_Psi, "C_inv": C_inv, "lam": lam, "lam_Wt": lam_Wt}

@@ -237,6 +237,53 @@ def make_lpj_fixtures():
         suff["storage"] = {"storagekeys": (), "counts_norm": 0, "counts": 0}
     np.savez_compressed(os.path.join(HERE, "lpj_sssc.npz"), H=np.int64(H), states=pack(states), Y=Y, lpj=lpj,
                         ljc=np.float64(theta["ljc"]), **theta_arrays("", theta, SSSC_KEYS))
+    # --- SSSC, exactly singular Psi_s (sssc.py:278-301: pinv branches; lpj = +inf -> B_max).  Direct operator calls, so
+    # check_params (which floors the diagonal of Psi) is not in the way of a zero variance.  k <= 2 only: those are the
+    # states evo_amd serves the reference's way; per state the lambda_s / kappa the reference's statistics use
+    D, H = 16, 14
+    model = SSSC(D, H, 20, use_storage=True)
+    theta = learned_like_sssc_theta(D, H, rng)
+    Psi = theta["Psi"]
+    for a, b in ((2, 5),):                    # two equal rows / columns inside every A that holds both
+        Psi[a, a] = Psi[b, b] = Psi[a, b] = Psi[b, a] = 1.0
+    for h in (7, 9, 11):                      # zero variance, uncorrelated with everything
+        Psi[h, :] = 0.0
+        Psi[:, h] = 0.0
+    Psi[3, 8] = 2.0 * Psi[3, 3]               # rows in a power-of-two ratio: [[p, 2p], [p/2... ]] made exact below
+    Psi[8, 3] = 0.5 * Psi[3, 3]
+    Psi[8, 8] = Psi[3, 3]                     # [[p, 2p], [p/2, p]]: row 1 = row 0 / 2 exactly
+    sets = [(), (2,), (5,), (2, 5), (7,), (2, 7), (7, 12), (9, 11), (9,), (3, 8), (3,), (8,), (1, 4), (0, 13), (6, 10),
+            (1,), (12,), (4, 6), (10, 13), (0,)]
+    states = np.zeros((len(sets), H), dtype=bool)
+    for c, on in enumerate(sets):
+        states[c, list(on)] = True
+    Y = rng.normal(size=(3, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    suff = {}
+    model.E_step_precompute(theta, suff, my_data)
+    lpj = np.zeros((3, len(sets)))
+    lam = np.zeros((len(sets), 2, 2))
+    kappa = np.zeros((3, len(sets), 2))
+    cnt = np.zeros((3, 3), dtype=np.int64)
+    for n in range(3):
+        my_data["this_y"] = Y[n]
+        my_data["this_x_infr"] = my_data["x_infr"][n]
+        suff["this_states"] = states
+        for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"):
+            suff[key] = 0
+        with np.errstate(all="ignore"):
+            lpj[n] = model.log_pseudo_joint(theta, suff, my_data)
+        cnt[n] = [suff["reset_lpj_isnan"], suff["reset_lpj_smaller_eps_lpj"], suff["reset_lpj_isinf"]]
+        for c, on in enumerate(sets):            # what the statistics loop reads from `storage` (sssc.py:566-575)
+            if not on:
+                continue
+            ent = suff["storage"][str((model.s_ids * states[c]).sum())]
+            k = len(on)
+            lam[c, :k, :k] = ent["lambda_s"]
+            kappa[n, c, :k] = np.dot(ent["lambda_s_W_s_sigma2_inv"], Y[n] - ent["W_s_mus_s"]) + theta["mus"][states[c]]
+    np.savez_compressed(os.path.join(HERE, "lpj_sssc_singular.npz"), H=np.int64(H), states=pack(states), Y=Y, lpj=lpj,
+                        lam=lam, kappa=kappa, reset_counts=cnt, psi_s_pinv=np.int64(suff["Psi_s_pinv"]),
+                        ljc=np.float64(theta["ljc"]), **theta_arrays("", theta, SSSC_KEYS))
     # --- clamp behaviour (_models.py:567-596)
     model = BSC(4, 4, 4)
     cases = [np.array([1.0, np.nan, -np.inf, np.inf]), np.array([-np.inf, 2.0, -3.0]), np.array([np.inf, 1.0]),
@@ -529,6 +576,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "perm":  # permanent all-zero state (S_perm = 1), added later
         make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
         make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lpj":  # the direct-operator fixtures only (lpj_*.npz)
+        make_lpj_fixtures()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prec32":  # SSSC(precision=np.float32) (sssc.py:49), added in round 3
         make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)

@@ -80,6 +80,51 @@ def test_lpj_sssc_kat(engine):
     _close(out, g["lpj"][1], 1e-11, "single")
 
 
+def test_lpj_sssc_singular_psi(engine):
+    """States with at most two active latents whose Psi_A is EXACTLY singular (np.linalg.inv raises: a zero variance, two
+    equal rows, rows in a power-of-two ratio): the reference goes on with pinv(Psi_A) and slogdet = -inf, i.e. lpj = +inf
+    -> B_max with the isinf counter, and its statistics use Lam = inv(G_A / sigma2 + pinv(Psi_A)) (sssc.py:278-301).
+    lpj_sssc_singular.npz holds the reference's lpj, lambda_s and kappa_s.  Served by the state-term tables (resident
+    pass, per-datapoint operator) and by the K = 2 register path (shared sets); the statistics against the oracle's
+    restatement of the reference loop on the same K^n."""
+    from oracle import evo_oracle as orc
+    g = load_golden("lpj_sssc_singular.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    theta = {k: np.array(g[k]) for k in ("W", "pies", "mus", "Psi")}
+    theta["sigma2"] = np.float64(g["sigma2"])
+    engine.configure("sssc", N, D, H, C, 0, 8)
+    engine.upload_data(Y)
+    engine.upload_states(np.tile(states[None], (N, 1, 1)))
+    engine.set_params_sssc(theta["W"], theta["pies"], theta["mus"], theta["Psi"], float(theta["sigma2"]))
+    engine.lpj_resident()
+    got = engine.download_lpj()
+    sing = g["lpj"][0] == 0.0
+    assert sing.sum() == 7
+    assert (got[:, sing] == 0.0).all()  # B_max exactly
+    _close(got[:, ~sing], g["lpj"][:, ~sing], 1e-11, "regular states beside singular ones")
+    shared = engine.lpj_shared(states)  # K = 2 register path (no tables)
+    assert (shared[:, sing] == 0.0).all()
+    _close(shared[:, ~sing], g["lpj"][:, ~sing], 1e-11, "shared set")
+    out, flags = engine.lpj_single(Y[1], states)
+    assert (out[sing] == 0.0).all()
+    _close(out[~sing], g["lpj"][1][~sing], 1e-11, "single")
+    # statistics of this K^n: the singular states carry weight exp(0 - max) = the dominant weight of their row
+    engine.lpj_resident()
+    v = engine.acc_views(engine.stats())
+    suff = {"ss": np.tile(states[None], (N, 1, 1)), "lpj": np.empty((N, C)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool),
+            "Mprime": C}
+    with np.errstate(all="ignore"):
+        want = orc.sssc_EM_accumulate(dict(theta), suff, Y, use_storage=False, evolve=False)
+    for name in ("xpt_s", "xpt_ss", "xpt_sz", "xpt_szsz", "Wp", "s_sz_outer", "sz_sz_outer"):
+        ref = want[name]
+        assert np.abs(v[name] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), name
+    assert int(v["reset_isinf"]) >= 1  # the +inf values were counted (_models.py:589-590)
+
+
 def test_reconfigure_after_masks_drops_them(engine):
     """Round-2 abort (gpurun_out/r2_tests1.txt: `Fatal Python error: Aborted` at the first synchronisation after the lpj
     pass of a shape test that followed the missing-data tests on the shared engine): evoamd_configure kept mask_infr /

@@ -214,6 +214,33 @@ def test_lpj_sssc():
     np.testing.assert_allclose(theta["ljc"], float(g["ljc"]), rtol=1e-15)
 
 
+def test_lpj_sssc_singular_psi():
+    """Exactly singular Psi_s (sssc.py:278-301): pinv branches, lpj = +inf -> B_max with the isinf counter, and the
+    lambda_s / kappa_s the reference's statistics loop reads from its storage -- all from the reference itself."""
+    g = load_golden("lpj_sssc_singular.npz")
+    H = int(g["H"])
+    theta = {k: g[k] for k in SSSC_KEYS}
+    theta["sigma2"] = np.float64(theta["sigma2"])
+    states = unpack_bits(g["states"], H)
+    Y = g["Y"]
+    assert int((g["lpj"][0] == 0.0).sum()) == 7  # seven of the twenty states hold an exactly singular Psi_s
+    for n in range(Y.shape[0]):
+        cnt = orc.sssc_precompute(theta, Y.shape[1])
+        cache = {}
+        with np.errstate(all="ignore"):
+            got = orc.sssc_lpj(theta, states, Y[n], cnt, cache)
+        np.testing.assert_allclose(got, g["lpj"][n], rtol=1e-13, atol=0)
+        assert [cnt["isnan"], cnt["smaller_eps"], cnt["isinf"]] == list(g["reset_counts"][n])
+        for c in range(states.shape[0]):
+            k = int(states[c].sum())
+            if k == 0:
+                continue
+            t = cache[states[c].tobytes()]
+            np.testing.assert_allclose(t["lam"], g["lam"][c, :k, :k], rtol=1e-12, atol=1e-14)
+            kap = np.dot(t["lam_Wt"], Y[n] - t["Wmu"]) + theta["mus"][states[c]]
+            np.testing.assert_allclose(kap, g["kappa"][n, c, :k], rtol=1e-11, atol=1e-13)
+
+
 def test_lpj_clamp():
     g = load_golden("lpj_clamp.npz")
     for i in range(4):
