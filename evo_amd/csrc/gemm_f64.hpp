@@ -600,63 +600,58 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
     for (int j = 0; j < 2; j++) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
   const int am = t >> 2, ak = (t & 3) * 4;   // A loader: row m, 4 consecutive k
   const int br = t >> 4, bc = (t & 15) * 4;  // B loader: row k, 4 consecutive columns
-  double ra[4], rb[4];
-  auto fetch = [&](int k0) {
+  // Two register sets: the slab stashed at the end of iteration s was fetched at the end of iteration s - 2, i.e. two
+  // slabs of MFMAs earlier.  (One set, fetched at the top of the iteration and stashed at its bottom, left a load one
+  // slab = 16 MFMAs per wave to land: with K = D = 256 the product B = Y W sat at 51 TF/s waiting for it.)
+  double ra[2][4], rb[2][4];
+  auto fetch = [&](double(&qa)[4], double(&qb)[4], int k0) {
     const i64 m = m0 + am;
     if (VEC) {
       // A: 4 consecutive k of row m as two 16-byte pieces; B: pieces p = t + 256 i of the 16 x 32 grid
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int k = k0 + ak + 2 * i;
-        // branch-free clamped loads (K and Nc are even in the VEC instantiation)
+        // branch-free clamped loads (K and Nc are even in the VEC instantiation), also behind the end of K
         const i64 mc = m < M ? m : M - 1;
         // (zeroing of what lies outside: in stash(), after the slab's MFMAs -- a select on the loaded value here
         // would make the wave wait for the load before it starts them)
         const double2 va = *(const double2 *)(A + mc * lda + (k < K ? k : K - 2));
-        ra[2 * i] = va.x;
-        ra[2 * i + 1] = va.y;
+        qa[2 * i] = va.x;
+        qa[2 * i + 1] = va.y;
         const int p = t + 256 * i, kb = k0 + (p >> 5), cc = (p & 31) * 2, nb = n0 + cc;
         const double2 vb = *(const double2 *)(B + (i64)(kb < K ? kb : K - 1) * ldb + (nb < Nc ? nb : Nc - 2));
-        rb[2 * i] = vb.x;
-        rb[2 * i + 1] = vb.y;
+        qb[2 * i] = vb.x;
+        qb[2 * i + 1] = vb.y;
       }
     } else {
       const int kb = k0 + br;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int k = k0 + ak + q, n = n0 + bc + q;
-        ra[q] = (m < M && k < K) ? A[m * lda + k] : 0.0;
-        rb[q] = (kb < K && n < Nc) ? B[(i64)kb * ldb + n] : 0.0;
+        qa[q] = (m < M && k < K) ? A[m * lda + k] : 0.0;
+        qb[q] = (kb < K && n < Nc) ? B[(i64)kb * ldb + n] : 0.0;
       }
     }
   };
-  auto stash = [&](int buf, int k0) {
+  auto stash = [&](const double(&qa)[4], const double(&qb)[4], int buf, int k0) {
     if (VEC) {
       const bool min = m0 + am < M;
 #pragma unroll
-      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = (min && k0 + ak + (q & ~1) < K) ? ra[q] : 0.0;
+      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = (min && k0 + ak + (q & ~1) < K) ? qa[q] : 0.0;
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int p = t + 256 * i, r = p >> 5, cc = (p & 31) * 2;
         const bool inb = k0 + r < K && n0 + cc < Nc;
-        *(double2 *)&Bs[buf][r][cc] = inb ? make_double2(rb[2 * i], rb[2 * i + 1]) : make_double2(0.0, 0.0);
+        *(double2 *)&Bs[buf][r][cc] = inb ? make_double2(qb[2 * i], qb[2 * i + 1]) : make_double2(0.0, 0.0);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = ra[q];
+      for (int q = 0; q < 4; q++) As[buf][ak + q][am] = qa[q];
 #pragma unroll
-      for (int q = 0; q < 4; q++) Bs[buf][br][bc + q] = rb[q];
+      for (int q = 0; q < 4; q++) Bs[buf][br][bc + q] = qb[q];
     }
   };
-  if (K > 0) {
-    fetch(0);
-    stash(0, 0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += GEMM_BK, buf ^= 1) {
-    const bool more = k0 + GEMM_BK < K;
-    if (more) fetch(k0 + GEMM_BK);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
       const int kl = kk * 4 + (lane >> 4);
@@ -671,8 +666,43 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
         for (int j = 0; j < 2; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1, k0 + GEMM_BK);
+  };
+  if (VEC) {
+    // branch-free slab loop (an `if (more) fetch` makes the compiler wait for vmcnt(0) before every stash, gemm_tn128_segment):
+    // slab count padded to even with an all-zero slab (stash() zeroes rows >= K), fetches behind the end clamped
+    int nslab = (K + GEMM_BK - 1) / GEMM_BK;
+    nslab = (nslab + 1) & ~1;
+    if (nslab > 0) {
+      fetch(ra[0], rb[0], 0);
+      stash(ra[0], rb[0], 0, 0);
+      fetch(ra[1], rb[1], GEMM_BK);
+      fetch(ra[0], rb[0], 2 * GEMM_BK);
+    }
     __syncthreads();
+    for (int s0 = 0; s0 < nslab; s0 += 2) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int sl = s0 + j;
+        compute(j);
+        stash(ra[j ^ 1], rb[j ^ 1], j ^ 1, (sl + 1) * GEMM_BK);   // slab sl + 1, fetched two iterations ago
+        fetch(ra[j ^ 1], rb[j ^ 1], (sl + 3) * GEMM_BK);
+        __syncthreads();
+      }
+    }
+  } else {
+    if (K > 0) {
+      fetch(ra[0], rb[0], 0);
+      stash(ra[0], rb[0], 0, 0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GEMM_BK, buf ^= 1) {
+      const bool more = k0 + GEMM_BK < K;
+      if (more) fetch(ra[0], rb[0], k0 + GEMM_BK);
+      compute(buf);
+      if (more) stash(ra[0], rb[0], buf ^ 1, k0 + GEMM_BK);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; i++)

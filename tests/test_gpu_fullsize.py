@@ -160,7 +160,7 @@ def test_ebsc_full_size_properties(name):
             pre1, pil_bar = float(theta["pre1"]), float(theta["pil_bar"])  # left in the dict by E_step_precompute (bsc.py:99-125)
             sig = float((q * ((lpj - pil_bar * k) / pre1)).sum())
             assert abs(float(v2["sigma"]) - sig) <= 1e-9 * abs(sig)
-        for opt, val in (("pair_bins", 0), ("bsc_stats_wave", 0)):
+        for opt, val in (("pair_bins", 0), ("bsc_stats_wave", 0), ("gemm_grouped", 0)):
             eng.set_option(opt, val)
             try:
                 v3 = eng.acc_views(eng.stats())
@@ -168,6 +168,37 @@ def test_ebsc_full_size_properties(name):
                 eng.set_option(opt, 1)
             for name in ("Wp", "Wq", "pies", "sigma"):
                 assert _rel(v3[name], v2[name]) <= 1e-10, (opt, name)
+    finally:
+        eng.close()
+
+
+def test_ebsc_float32_full_size():
+    """BASELINE configs[4] in the float32 mode at its full one-GPU size (N = 200k): the E_q[s] rows are float and
+    Wp = Es^T Y runs on the f32 matrix cores as a grouped split-K (16 tiles x 32 chunks; partial tiles in f32 over
+    6 250 rows each, summed in double).  With Theta fixed the E-step only raises F, the passes are idempotent, the
+    grouped and the stream-K contraction agree to float32 accumulation accuracy, and the double sums (Wq, pies, sigma)
+    do not depend on the contraction's form."""
+    cfg, eng, model, theta, suff, my_data = _setup("c5", dtype=np.float32)
+    try:
+        for _ in range(2):
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            assert np.isfinite(F)
+        Fe = [model.E_step(theta, suff, my_data)[0] for _ in range(2)]
+        assert Fe[1] >= Fe[0] - 1e-9 * abs(Fe[0]), Fe
+        eng.lpj_resident()
+        l1 = eng.download_lpj()
+        eng.lpj_resident()
+        assert np.array_equal(l1, eng.download_lpj())
+        v1 = {k: np.array(v) for k, v in eng.acc_views(eng.stats()).items() if k in ("Wp", "Wq", "pies", "sigma")}
+        eng.set_option("gemm_grouped", 0)
+        try:
+            v2 = eng.acc_views(eng.stats())
+            assert _rel(v2["Wp"], v1["Wp"]) <= 5e-6          # two float32 summation orders
+            for name in ("Wq", "pies", "sigma"):              # double sums: untouched by the contraction's form
+                assert _rel(v2[name], v1[name]) <= 1e-10, name
+        finally:
+            eng.set_option("gemm_grouped", 1)
+        assert np.array_equal(np.diag(v1["Wq"]), v1["pies"]) and np.array_equal(v1["Wq"], v1["Wq"].T)
     finally:
         eng.close()
 
