@@ -2838,6 +2838,13 @@ static int launch_inverse_spd(evoamd_ctx *c, double *A, double *B, int n) {
   gm.w[1] = c->gjwork + (size_t)n * n;
   double *Pinv = c->gjwork + (size_t)2 * n * n + (size_t)130 * n + 8;
   double *d0 = Pinv + 2 * 2 * GJS_B * GJS_B;
+  // n <= 128: one launch, the matrix in the registers of one workgroup per matrix ("inverse_block" = 16 / 32 force the
+  // multi-launch forms)
+  if (n <= GJR_MAXN && c->spd_block == 0) {
+    gjs_resident_kernel<<<nmat, 1024, 0, c->stream>>>(gm, n, c->dpar + DP_STATUS);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   // measured per inverse pair (tools/bench_inverse.py): n = 128 71 vs 73 us, 256 129 vs 141, 512 241 vs 286,
   // 1024 629 vs 774 -- the wider step pays from n = 256 on ("inverse_block" = 32 forces it from n = 32 for the tests)
   if (n >= GJS32 && (c->spd_block == 32 || (c->spd_block == 0 && n >= 256))) {

@@ -792,6 +792,104 @@ __global__ __launch_bounds__(256) void gjs_step_kernel(GjMats m, int n, int p0, 
 }
 
 // ---------------------------------------------------------------------------------------
+// n <= 128: the whole SPD block Gauss-Jordan in ONE launch, one workgroup of 16 waves per matrix.  The matrix never
+// leaves the registers: wave w holds the 16-row strip (row tile w >> 1, column tiles 4 (w & 1) .. + 3) as four MFMA
+// accumulator tiles; per 16-column step only the pivot block, the column panel and the row panel pass through LDS.
+// Same arithmetic as gjs_step_kernel (E[:, J] = [-A[i, J] P^-1 ; P^-1], A <- A + (E - I_J) A[J, :]) with the padding
+// of the last block made an identity block, so no masks are needed.  Replaces 1 + n / 16 dependent launches of 5-8 us
+// each (H = 128: 70 us, a sixth of a BASELINE configs[1] iteration) by one of ~30 us.
+// ---------------------------------------------------------------------------------------
+#define GJR_MAXN 128
+__global__ __launch_bounds__(1024) void gjs_resident_kernel(GjMats m, int n, double *__restrict__ status) {
+  const int mat = blockIdx.x;
+  double *__restrict__ A = m.a[mat];
+  __shared__ double Pn[GJS_B][GJS_B + 1];   // pivot block, then its inverse
+  __shared__ double dn[GJS_B];
+  __shared__ double Ar[GJR_MAXN][GJS_B + 1];  // column panel A[:, J]
+  __shared__ double Ds[GJS_B][GJR_MAXN + 4];  // D = E - I_J, transposed: Ds[k][row]
+  __shared__ double Rs[GJS_B][GJR_MAXN + 4];  // row panel A[J, :], zero inside J
+  __shared__ double d0[GJR_MAXN];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ti = w >> 1, tj0 = 4 * (w & 1);
+  const int li = lane & 15, lg = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * ti + lg + 4 * r, col = 16 * (tj0 + j) + li;
+      acc[j][r] = (row < n && col < n) ? A[(size_t)row * n + col] : ((row == col) ? 1.0 : 0.0);
+    }
+  if (t < GJR_MAXN) d0[t] = (t < n) ? A[(size_t)t * n + t] : 1.0;
+  const int nsteps = (n + GJS_B - 1) / GJS_B;
+  bool ok = true;
+  __syncthreads();
+  for (int p = 0; p < nsteps; p++) {
+    // the pivot block, from the wave that holds tile (p, p)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (ti == p && tj0 + j == p) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Pn[lg + 4 * r][li] = acc[j][r];
+      }
+    if (w == 0 && lane < GJS_B) dn[lane] = d0[GJS_B * p + lane];
+    __syncthreads();
+    // wave 0 inverts it while the others lay out the panels
+    if (w == 0) ok = inv16_spd_wave(Pn, dn) && ok;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (tj0 + j == p) {  // column panel: my rows of A[:, J]
+#pragma unroll
+        for (int r = 0; r < 4; r++) Ar[16 * ti + lg + 4 * r][li] = acc[j][r];
+      }
+      if (ti == p) {  // row panel: my columns of A[J, :]
+#pragma unroll
+        for (int r = 0; r < 4; r++) Rs[lg + 4 * r][16 * (tj0 + j) + li] = (tj0 + j == p) ? 0.0 : acc[j][r];
+      }
+    }
+    __syncthreads();
+    if ((w & 1) == 0) {  // D for row tile ti: -A[i, J] P^-1, or P^-1 - I for the rows of J
+      v4f64 ad = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < GJS_B / 4; kk++)
+        ad = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[16 * ti + li][4 * kk + lg], Pn[4 * kk + lg][li], ad, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int lr = lg + 4 * r;
+        double v = -ad[r];
+        if (ti == p) v = Pn[lr][li] - ((lr == li) ? 1.0 : 0.0);
+        Ds[li][16 * ti + lr] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (tj0 + j == p) {  // E = D + I_J
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int lr = lg + 4 * r;
+          acc[j][r] = Ds[li][16 * ti + lr] + ((ti == p && lr == li) ? 1.0 : 0.0);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < GJS_B / 4; kk++)
+          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[4 * kk + lg][16 * ti + li], Rs[4 * kk + lg][16 * (tj0 + j) + li],
+                                                        acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * ti + lg + 4 * r, col = 16 * (tj0 + j) + li;
+      if (row < n && col < n) A[(size_t)row * n + col] = acc[j][r];
+    }
+  if (w == 0 && !ok && lane == 0) status[0] = 3.0;
+}
+
+// ---------------------------------------------------------------------------------------
 // 32-column block steps (n >= 32).  A 16-column step costs ~8.5 us whatever n is: ~2 us launch, ~2.5 us
 // of tile loads / MFMA / stores and ~2.5 us for the chain of 16 scalar pivots of the next diagonal block,
 // with only the last part depending on the block width.  Here one launch eliminates 32 columns and the

@@ -83,7 +83,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * next statistics pass forms y_reconstructed between the moment rows and the Wp contraction
  * (bsc.py:184-189, sssc.py:630-633).
  * "inverse_block" (0 / 16 / 32, default 0): columns eliminated per launch by the SPD block Gauss-Jordan;
- * 0 = 32 from n = 256 on (32 x 32 pivot block inverted in registers through its Schur complement), else 16.
+ * 0 = up to n = 128 the whole elimination in ONE launch (one workgroup per matrix, the matrix in its registers), 32 from
+ * n = 256 on (32 x 32 pivot block inverted in registers through its Schur complement), 16 in between; 16 / 32 force the
+ * multi-launch forms.
  * "prefetch_lpj" (0/1, default 1): evoamd_mstep_device enqueues the next iteration's evoamd_lpj_resident
  * pass behind its mailbox kernel (the GPU works while the host turns the iteration around); the next
  * evoamd_lpj_resident call returns at once unless Theta, K^n, the data or an option changed in between.
