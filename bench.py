@@ -646,8 +646,8 @@ def main():
             fl = gemm_flops_per_iteration(cfg, n_loc, executed=True)
             f32 = bool(cfg.get("f32"))
             peak = F32_MFMA_PEAK_TFLOPS if f32 else F64_MFMA_PEAK_TFLOPS
-            out["mfma"] = {"kernels": ("gemm_tn128_sk_f32 / gemm_tn128_store_f32 (v_mfma_f32_16x16x4_f32)" if f32 else
-                                       "gemm_tn128_sk_f64 / gemm_tn128_rows_f64 / gemm_tn_f64 / gemm_nn_f64 (v_mfma_f64_16x16x4_f64)"),
+            out["mfma"] = {"kernels": ("gemm_tn128_gk<float> (grouped split-K) / gemm_tn128_sk_f32 / gemm_tn128_store_f32 (v_mfma_f32_16x16x4_f32)" if f32 else
+                                       "gemm_tn128_gk (grouped split-K; gemm_tn128_sk_f64 where chunks do not fill the grid) / gemm_tn128_rows_f64 / gemm_tn_f64 / gemm_nn_f64 (v_mfma_f64_16x16x4_f64)"),
                            "flops_per_iteration": fl,
                            "flops_note": "EXECUTED flops: 2 M N K of every product, the symmetric block of the ES3C contraction "
                                          "counted with the upper tiles it really runs (34 of 40 tiles at H = 512); "

@@ -9,8 +9,10 @@ from collections import defaultdict
 
 
 def find(root, suffix):
+    # newest match: gpurun MERGES what a run wrote into the local gpurun_out/, so files of earlier runs of the same
+    # tag may still lie beside the new ones
     hits = glob.glob(os.path.join(root, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def short(name):
@@ -50,7 +52,7 @@ def main(out):
             print("(no bench line next to the trace: %s)\n" % e)
         print("Note: a kernel's duration runs from its dispatch to its end.  The H x H elimination chain (gjs32_first_kernel, "
               "then gjs32_step_kernel) is launched on the main stream while the persistent stream-K contraction "
-              "(gemm_tn128_sk_f64) holds every CU slot on the second stream: the first kernel of the chain waits for a slot "
+              "(gemm_tn128_gk / gemm_tn128_sk_f64) holds every CU slot on the second stream: the first kernel of the chain waits for a slot "
               "for most of the contraction, so its `avg us` (and its share of the GPU time) is queueing, not work -- its min "
               "(~15 us) is the kernel itself.\n")
     pmc = {}
