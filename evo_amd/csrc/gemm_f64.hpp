@@ -35,7 +35,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // instructions per thread and K slab and ran at ~50 % of the MFMA rate: the address coalescer, not
 // the matrix cores, was the busy unit.
 template <bool VEC>
-__global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A, int lda,
+__global__ __launch_bounds__(256, 3) void gemm_tn_f64(const double *__restrict__ A, int lda,
                                                    const double *__restrict__ B, int ldb,
                                                    double *__restrict__ C, int ldc, int M, int Nc,
                                                    i64 K, i64 k_per_split, int gx, int gy, int split, int sym_row0) {
@@ -151,7 +151,41 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(const double *__restrict__ A,
   }
   __syncthreads();
   // slab s is in LDS buffer s & 1; slab s + 1 + j waits in register set j (rotating)
-  for (i64 s0 = 0; s0 < nslab; s0 += 3) {
+  i64 s0 = 0;
+  if (VEC && m0 + GEMM_BM <= M && n0 + GEMM_BN <= Nc) {  // uniform
+    // interior fast path (as in gemm_tn128_segment): while the three slabs stashed and the three fetched by a round lie
+    // wholly inside [kbeg, kend), plain LDS writes and two running pointers -- the general form spends 128 vector
+    // instructions beside the 32 MFMAs of two slabs
+    const int r0 = t >> 5, pc = (t & 31) * 2;
+    const double *pa = A + (kbeg + 4 * GEMM_BK + r0) * (i64)lda + m0 + pc;  // slab 4, piece 0; piece 1 is 8 rows below
+    const double *pb = B + (kbeg + 4 * GEMM_BK + r0) * (i64)ldb + n0 + pc;
+    const i64 a8 = (i64)8 * lda, b8 = (i64)8 * ldb, aS = (i64)GEMM_BK * lda, bS = (i64)GEMM_BK * ldb;
+    for (; kbeg + (s0 + 7) * GEMM_BK <= kend; s0 += 3) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int buf = (int)((s0 + j) & 1);
+        compute(buf);
+        *(double2 *)&As[buf ^ 1][r0][pc] = make_double2(ra[j][0], ra[j][1]);
+        *(double2 *)&As[buf ^ 1][r0 + 8][pc] = make_double2(ra[j][2], ra[j][3]);
+        *(double2 *)&Bs[buf ^ 1][r0][pc] = make_double2(rb[j][0], rb[j][1]);
+        *(double2 *)&Bs[buf ^ 1][r0 + 8][pc] = make_double2(rb[j][2], rb[j][3]);
+        const double2 a0 = *(const double2 *)pa, a1 = *(const double2 *)(pa + a8);
+        const double2 b0 = *(const double2 *)pb, b1 = *(const double2 *)(pb + b8);
+        ra[j][0] = a0.x;
+        ra[j][1] = a0.y;
+        ra[j][2] = a1.x;
+        ra[j][3] = a1.y;
+        rb[j][0] = b0.x;
+        rb[j][1] = b0.y;
+        rb[j][2] = b1.x;
+        rb[j][3] = b1.y;
+        pa += aS;
+        pb += bS;
+        __syncthreads();
+      }
+    }
+  }
+  for (; s0 < nslab; s0 += 3) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const i64 sl = s0 + j;
@@ -298,7 +332,39 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
     fetch(ra, rb, kbeg + GEMM_BK);
   }
   __syncthreads();
-  for (i64 s0 = 0; s0 < nslab; s0 += 2) {
+  i64 s0 = 0;
+  // Interior fast path: while the slab being stashed and the slab being fetched lie wholly inside [kbeg, kend) of a
+  // tile that lies wholly inside C, nothing needs a mask or a clamp -- the stash is 2 NP plain 16-byte LDS writes (the
+  // general form selects every piece against zero: 4 v_cndmask per write) and the fetch walks two running pointers
+  // (the general form rebuilds 2 NP clamped 64-bit addresses per slab).  Per slab and wave that is ~25 vector
+  // instructions beside the 64 MFMAs instead of ~100 (ISA of the loop: tools/isa_loop.py).
+  if (m0 + GEMM_T <= M && n0 + GEMM_T <= Nc) {  // uniform
+    constexpr int RPP = 256 / PPR;  // rows between a thread's consecutive pieces: p = t + 256 i -> row t / PPR + RPP i
+    const int pr = t / PPR, pc = (t % PPR) * EPP;
+    const T *pa = A + (kbeg + 2 * GEMM_BK + pr) * (i64)lda + m0 + pc;  // this thread's first piece of slab 2
+    const T *pb = B + (kbeg + 2 * GEMM_BK + pr) * (i64)ldb + n0 + pc;
+    const i64 stepA = (i64)RPP * lda, stepB = (i64)RPP * ldb, slabA = (i64)GEMM_BK * lda, slabB = (i64)GEMM_BK * ldb;
+    for (; kbeg + (s0 + 4) * GEMM_BK <= kend; s0 += 2) {
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        compute(j);
+#pragma unroll
+        for (int i = 0; i < NP; i++) {  // slab s0 + j + 1, fetched one iteration ago
+          *(piece_t *)&As[j ^ 1][pr + RPP * i][pc] = ra[i];
+          *(piece_t *)&Bs[j ^ 1][pr + RPP * i][pc] = rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {  // slab s0 + j + 2
+          ra[i] = *(const piece_t *)(pa + i * stepA);
+          rb[i] = *(const piece_t *)(pb + i * stepB);
+        }
+        pa += slabA;
+        pb += slabB;
+        __syncthreads();
+      }
+    }
+  }
+  for (; s0 < nslab; s0 += 2) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const i64 sl = s0 + j;
@@ -578,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // C (M x Nc) = A B with A: M x K (lda) row-major, B: K x Nc (ldb).  No K split (K = D or H is small).
 template <bool VEC>
-__global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A, int lda,
+__global__ __launch_bounds__(256, 4) void gemm_nn_f64(const double *__restrict__ A, int lda,
                                                    const double *__restrict__ B, int ldb,
                                                    double *__restrict__ C, int ldc, i64 M, int Nc,
                                                    int K, int gx, int gy, int rows_per_xcd) {
@@ -679,7 +745,38 @@ __global__ __launch_bounds__(256) void gemm_nn_f64(const double *__restrict__ A,
       fetch(ra[0], rb[0], 2 * GEMM_BK);
     }
     __syncthreads();
-    for (int s0 = 0; s0 < nslab; s0 += 2) {
+    int s0 = 0;
+    // interior fast path (as in gemm_tn128_segment): no masks in the stash, two running pointers in the fetch -- the
+    // general form spends 78 vector instructions beside the 32 MFMAs of a slab pair
+    if (m0 + GEMM_BM <= M && n0 + GEMM_BN <= Nc) {  // uniform
+      const double *pa = A + (m0 + am) * (i64)lda + 3 * GEMM_BK + ak;               // slab 3: 4 consecutive k of row m
+      const double *pb = B + (i64)(3 * GEMM_BK + (t >> 5)) * ldb + n0 + (t & 31) * 2;  // piece 0; piece 1 is 8 rows below
+      const i64 step8 = (i64)8 * ldb, slabB = (i64)GEMM_BK * ldb;
+      for (; (s0 + 5) * GEMM_BK <= K; s0 += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          compute(j);
+#pragma unroll
+          for (int q = 0; q < 4; q++) As[j ^ 1][ak + q][am] = ra[j ^ 1][q];
+          *(double2 *)&Bs[j ^ 1][t >> 5][(t & 31) * 2] = make_double2(rb[j ^ 1][0], rb[j ^ 1][1]);
+          *(double2 *)&Bs[j ^ 1][8 + (t >> 5)][(t & 31) * 2] = make_double2(rb[j ^ 1][2], rb[j ^ 1][3]);
+          const double2 a0 = *(const double2 *)pa, a1 = *(const double2 *)(pa + 2);
+          const double2 b0 = *(const double2 *)pb, b1 = *(const double2 *)(pb + step8);
+          ra[j ^ 1][0] = a0.x;
+          ra[j ^ 1][1] = a0.y;
+          ra[j ^ 1][2] = a1.x;
+          ra[j ^ 1][3] = a1.y;
+          rb[j ^ 1][0] = b0.x;
+          rb[j ^ 1][1] = b0.y;
+          rb[j ^ 1][2] = b1.x;
+          rb[j ^ 1][3] = b1.y;
+          pa += GEMM_BK;
+          pb += slabB;
+          __syncthreads();
+        }
+      }
+    }
+    for (; s0 < nslab; s0 += 2) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int sl = s0 + j;
