@@ -363,6 +363,20 @@ __device__ __forceinline__ void gemm_tn128_segment(const T *__restrict__ A, int 
         __syncthreads();
       }
     }
+    // drain: the K range is a whole number of slab pairs, so the last pair needs no masks either and nothing is left to
+    // fetch (the general form would stash through selects and re-read the last row twice) -- it matters for the
+    // whole-K-per-tile products, B = Y W with K = D = 256: two of sixteen slabs
+    if (s0 + 2 == nslab && kbeg + nslab * GEMM_BK == kend) {
+      compute(0);
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        *(piece_t *)&As[1][pr + RPP * i][pc] = ra[i];
+        *(piece_t *)&Bs[1][pr + RPP * i][pc] = rb[i];
+      }
+      __syncthreads();
+      compute(1);
+      s0 = nslab;
+    }
   }
   for (; s0 < nslab; s0 += 2) {
 #pragma unroll
@@ -774,6 +788,40 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_f64(const double *__restrict__
           pb += slabB;
           __syncthreads();
         }
+      }
+      // drain (K a whole number of slab pairs): the last four slabs without masks, one real fetch left (slab S - 1) --
+      // with K = D = 256 they are a quarter of the product
+      if (s0 + 4 == nslab && nslab * GEMM_BK == K) {
+#define NN_STASH(set, buf)                                                                                   \
+  {                                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; q++) As[buf][ak + q][am] = ra[set][q];                          \
+    *(double2 *)&Bs[buf][t >> 5][(t & 31) * 2] = make_double2(rb[set][0], rb[set][1]);                       \
+    *(double2 *)&Bs[buf][8 + (t >> 5)][(t & 31) * 2] = make_double2(rb[set][2], rb[set][3]);                 \
+  }
+        compute(0);  // slab S - 4
+        NN_STASH(1, 1);  // slab S - 3
+        {
+          const double2 a0 = *(const double2 *)pa, a1 = *(const double2 *)(pa + 2);
+          const double2 b0 = *(const double2 *)pb, b1 = *(const double2 *)(pb + step8);
+          ra[1][0] = a0.x;
+          ra[1][1] = a0.y;
+          ra[1][2] = a1.x;
+          ra[1][3] = a1.y;
+          rb[1][0] = b0.x;
+          rb[1][1] = b0.y;
+          rb[1][2] = b1.x;
+          rb[1][3] = b1.y;  // slab S - 1
+        }
+        __syncthreads();
+        compute(1);  // slab S - 3
+        NN_STASH(0, 0);  // slab S - 2
+        __syncthreads();
+        compute(0);  // slab S - 2
+        NN_STASH(1, 1);  // slab S - 1
+        __syncthreads();
+        compute(1);  // slab S - 1
+#undef NN_STASH
+        s0 = nslab;
       }
     }
     for (; s0 < nslab; s0 += 2) {
