@@ -847,13 +847,15 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
       // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
       // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
       pb.nwg = c->bins_nwg;
-      pb.nsh = (i64)N * S >= (i64)8 << 20 ? PB_NSH_MAX : 4;
+      // reduce workgroups per bin: 4 (8 from 8 M resident states on), and enough of them that bins x workgroups fill
+      // the chip -- H = 128 has 4 bins, H = 256 has 16: with 4 workgroups each the reduce ran on 16 / 64 of 256 CUs
+      pb.nsh = std::max((i64)N * S >= (i64)8 << 20 ? 8 : 4, std::min(PB_NSH_MAX, 256 / std::max(1, pb.nb)));
       pb.cap = (int)std::max<i64>(64, (i64)c->bins_scale * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
       const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
       // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
       // rest, the statistics kernels use their global-atomic paths
       const bool got = hipMalloc((void **)&pb.ent, ne * sizeof(double4)) == hipSuccess &&
-                       hipMalloc((void **)&pb.part, (size_t)pb.nb * PB_NSH_MAX * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
+                       hipMalloc((void **)&pb.part, (size_t)pb.nb * pb.nsh * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
                        hipMalloc((void **)&pb.gcnt, (size_t)pb.nb * pb.nwg * sizeof(int)) == hipSuccess;
       if (got) {
         HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
@@ -1231,7 +1233,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     // chunk is long enough for the pipeline ramp
     const i64 J = (i64)8 * wpx / real;
     if (ws && c->gemm_grouped && J >= 2 && real * J * 100 >= (i64)8 * wpx * 93 && K / J >= 256) {
-      const i64 Kc = ((cdiv(K, J) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+      const i64 Kc = ((cdiv(K, J) + 2 * GEMM_BK - 1) / (2 * GEMM_BK)) * (2 * GEMM_BK);  // whole slab pairs: no padding slab, mask-free drain
       gemm_tn128_gk<double><<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kc, gx, gy,
                                                                             sym_row0, (int)real, (int)J, ws);
       gemm_gk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(ws, C, ldc, M, Nc, gx, gy,
@@ -1415,7 +1417,7 @@ static int launch_gemm_tn_f32(evoamd_ctx *c, const float *A, int lda, const floa
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, (i64)gx * gy, &segmax) : nullptr;
     const i64 real = (i64)gx * gy, J = (i64)8 * wpx / real;
     if (ws && c->gemm_grouped && J >= 2 && real * J * 100 >= (i64)8 * wpx * 93 && K / J >= 256) {  // see launch_gemm_tn
-      const i64 Kc = ((cdiv(K, J) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
+      const i64 Kc = ((cdiv(K, J) + 2 * GEMM_BK - 1) / (2 * GEMM_BK)) * (2 * GEMM_BK);
       gemm_tn128_gk<float><<<8 * wpx, 256, GEMM128_LDS_BYTES, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, Kc, gx, gy, -1,
                                                                            (int)real, (int)J, ws);
       gemm_gk_reduce_kernel<<<dim3((unsigned)real, GEMM_T * GEMM_T / 256), 256, 0, c->stream>>>(ws, C, ldc, M, Nc, gx, gy, -1,

@@ -15,8 +15,9 @@
 // ---------------------------------------------------------------------------------------
 #define PB_TILE 4096  // pair slots per LDS tile (x 3 values x 8 bytes = 96 KiB)
 #define PB_MAX_BINS 256
-#define PB_NSH_MAX 8  // reduce workgroups per bin: pb.nsh <= this (bins fill unevenly -- a few popular latents --: more,
-                      // smaller workgroups per bin let the scheduler even it out: 146 -> 116 us at c4; 16: no further gain)
+#define PB_NSH_MAX 16  // reduce workgroups per bin: pb.nsh <= this.  8 at large H (bins fill unevenly -- a few popular
+                       // latents --: more, smaller workgroups per bin let the scheduler even it out: 146 -> 116 us at c4; 16:
+                       // no further gain); more where there are few bins (H = 128: 4 bins, H = 256: 16), evo_amd.hip
 #define PB_RTHREADS 1024  // threads of a reduce workgroup (the 96 KiB tile leaves one workgroup per CU)
 struct PairBins {
   // nb x nwg private regions of `cap` 32-byte entries (one aligned sector each): {q, q (Lam_01 + kappa_0 kappa_1),
@@ -26,7 +27,7 @@ struct PairBins {
   int *gcnt;       // nb x nwg: entries each producer workgroup left in each bin (the reduce kernel zeroes them)
   double *part;    // nb x nsh reduced tiles of 3 planes x (2 rf H) slots, summed by sssc_finish_kernel
   int cap, nb, rf, nwg;  // rf folded rows per bin: the tile holds 2 rf rows x H columns; nwg producer workgroups
-  int nsh;               // reduce workgroups per bin (4: small shards, 8: from 8 M resident states on)
+  int nsh;               // reduce workgroups per bin (4: small shards, 8: from 8 M resident states on; up to 256 / nb)
 };
 __device__ __forceinline__ int pb_fold(int i, int H) { return i < H - 2 - i ? i : H - 2 - i; }
 
