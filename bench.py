@@ -116,7 +116,7 @@ def pass_kernels(cfg):
     """Kernels of the pass over all N x S resident states, as rocprofv3 names them (TAG 0 = the pass over K^n)."""
     hw = (cfg["H"] + 63) // 64
     if cfg["algo"] == "es3c":  # census lists (round 3): main kernel (|s| <= 2), quad levels 3..4 / 5..8, wavefront kernel
-        return ["void sssc_main_lpj_kernel<0, 512, %d, 2, false>" % (hw if hw in (1, 2, 4, 8, 16) else 0),
+        return ["void sssc_main_lpj_kernel<0, 512, %d, 2, false, true>" % (hw if hw in (1, 2, 4, 8, 16) else 0),
                 "void sssc_quad_kernel<1, 0, 0>", "void sssc_quad_kernel<2, 0, 0>", "void sssc_big_kernel<0, 0>"]
     return ["void bsc_lpj_gram2_kernel<0, %d>" % (hw if hw in (1, 2, 4, 8) else 16)]
 

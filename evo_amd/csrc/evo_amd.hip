@@ -183,6 +183,7 @@ struct evoamd_ctx {
                      // H x H elimination chain on the main stream finds free CU slots beside it (a persistent grid of
                      // 2 workgroups per CU otherwise holds every slot until the product is done)
   int sssc_prec32 = 0;  // option "sssc_precision" = 32: SSSC(precision=np.float32), see evoamd_set_option in the header
+  int main_unstaged = 1;  // option "lpj_main_unstaged": candidate batches on the table-driven lpj kernel without staged B rows
   int gemm_grouped = 1;  // option "gemm_grouped": grouped split-K instead of stream-K where whole chunks fill the grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
@@ -612,6 +613,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "sssc_precision") == 0) {
     if (value != 64 && value != 32) return fail(EVOAMD_E_INVALID, "sssc_precision: 64 or 32");
     c->sssc_prec32 = value == 32;
+    return 0;
+  }
+  if (strcmp(name, "lpj_main_unstaged") == 0) {
+    c->main_unstaged = value != 0;
     return 0;
   }
   if (strcmp(name, "gemm_grouped") == 0) {
@@ -1776,6 +1781,18 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
         case 8: sssc_main_lpj_kernel<TAG, 512, 8, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
         case 16: sssc_main_lpj_kernel<TAG, 512, 16, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
         default: sssc_main_lpj_kernel<TAG, 512, 0, 2><<<grid, 512, lds, c->stream>>>(a, o1, rows_cap, stage_dg); break;
+      }
+    } else if (!a.shared && (a.H % 2) == 0 && a.dig && c->main_unstaged) {
+      // the rows of the workgroup's datapoints do not fit the LDS (candidate batches: 1024 / Cmax datapoints per
+      // workgroup): the same table-driven kernel with the B values gathered from global memory
+      const size_t lds_u = (stage_dg ? (size_t)4 * a.H : 0) * sizeof(double);
+      switch (a.HW) {
+        case 1: sssc_main_lpj_kernel<TAG, 512, 1, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
+        case 2: sssc_main_lpj_kernel<TAG, 512, 2, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
+        case 4: sssc_main_lpj_kernel<TAG, 512, 4, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
+        case 8: sssc_main_lpj_kernel<TAG, 512, 8, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
+        case 16: sssc_main_lpj_kernel<TAG, 512, 16, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
+        default: sssc_main_lpj_kernel<TAG, 512, 0, 2, true, false><<<grid, 512, lds_u, c->stream>>>(a, o1, 0, stage_dg); break;
       }
     } else
       sssc_small_kernel<2, 0, TAG, 512><<<cdiv(total, 512), 512, 0, c->stream>>>(a, none, o1, PairBins{});

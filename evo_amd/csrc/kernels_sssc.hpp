@@ -674,14 +674,18 @@ __device__ __forceinline__ void append_end(const ListOut &lo, int shard, const i
 // single round with twice the loads in flight per wave.
 // APPEND = false (pass over the resident K^n with census lists, kernels_sssc_quad.hpp): states above two active latents
 // are simply left out -- the census lists name them already.
-template <int TAG, int BS, int HWT, int PPT, bool APPEND = true>
+// STAGEB = false: the B rows are gathered from global memory instead of being staged (candidate batches: a workgroup's
+// 1024 states span 1024 / Cmax datapoints, whose rows do not fit the LDS; the ~2 Cmax gathers per row hit it in the
+// caches) -- the table-driven form for them too: the K = 2 register kernel that served them evaluated 12 G states/s
+// against this kernel's 90.
+template <int TAG, int BS, int HWT, int PPT, bool APPEND = true, bool STAGEB = true>
 __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut lo, int rows_cap, int stage_dg) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double smem[];
   __shared__ int ovf_buf[BS * PPT];
   __shared__ int ovf_ctl[2];
   double *Bs = smem;
-  double4 *DGs = (double4 *)(smem + (size_t)rows_cap * a.H);
+  double4 *DGs = (double4 *)(smem + (STAGEB ? (size_t)rows_cap * a.H : 0));
   const i64 total = a.N * (i64)a.C;
   const i64 t0 = (i64)blockIdx.x * (BS * PPT);
   const i64 n_first = t0 / a.C;
@@ -729,10 +733,12 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
     yyn[p] = a.yy[live[p] ? n_first + nloc[p] : 0];
   }
   {  // stage B rows n_first .. n_last (contiguous) and the singleton table
-    const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
-    double2 *dst = (double2 *)Bs;
-    const int n2 = rows * a.H / 2;
-    for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
+    if (STAGEB) {
+      const double2 *src = (const double2 *)(a.Bm + n_first * a.H);  // H is even (host)
+      double2 *dst = (double2 *)Bs;
+      const int n2 = rows * a.H / 2;
+      for (int i = threadIdx.x; i < n2; i += BS) dst[i] = src[i];
+    }
     if (stage_dg)
       for (int i = threadIdx.x; i < a.H; i += BS) DGs[i] = a.D1[i];
   }
@@ -759,19 +765,20 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   for (int p = 0; p < PPT; p++) {
     if (live[p] && !over[p]) {
       const int k = ktot[p];
-      const double *Bn = Bs + (size_t)nloc[p] * a.H;
+      const double *Bn = Bs + (size_t)nloc[p] * a.H;                  // LDS (STAGEB)
+      const double *Bg = a.Bm + (n_first + nloc[p]) * (i64)a.H;       // global (!STAGEB)
       // identity padding makes the k = 2 expressions exact for k < 2
       double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
       double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
       if (k >= 1) {
         d0 = D1t[idx0[p]];
-        b0 = Bn[idx0[p]];
+        b0 = STAGEB ? Bn[idx0[p]] : Bg[idx0[p]];
         L = d0.y;
         l00 = d0.w;
       }
       if (k == 2) {
         d1 = D1t[idx1[p]];
-        b1 = Bn[idx1[p]];
+        b1 = STAGEB ? Bn[idx1[p]] : Bg[idx1[p]];
         g01 = pe[p].g01;
         L = pe[p].L;
         l00 = pe[p].l00;

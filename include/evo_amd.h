@@ -115,6 +115,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * 484-498): 1 / sigma2 and D log sigma2 pass through float32 and the moment sums (xpt_s, xpt_ss, xpt_sz, xpt_szsz,
  * s_sz_outer, sz_sz_outer) are float32 VALUES; every product and sum is still formed in double on the device and rounded
  * once (the reference accumulates them in float32 arrays datapoint by datapoint).
+ * "lpj_main_unstaged" (0/1, default 1): ES3C batches whose B rows do not fit the LDS of the table-driven lpj kernel (candidate
+ * batches: 1024 / Cmax datapoints per workgroup) run on that kernel with the B values gathered from global memory; 0: on the
+ * K = 2 register kernel, which eliminates a 2 x 2 system per state.
  * "gemm_grouped" (0/1, default 1): long-K contractions whose real tiles fill the resident grid with whole K chunks
  * (>= 93 % of the slots) run as a grouped split-K -- the workgroups of one K chunk, one per tile, sit in one XCD and share
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
