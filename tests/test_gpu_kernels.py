@@ -183,6 +183,42 @@ def test_lpj_sssc_dense_candidates(engine):
         _close(got[n, :counts[n]], g["lpj"][n, :counts[n]], 1e-11, "candidates of datapoint %d" % n)
 
 
+def test_lpj_candidates_unstaged_rows(engine):
+    """A candidate batch whose B rows do not fit the LDS of the table-driven lpj kernel (1024 / Cmax datapoints per
+    workgroup at H = 256: 0.5 MB): it runs on that kernel with the B values gathered from global memory (option
+    "lpj_main_unstaged", default), before on the K = 2 register kernel.  Both against the oracle, and against each other."""
+    from oracle import evo_oracle as orc
+    rng = np.random.RandomState(5)
+    N, D, H, S, C = 300, 12, 256, 4, 4
+    Y = rng.normal(size=(N, D))
+    A = rng.normal(size=(H, H)) * 0.05
+    theta = {"W": rng.normal(size=(D, H)), "pies": rng.uniform(0.05, 0.4, H), "mus": rng.normal(size=H),
+             "Psi": np.eye(H) + A @ A.T + rng.normal(size=(H, H)) * 0.01, "sigma2": np.float64(0.8)}
+    cand = np.zeros((N, C, H), dtype=bool)
+    ks = rng.randint(0, 4, size=(N, C))  # 0..3 active latents: the table path and its overflow level
+    for n in range(N):
+        for c in range(C):
+            cand[n, c, rng.choice(H, ks[n, c], replace=False)] = True
+    counts = rng.randint(1, C + 1, size=N).astype(np.int32)
+    engine.configure("sssc", N, D, H, S, 0, C)
+    engine.upload_data(Y)
+    engine.upload_states(np.zeros((N, S, H), dtype=bool))
+    engine.set_params_sssc(theta["W"], theta["pies"], theta["mus"], theta["Psi"], float(theta["sigma2"]))
+    got = {}
+    for opt in (1, 0):
+        engine.set_option("lpj_main_unstaged", opt)
+        try:
+            got[opt] = engine.lpj_candidates(cand, counts)
+        finally:
+            engine.set_option("lpj_main_unstaged", 1)
+    orc.sssc_precompute(theta, D)
+    for n in range(0, N, 37):
+        want = orc.sssc_lpj(theta, cand[n, :counts[n]], Y[n], orc.new_counters(), {})
+        _close(got[1][n, :counts[n]], want, 1e-10, "unstaged table kernel, datapoint %d" % n)
+    for n in range(N):
+        _close(got[1][n, :counts[n]], got[0][n, :counts[n]], 1e-11, "table kernel vs K = 2 register kernel")
+
+
 def test_vary_kn_kat(engine):
     g = load_golden("vary_kn.npz")
     for i in range(int(g["n_cases"])):
