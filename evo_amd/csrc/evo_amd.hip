@@ -179,7 +179,8 @@ struct evoamd_ctx {
   size_t gemm_ws_n = 0;
   int pair_bins = 1;
   int gemm_streamk = 1;  // option "gemm_streamk": long-K 128-tile contraction as one resident-sized stream-K grid
-  int sk_spare = 0;  // option "sk_spare": workgroups per XCD the FORKED stream-K contraction leaves unlaunched, so that the
+  int fork_spare = 0;  // what "sk_spare" = -1 (automatic) resolves to for the product being forked (stats_compute)
+  int sk_spare = -1;  // option "sk_spare": workgroups per XCD the FORKED stream-K contraction leaves unlaunched, so that the
                      // H x H elimination chain on the main stream finds free CU slots beside it (a persistent grid of
                      // 2 workgroups per CU otherwise holds every slot until the product is done)
   int sssc_prec32 = 0;  // option "sssc_precision" = 32: SSSC(precision=np.float32), see evoamd_set_option in the header
@@ -640,7 +641,7 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     return 0;
   }
   if (strcmp(name, "sk_spare") == 0) {
-    if (value < 0 || value > 32) return fail(EVOAMD_E_INVALID, "sk_spare: 0 .. 32 workgroups per XCD");
+    if (value < -1 || value > 32) return fail(EVOAMD_E_INVALID, "sk_spare: -1 (automatic) or 0 .. 32 workgroups per XCD");
     c->sk_spare = value;
     return 0;
   }
@@ -1230,7 +1231,7 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     }
     const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
     // forked beside the Theta-update chain (stats_compute): leave sk_spare slots per XCD to the chain's kernels
-    const int spare = (c->stream == c->stream2) ? c->sk_spare : 0;
+    const int spare = (c->stream == c->stream2) ? (c->sk_spare >= 0 ? c->sk_spare : c->fork_spare) : 0;
     const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8 - spare);
     int segmax = 0;
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, real, &segmax) : nullptr;
@@ -2347,6 +2348,16 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   nchunks = (int)cdiv(N, rows_per_chunk);
   const bool second_stream = fork_gemm || nchunks > 1;
   hipStream_t main_stream = c->stream;
+  // Forked beside the elimination chain: a resident-sized grid holds every workgroup slot until it has drained, and the
+  // grouped split-K drains all at once -- the chain (H / 32 block steps of 128 workgroups each) then runs entirely BEHIND
+  // the product (0.25 ms at the north-star shape).  Four slots per XCD left free (34 tiles x 14 chunks = 476 workgroups
+  // instead of 510) cost the product 6 % and let the chain finish well inside it.  Measured (interleaved A/B, ms per
+  // iteration): c4 3.90 -> 3.82, N / 2 2.31 -> 2.16 (8 slots: 2.22), N / 4 1.54 -> 1.45 with 4 and 1.41 with 8, N / 8
+  // 1.14 -> 1.09 with 4 and 1.065 with 8 (12 / 16: the same): 4 where the product is long against the chain, else 8.
+  {
+    const double chain_us = c->H >= 256 ? 15.0 * cdiv(c->H, 32) : 8.5 * cdiv(c->H, 16);
+    c->fork_spare = !(fork_gemm && nchunks == 1) ? 0 : (gemm_flops / 65e6 >= 3.0 * chain_us ? 4 : 8);
+  }
   int skipped = 0;
   // the whole statistics pass (everything that reads K^n + lpj and leaves the M-step sums, the GEMM aside)
   std::unique_ptr<SpanGuard> pass(new SpanGuard(c, KID_STATS_PASS));

@@ -133,8 +133,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * states with 3..4 / 5..8 / more than 8 active latents are listed by one pass over the digests per K^n (shared by the
  * statistics pass and the next pass over K^n) and served by the four-lanes-per-state kernels; 0: the round-2 chains
  * (lists appended by the main kernels, K = 4 / K = 8 register kernels, wavefront kernel).
- * "sk_spare" (0 .. 32): workgroups per XCD that the stream-K contraction does not launch while it runs on the second
- * stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free CU slots. */
+ * "sk_spare" (-1 = automatic (default), 0 .. 32): workgroups per XCD that the long-K contraction does not launch while it
+ * runs on the second stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free
+ * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8). */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */
