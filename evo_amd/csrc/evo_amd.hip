@@ -2299,7 +2299,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // ES3C H = 128 and the EBSC shapes at N <= 50k lose ~1 %: the fork / join events cost ~10 us)
   const double gemm_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H
                                                           : 2.0 * (double)c->N * c->D * c->H;
-  bool pays = c->model == EVOAMD_MODEL_SSSC && gemm_flops >= 8e9;
+  // (EBSC: from ~5e10 flops on and without a communicator -- c5 on one GPU 6.47 -> 6.24 ms per iteration with eight
+  // slots per XCD left to its 32 block steps of 256 workgroups; its accumulator is all-reduced in one piece)
+  bool pays = (c->model == EVOAMD_MODEL_SSSC && gemm_flops >= 8e9) || (c->model == EVOAMD_MODEL_BSC && !c->comm && gemm_flops >= 5e10);
   if (c->comm && c->model == EVOAMD_MODEL_SSSC) {
     // np.array_split shards differ by one row, so a shard size next to the threshold would make some ranks
     // issue three all-reduces and others one: agree once per geometry (max over ranks), same call on every rank
@@ -2356,7 +2358,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // 1.14 -> 1.09 with 4 and 1.065 with 8 (12 / 16: the same): 4 where the product is long against the chain, else 8.
   {
     const double chain_us = c->H >= 256 ? 15.0 * cdiv(c->H, 32) : 8.5 * cdiv(c->H, 16);
-    c->fork_spare = !(fork_gemm && nchunks == 1) ? 0 : (gemm_flops / 65e6 >= 3.0 * chain_us ? 4 : 8);
+    c->fork_spare = !(fork_gemm && nchunks == 1) ? 0 : ((gemm_flops / 65e6 >= 3.0 * chain_us && c->H <= 512) ? 4 : 8);
   }
   int skipped = 0;
   // the whole statistics pass (everything that reads K^n + lpj and leaves the M-step sums, the GEMM aside)
