@@ -652,6 +652,10 @@ def main():
                            "flops_note": "EXECUTED flops: 2 M N K of every product, the symmetric block of the ES3C contraction "
                                          "counted with the upper tiles it really runs (34 of 40 tiles at H = 512); "
                                          "`frac_nominal` prices all tiles",
+                           "slots_note": "the K = N contraction, forked beside the Theta-update chain, runs on 14 (30 at H = 1024) of the 15 (32) K "
+                                         "chunks per tile a full resident grid would hold (option sk_spare, automatic): the product takes ~6 % "
+                                         "longer, the chain hides inside it and the iteration is 2-6 % shorter (DESIGN 3); on all slots "
+                                         "the same kernels reach 0.87 of the peak at the north-star shape",
                            "ms_per_iteration": t_ms,
                            "achieved": fl / (t_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": fl / (t_ms * 1e-3) / 1e12 / peak,
