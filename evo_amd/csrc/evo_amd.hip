@@ -1418,7 +1418,8 @@ static int launch_gemm_tn_f32(evoamd_ctx *c, const float *A, int lda, const floa
   if (M >= 128 && Nc >= 128 && K >= 2048 && (M % 4) == 0 && (Nc % 4) == 0) {
     const int gx = (int)cdiv(Nc, GEMM_T), gy = (int)cdiv(M, GEMM_T);
     const i64 Kx = ((cdiv(K, 8) + GEMM_BK - 1) / GEMM_BK) * GEMM_BK;
-    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8);
+    const int spare = (c->stream == c->stream2) ? (c->sk_spare >= 0 ? c->sk_spare : c->fork_spare) : 0;  // see launch_gemm_tn
+    const unsigned wpx = (unsigned)std::max(1, 2 * c->n_cu / 8 - spare);
     int segmax = 0;
     double *ws = c->gemm_ws_opt ? streamk_workspace(c, wpx, (i64)gx * gy, &segmax) : nullptr;
     const i64 real = (i64)gx * gy, J = (i64)8 * wpx / real;
