@@ -185,6 +185,11 @@ struct evoamd_ctx {
                      // 2 workgroups per CU otherwise holds every slot until the product is done)
   int sssc_prec32 = 0;  // option "sssc_precision" = 32: SSSC(precision=np.float32), see evoamd_set_option in the header
   int main_unstaged = 1;  // option "lpj_main_unstaged": candidate batches on the table-driven lpj kernel without staged B rows
+  // option "lpj_singular_screen": exactly singular Psi_A above two latents the reference's way (kernels_sssc.hpp,
+  // sssc_exact_mode) -- 0 never, 1 when the tables kernel has stamped this Theta (default), 2 always
+  int sing_screen = 1;
+  int *sing_gen = nullptr;  // = err + 4: generation of the last Theta whose Psi held an exactly singular 1x1 / 2x2 block
+  int theta_gen = 0;        // stamp of the current Theta (one per sssc_tables_kernel launch)
   int gemm_grouped = 1;  // option "gemm_grouped": grouped split-K instead of stream-K where whole chunks fill the grid
   int gemm_per_xcd = 0;  // option "gemm_per_xcd" (experiments): K chunks per XCD of the 128-tile contraction, 0 = automatic
   double grid_scale = 1.0;  // share of the datapoints the launch being prepared covers (level_grid expectations)
@@ -461,13 +466,13 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
 
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_stats_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              112 * 1024));
+                              136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              112 * 1024));
+                              136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              112 * 1024));
+                              136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              112 * 1024));
+                              136 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)GEMM128_LDS_BYTES));
   HIP_TRY(hipFuncSetAttribute((const void *)gemm_tn128_rows_f64, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -618,6 +623,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "lpj_main_unstaged") == 0) {
     c->main_unstaged = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "lpj_singular_screen") == 0) {
+    if (value < 0 || value > 2) return fail(EVOAMD_E_INVALID, "lpj_singular_screen: 0 (never), 1 (automatic) or 2 (always)");
+    c->sing_screen = (int)value;
     return 0;
   }
   if (strcmp(name, "gemm_grouped") == 0) {
@@ -775,7 +785,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->census = c->acc_base;
   c->acc = c->acc_base + c->ovf_n;
   c->dpar = c->acc + c->acc_n;
-  ALLOC(c->err, 4);
+  ALLOC(c->err, 8);
+  c->sing_gen = c->err + 4;
   for (float **fp : {&c->Yf, &c->Ytf, &c->Wf, &c->Bf, &c->Esf}) {
     if (*fp) (void)hipFree(*fp);
     *fp = nullptr;
@@ -895,7 +906,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   HIP_TRY(hipMemsetAsync(c->flags, 0, (size_t)3 * N * sizeof(unsigned), c->stream));
   HIP_TRY(hipMemsetAsync(c->cand_counts, 0, (size_t)N * sizeof(int), c->stream));
   HIP_TRY(hipMemsetAsync(c->acc_base, 0, ((size_t)c->ovf_n + c->acc_n + DP_COUNT) * sizeof(double), c->stream));
-  HIP_TRY(hipMemsetAsync(c->err, 0, 4 * sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(c->err, 0, 8 * sizeof(int), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   // masks / reconstructions belong to the previous geometry (their buffers are N x D of THAT shard)
   if (c->mask_infr) (void)hipFree(c->mask_infr);
@@ -1390,7 +1401,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
   if (r) return r;
   DBG_SYNC(c, "set_params_sssc: G = W^T W");
   sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
-                                                                     c->PT, c->GP, c->DG);
+                                                                     c->PT, c->GP, c->DG, c->sing_gen, ++c->theta_gen);
   DBG_SYNC(c, "set_params_sssc: tables");
   if (c->mask_infr) {  // incomplete data: the per-datapoint Gram blocks read W^T
     if (!c->Wt) ALLOC(c->Wt, (size_t)H * D);
@@ -1583,13 +1594,16 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.col0 = b.col0;
   a.flags = b.flags;
   a.err = c->err;
+  a.sing_gen = c->sing_gen;
+  a.gen = c->theta_gen;
+  a.screen = c->sing_screen;
   a.mask = b.mask;
   a.Wt = c->Wt;
   a.D = c->D;
   return a;
 }
 
-static size_t big_lds(int kc) { return (size_t)(3 * kc * kc + 5 * kc) * sizeof(double) + (size_t)kc * sizeof(int); }
+static size_t big_lds(int kc) { return (size_t)(4 * kc * kc + 5 * kc) * sizeof(double) + (size_t)kc * sizeof(int); }
 
 // ES3C lpj of a batch: states are binned by their number of active latents on the fly.  The main
 // launch walks the pairs in natural (coalesced) order, evaluates every state with k <= 2 in
@@ -1809,7 +1823,7 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     // (3..4 latents of a chain: the K = 4 thread-per-state register kernel -- 58 us against 77 us of the quad kernel
     // on the ~400k listed candidates of the north-star shape; its lists are long enough to fill whole waves)
     if (need[0])
-      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{});
+      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{}, o3);
     DBG_SYNC(c, "sssc lpj chain 3..4");
     if (need[1]) sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, i2, o3, o3, PairBins{}, nullptr);
     DBG_SYNC(c, "sssc lpj chain 5..8");
@@ -1824,17 +1838,18 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     // candidate batch level by level
     bool merged23 = false;
     if (need[0])
-      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{});
+      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{}, o3);
     DBG_SYNC(c, "sssc lpj K=4 level");
     const ListOut none_out = {nullptr, nullptr, 0};
     if (use_k8_kernel(c, TAG)) {
       if (need[1])
-        sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3, PairBins{});
+        sssc_small_kernel<8, 0, TAG, 256><<<level_grid(c, 1, TAG, total, 256, 256), 256, 0, c->stream>>>(a, i2, o3, PairBins{}, o3);
     } else if (need[1] && few_dense_states(c, TAG)) {
       // a handful of states above 4 active latents: ONE launch of the wavefront kernel at full capacity serves list 2
       // (a launch costs ~8 us however little it does; the k <= 8 sizing only pays for thousands of states)
       sssc_big_kernel<0, TAG><<<level_grid(c, 1, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-          a, i2, none_out, SSSC_KCAP);
+          a, i2, none_out, SSSC_KCAP, i3);  // (list 3: what the K = 4 level passed on in exact mode)
+      c->pending_skip &= ~4;
       merged23 = true;
     } else if (need[1]) {
       // a few thousand states above 4 active latents: the wavefront-per-state kernel, sized for k <= 8
@@ -1842,9 +1857,12 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
       sssc_big_kernel<0, TAG><<<level_grid(c, 1, TAG, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(a, i2, o3, 8);
     }
     DBG_SYNC(c, "sssc lpj K=8 level");
-    if (need[2] && !merged23)
+    // (with the screen on, list 3 is served whenever a level ran: in exact mode the register kernels pass their states on)
+    if ((need[2] || c->sing_screen) && !merged23) {
       sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
           a, i3, none_out, SSSC_KCAP);
+      c->pending_skip &= ~4;
+    }
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "sssc lpj wavefront level");
   }
@@ -2362,6 +2380,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     c->fork_spare = !(fork_gemm && nchunks == 1) ? 0 : ((gemm_flops / 65e6 >= 3.0 * chain_us && c->H <= 512) ? 4 : 8);
   }
   int skipped = 0;
+  bool served3 = false;  // the wavefront level ran on list 3 although the census did not ask for it (exact-mode hand-over)
   // the whole statistics pass (everything that reads K^n + lpj and leaves the M-step sums, the GEMM aside)
   std::unique_ptr<SpanGuard> pass(new SpanGuard(c, KID_STATS_PASS));
   const int cols = c->model == EVOAMD_MODEL_BSC ? H : 3 * H;
@@ -2654,23 +2673,26 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         const size_t cs_lds = sc.cs ? (size_t)3 * H * sizeof(double) : 0;  // in-kernel column sums (LDS)
         bool merged23 = false;
         if (need[0])
-          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2, pb);
+          sssc_small_kernel<4, 1, 2, 256><<<level_grid(c, 0, tg, total, 1024, 256), 256, cs_lds, c->stream>>>(sc, i1, o2, pb, o3);
         // (statistics mode of the K = 8 register kernel: 256 registers + 736 bytes of scratch per lane, one wave per
         // SIMD -- measured slower than the wavefront kernel at every size seen: 187 vs ~110 us at 5k states, 0.32
         // vs 0.25 ms for the pass's levels at the north-star shape; only when forced by option "sssc_k8" = 1)
         if (c->k8_mode == 1) {
           if (need[1])
-            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3, pb);
+            sssc_small_kernel<8, 1, 2, 256><<<level_grid(c, 1, tg, total, 256, 256), 256, cs_lds, c->stream>>>(sc, i2, o3, pb, o3);
         } else if (need[1] && few_dense_states(c, tg)) {
           sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
-              sc, i2, none_out, SSSC_KCAP);  // one launch for both wavefront levels (see launch_sssc_lpj)
+              sc, i2, none_out, SSSC_KCAP, i3);  // one launch for both wavefront levels (see launch_sssc_lpj)
+          served3 = true;
           merged23 = true;
         } else if (need[1]) {
           sssc_big_kernel<1><<<level_grid(c, 1, tg, total * 256, 4096, 1), 64, big_lds(8), c->stream>>>(sc, i2, o3, 8);
         }
-        if (need[2] && !merged23)
+        if ((need[2] || c->sing_screen) && !merged23) {
           sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
               sc, i3, none_out, SSSC_KCAP);
+          served3 = true;
+        }
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats overflow levels");
       }
@@ -2681,7 +2703,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         DBG_SYNC(c, "pair bins reduce");
       }
       // a skipped level must have found its input list empty (census_lists_kernel / tail_kernel check)
-      skipped = skip_mask(need);
+      skipped = skip_mask(need) & ~(served3 ? 4 : 0);
     }
     c->grid_scale = 1.0;
     if (ci == nchunks - 1) {
@@ -2928,7 +2950,7 @@ static int refresh_after_update(evoamd_ctx *c) {
       transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->W, D, H, c->Wt);
     }
     sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,
-                                                                     c->PT, c->GP, c->DG);
+                                                                     c->PT, c->GP, c->DG, c->sing_gen, ++c->theta_gen);
     HIP_TRY(hipGetLastError());
     r = launch_B(c);
     if (r) return r;

@@ -84,6 +84,10 @@ struct SsscArgs {
   double *xss, *xszsz;    // (H,H) zero-initialised: strict UPPER triangle sums of the states with 2 active latents
   double *xss_o, *xszsz_o;  // (H,H) zero-initialised: what the overflow kernels (> 2 active latents) add, xszsz_o both triangles
   int *err;               // [0] |= 1: k > KCAP, |= 2: singular system
+  // exactly singular Psi_A for |A| >= 3 (sssc.py:278-301, see sssc_exact_mode): generation stamp the tables kernel leaves
+  // when Psi holds an exactly singular 1 x 1 / 2 x 2 principal block, the stamp of the current Theta, option value
+  const int *sing_gen;
+  int gen, screen;
   // incomplete data (sssc.py:276 W[this_x_infr, :]): reliable-entry mask rows of this batch, W^T, D
   const uint8_t *mask;    // (N, D) or nullptr
   const double *Wt;       // (H, D)
@@ -91,6 +95,17 @@ struct SsscArgs {
 };
 
 #define SSSC_KCAP 64
+
+// "Exact mode" of the levels above two active latents.  The Gram form T = I + Psi_A G_A / sigma2 stays regular when Psi_A
+// alone is exactly singular, where the reference's inv(Psi_s) raises and it goes on with pinv(Psi_s), slogdet = -inf
+// (lpj = +inf -> B_max) and Lam = inv(G_A / sigma2 + pinv(Psi_A)).  Telling the two apart takes an LU of Psi_A per state,
+// so it is only done when it can matter: option "lpj_singular_screen" = 2 (always), or 1 (default) and the tables kernel
+// has found an exactly singular 1 x 1 / 2 x 2 principal block in THIS Theta (a dead or a duplicated latent: what a
+// degenerate Psi looks like in practice).  In exact mode the register / quad kernels pass every state on to the pivoting
+// wavefront kernel, which screens Psi_A with LAPACK's elimination order and follows the reference's pinv branches.
+__device__ __forceinline__ bool sssc_exact_mode(const SsscArgs &a) {
+  return a.screen == 2 || (a.screen == 1 && a.sing_gen != nullptr && *a.sing_gen == a.gen);
+}
 
 // What np.linalg.inv raises LinAlgError on for a 2 x 2 matrix: an exactly zero pivot of the LU factorisation with
 // partial pivoting (first entry of largest magnitude in column 0; the entry below it is scaled by the RECIPROCAL of
@@ -450,8 +465,12 @@ __device__ __forceinline__ void sssc_scatter_hh(const SsscArgs &a, const int (&i
 // that profilers report the pass over K^n (0), over the candidate batch (1) and the list-driven /
 // auxiliary launches (2) under different kernel names.  BS = workgroup size.
 template <int K, int MODE, int TAG, int BS>
-__global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo, PairBins pb) {
+__global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, ListOut lo, PairBins pb,
+                                                        ListOut hard_out = ListOut{nullptr, nullptr, 0}) {
   a.s2inv = a.dpar[DP_S2INV];
+  // exact mode: this level's own states go straight to the pivoting wavefront kernel's list (sssc_exact_mode); the
+  // states above K still move down the chain, so the lists keep counting what they always count
+  const bool exact = K > 2 && hard_out.items != nullptr && sssc_exact_mode(a);
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int ovf_buf[BS];
   __shared__ int ovf_ctl[2];
@@ -506,6 +525,11 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
     }
     const bool over = live && ktot > K;
     block_append<BS>(lo, (int)(round & (LIST_SHARDS - 1)), (int)e, over, ovf_buf, ovf_ctl);
+    if (exact) {  // uniform
+      const bool hard = live && !over && ktot > 2;
+      block_append<BS>(hard_out, (int)(round & (LIST_SHARDS - 1)), (int)e, hard, ovf_buf, ovf_ctl);
+      if (hard) continue;
+    }
     if (!live || over) continue;  // no barrier below this point in the iteration
     double qn = 0.0;
     if (MODE == 1) {
@@ -1169,6 +1193,88 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
     xss[t] = xss[(i64)j * H + i];
 }
 
+// ---- exact mode of the wavefront kernel (sssc_exact_mode): one wave, k x k matrices in LDS (row-major, stride k) ----
+// LU with partial pivoting of M: true when an exactly zero pivot turns up, which is what makes np.linalg.inv raise
+// LinAlgError (dgetrf's info > 0; sssc.py:280).  dgetf2's arithmetic: the first entry of largest magnitude is the pivot
+// (idamax), the column below it is scaled by the RECIPROCAL of the pivot.  Exact for the structural cases -- zero rows,
+// equal rows, exactly dependent small-integer blocks; a matrix whose elimination leaves rounding noise is regular for
+// LAPACK and for this.  M is destroyed; fv: k doubles of scratch.
+__device__ __forceinline__ bool wave_lu_exactly_singular(double *M, double *fv, int k, int lane) {
+  for (int p = 0; p < k; p++) {
+    const double v = (lane >= p && lane < k) ? fabs(M[lane * k + p]) : -1.0;
+    const double m = wave_max(v);
+    if (m == 0.0) return true;     // uniform
+    if (!(m > 0.0)) return false;  // NaN: inv does not raise, the values stay NaN
+    const int piv = __ffsll((long long)__ballot(v == m)) - 1;
+    if (piv != p && lane < k) {
+      const double t1 = M[p * k + lane];
+      M[p * k + lane] = M[piv * k + lane];
+      M[piv * k + lane] = t1;
+    }
+    lds_barrier();
+    const double r = __ddiv_rn(1.0, M[p * k + p]);
+    if (lane > p && lane < k) fv[lane] = M[lane * k + p] * r;
+    lds_barrier();
+    const int mm = k - p - 1;
+    for (int q = lane; q < mm * mm; q += 64) {
+      const int i = p + 1 + q / mm, j = p + 1 + q % mm;
+      M[i * k + j] = fma(-fv[i], M[p * k + j], M[i * k + j]);
+    }
+    lds_barrier();
+  }
+  return false;
+}
+
+// out = pinv(A) the way np.linalg.pinv defines it (SVD, singular values up to rcond = 1e-15 of the largest dropped;
+// sssc.py:281/300), by one-sided Jacobi: the columns of A are rotated until they are mutually orthogonal, V collects the
+// rotations, so A_in = A_out V^T with A_out's columns = sigma_j u_j and pinv = sum_j v_j a_j^T / sigma_j^2.  Lane i owns
+// row i of A and of V (no barrier inside the sweeps).  A and V are destroyed; out may not alias them.
+__device__ __forceinline__ void wave_pinv(double *A, double *V, double *out, int k, int lane) {
+  const bool mine = lane < k;
+  if (mine)
+    for (int j = 0; j < k; j++) V[lane * k + j] = (j == lane) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p + 1 < k; p++)
+      for (int q = p + 1; q < k; q++) {
+        const double ap = mine ? A[lane * k + p] : 0.0, aq = mine ? A[lane * k + q] : 0.0;
+        const double alpha = wave_sum(ap * ap), beta = wave_sum(aq * aq), gamma = wave_sum(ap * aq);
+        if (!(fabs(gamma) > 1e-16 * sqrt(alpha * beta))) continue;  // uniform
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+        if (mine) {
+          A[lane * k + p] = cs * ap - sn * aq;
+          A[lane * k + q] = sn * ap + cs * aq;
+          const double vp = V[lane * k + p], vq = V[lane * k + q];
+          V[lane * k + p] = cs * vp - sn * vq;
+          V[lane * k + q] = sn * vp + cs * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double smax2 = 0.0;
+  for (int j = 0; j < k; j++) {
+    const double a = mine ? A[lane * k + j] : 0.0;
+    smax2 = fmax(smax2, wave_sum(a * a));
+  }
+  for (int j = 0; j < k; j++) {  // a_j / sigma_j^2, or nothing for a dropped singular value
+    const double a = mine ? A[lane * k + j] : 0.0;
+    const double s2 = wave_sum(a * a);
+    const bool keep = sqrt(s2) > 1e-15 * sqrt(smax2);
+    if (mine) A[lane * k + j] = keep ? a / s2 : 0.0;
+  }
+  lds_barrier();
+  if (mine)
+    for (int l = 0; l < k; l++) {
+      double acc = 0.0;
+      for (int j = 0; j < k; j++) acc = fma(V[lane * k + j], A[l * k + j], acc);
+      out[lane * k + l] = acc;
+    }
+  lds_barrier();
+}
+
 // One wavefront (64-thread workgroup) per listed pair, the k x k system in LDS, lanes over matrix
 // elements.  `kc` is the largest k this launch holds (LDS = 3 kc^2 + 5 kc doubles: 1.9 KiB at
 // kc = 8, 98 KiB at kc = 64); pairs above kc go to `lo` (or raise EVOAMD_E_KLIMIT when there is no
@@ -1194,8 +1300,10 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
   double *vv = muv + kc;
   double *wv = vv + kc;
   double *fv = wv + kc;
-  int *idx = (int *)(fv + kc);
+  double *Vm = fv + kc;  // exact mode only: the rotations of wave_pinv
+  int *idx = (int *)(Vm + kc * kc);
   const int lane = threadIdx.x;
+  const bool exact = sssc_exact_mode(a);
   const i64 total1 = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
   const i64 total = total1 + (li2.items ? (i64)list_prefix(li2, prefix2) : 0);
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
@@ -1290,21 +1398,69 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     }
     const double rr = a.yy[n] - wave_sum(rr_part);
     lds_barrier();
-    if (lane < k) {
-      double s = 0.0;
-      for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
-      wv[lane] = s;
+    bool psing = false;
+    if (exact && k > 0) {  // is Psi_A exactly singular (np.linalg.inv raises, sssc.py:280)?
+      for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
+      lds_barrier();
+      psing = wave_lu_exactly_singular(Tm, fv, k, lane);
+      lds_barrier();
     }
-    for (int q = lane; q < k * k; q += 64) {
-      const int i = q / k, j = q - i * k;
-      double tt = 0.0;
-      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
-      Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+    bool solved = false;
+    if (psing) {
+      // the reference goes on with pinv(Psi_A) and slogdet(Psi_A) = -inf: C_det = -inf, lpj = +inf, which lpj_reset_check
+      // turns into B_max (sssc.py:281-305, _models.py:589); its statistics read Lam = inv(M_A), M_A = G_A / sigma2 +
+      // pinv(Psi_A) -- pinv(M_A) when that is exactly singular too (sssc.py:296-300) -- and kappa = mu + Lam v / sigma2
+      if (MODE == 0) {
+        if (lane == 0) {
+          unsigned fl = 0;
+          a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(__builtin_inf(), fl);
+          atomicOr(&a.flags[n], fl);
+          atomicOr(&a.err[1], 1);
+        }
+        continue;  // uniform
+      }
+      for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
+      lds_barrier();
+      wave_pinv(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
+      for (int q = lane; q < k * k; q += 64) {
+        const double mq = a.s2inv * Gm[q] + Pm[q];
+        Gm[q] = mq;  // M_A (G_A is not read again)
+        Tm[q] = mq;
+      }
+      lds_barrier();
+      const bool msing = wave_lu_exactly_singular(Tm, fv, k, lane);
+      lds_barrier();
+      for (int q = lane; q < k * k; q += 64) Tm[q] = Gm[q];
+      lds_barrier();
+      if (msing) {
+        wave_pinv(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
+        if (lane < k) {
+          double s = 0.0;
+          for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+          wv[lane] = s;
+        }
+        solved = true;
+      } else {  // the elimination below with M_A in the place of T and the identity in the place of Psi_A: Pm = inv(M_A)
+        for (int q = lane; q < k * k; q += 64) Pm[q] = (q / k == q % k) ? 1.0 : 0.0;
+        if (lane < k) wv[lane] = vv[lane];
+      }
+    } else {
+      if (lane < k) {
+        double s = 0.0;
+        for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+        wv[lane] = s;
+      }
+      for (int q = lane; q < k * k; q += 64) {
+        const int i = q / k, j = q - i * k;
+        double tt = 0.0;
+        for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
+        Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+      }
     }
     lds_barrier();
     // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
     bool singular = false;
-    for (int p = 0; p < k; p++) {
+    for (int p = 0; p < (solved ? 0 : k); p++) {
       // pivot: |column p| with 63 - row in the low 6 mantissa bits, one DPP max-reduce
       double key = -1.0;
       if (lane >= p && lane < k) {
@@ -1354,7 +1510,7 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
     const double logdet = wave_sum(ld);
     // ---- back substitution, column oriented
-    for (int p = k - 1; p >= 0; p--) {
+    for (int p = (solved ? 0 : k) - 1; p >= 0; p--) {
       const double r = fast_rcp(Tm[p * k + p]);
       if (lane == 0) wv[p] *= r;
       if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
@@ -1467,7 +1623,10 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
                                                           const double *__restrict__ pil_bar,
                                                           const double *__restrict__ dpar, int H,
                                                           double4 *__restrict__ D1, PairEntry *__restrict__ PT,
-                                                          double2 *__restrict__ GP, double4 *__restrict__ DG) {
+                                                          double2 *__restrict__ GP, double4 *__restrict__ DG,
+                                                          int *__restrict__ sing_gen, int gen) {
+  // sing_gen / gen: an exactly singular 1 x 1 or 2 x 2 principal block of Psi stamps this Theta's generation
+  // (sssc_exact_mode: the levels above two latents then screen every Psi_A)
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int h0 = (int)(t / H), h1 = (int)(t - (i64)h0 * H);
@@ -1485,6 +1644,7 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
       // (pinv of that where G_hh = 0 as well)
       d.y = __builtin_inf();
       d.w = (s * g != 0.0) ? 1.0 / (s * g) : 0.0;
+      atomicMax(sing_gen, gen);
     }
     D1[h0] = d;
     return;
@@ -1512,6 +1672,7 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
     // too) -- NOT the continuous limit T^-1 Psi_A of the lines above (sssc.py:278-301).  L = +inf with a FINITE Lam.
     pair_lam_singular_psi(s, G00, G01, G10, G11, P00, P01, P10, P11, e.l00, e.l01, e.l10, e.l11);
     e.L = __builtin_inf();
+    atomicMax(sing_gen, gen);
   }
   PT[t] = e;
 }

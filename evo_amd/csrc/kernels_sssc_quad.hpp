@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
     SsscArgs a, ListIn li, ListOut lo, ListOut hard_out, PairBins pb, OvfRec *__restrict__ rec) {
   constexpr int K = 4 * C;
   a.s2inv = a.dpar[DP_S2INV];
+  const bool exact = sssc_exact_mode(a);  // every state on to the pivoting kernel, which screens Psi_A (kernels_sssc.hpp)
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int idx_sh[4][16][K];
   __shared__ int bcnt[MODE == 1 ? PB_MAX_BINS : 1];
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
       const i64 nn = (i64)(eu / (unsigned)a.C);
       quad_solve<C, MODE>(a, t, ks, idx, cidx, a.Bm + nn * H, a.yy[nn], val, hard, kap_all, Lam);
     }
-    hard = hard && ks > 0;  // (a state with k = 0 never reaches a list; ks == 0 <=> idle quad)
+    hard = (hard || exact) && ks > 0;  // (a state with k = 0 never reaches a list; ks == 0 <=> idle quad)
     const int e_mine = (MODE == 0) ? stage_l[wave].e[q] : stage[MODE == 1 ? wave : 0].e[q];
     {  // states that need row exchanges: the pivoting wavefront kernel's list
       const u64 hm = __ballot(hard && t == 0);

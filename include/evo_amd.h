@@ -118,6 +118,15 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "lpj_main_unstaged" (0/1, default 1): ES3C batches whose B rows do not fit the LDS of the table-driven lpj kernel (candidate
  * batches: 1024 / Cmax datapoints per workgroup) run on that kernel with the B values gathered from global memory; 0: on the
  * K = 2 register kernel, which eliminates a 2 x 2 system per state.
+ * "lpj_singular_screen" (0 / 1 / 2, default 1): ES3C states with three or more active latents whose Psi_A is exactly
+ * singular, the reference's way (evo/models/sssc.py:278-301: pinv(Psi_s), slogdet = -inf, lpj = +inf -> B_max, Lam =
+ * inv(G_A / sigma2 + pinv(Psi_A)), pinv of that if it is exactly singular too).  The Gram form of the kernels stays regular
+ * there (it returns the continuous limit), so telling the cases apart takes an LU of Psi_A per state: in "exact mode" the
+ * register / quad kernels pass every such state on to the pivoting wavefront kernel, which screens Psi_A in LAPACK's
+ * elimination order and follows the pinv branches (one-sided Jacobi).  1: exact mode for a Theta in which the tables kernel
+ * has found an exactly singular 1 x 1 or 2 x 2 principal block of Psi (a dead or a duplicated latent); 2: always (slow:
+ * every state above two latents on the wavefront kernel); 0: never.  States with at most two active latents always follow
+ * the reference (state-term tables).
  * "gemm_grouped" (0/1, default 1): long-K contractions whose real tiles fill the resident grid with whole K chunks
  * (>= 93 % of the slots) run as a grouped split-K -- the workgroups of one K chunk, one per tile, sit in one XCD and share
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.

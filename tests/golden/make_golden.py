@@ -298,6 +298,65 @@ def make_lpj_fixtures():
     np.savez_compressed(os.path.join(HERE, "lpj_clamp.npz"), **res)
 
 
+def make_lpj_singular_k3():
+    """SSSC states with THREE OR MORE active latents whose Psi_A is exactly singular (sssc.py:278-301), round 3: equal
+    rows / columns, zero variances, a rank-2 3 x 3 block whose 2 x 2 minors are all regular, and one set whose
+    M_A = G_A / sigma2 + pinv(Psi_A) is exactly singular as well (Psi_A = 0 and two equal columns of W: pinv(M_A))."""
+    rng = np.random.RandomState(77)
+    D, H = 16, 16
+    model = SSSC(D, H, 24, use_storage=True)
+    theta = learned_like_sssc_theta(D, H, rng)
+    Psi, W = theta["Psi"], theta["W"]
+    Psi[5, :] = Psi[2, :]                     # latent 5 a copy of latent 2 (row, then column: Psi[5,5] = Psi[2,2])
+    Psi[:, 5] = Psi[:, 2]
+    for h in (7, 9, 10):                      # zero variance, uncorrelated with everything
+        Psi[h, :] = 0.0
+        Psi[:, h] = 0.0
+    W[:, 9] = W[:, 7]                         # G_A of a set holding 7 and 9 has two equal rows / columns
+    blk = (0, 1, 3)                           # V V^T, V = [[1,0],[0,1],[1,1]]: rank 2, every 2 x 2 minor equals 1
+    for h in blk:
+        Psi[h, :] = 0.0
+        Psi[:, h] = 0.0
+    Psi[np.ix_(blk, blk)] = np.array([[1.0, 0.0, 1.0], [0.0, 1.0, 1.0], [1.0, 1.0, 2.0]])
+    sets = [(2, 5, 12), (1, 4, 7), (0, 1, 3), (0, 1, 3, 6), (7, 9, 10), (4, 6, 8), (4, 8, 12, 13), (4, 6, 8, 11, 13),
+            (4, 6, 8, 10, 12, 14), (0, 1, 3, 4, 6, 8, 12, 13, 2), (4, 6, 8, 11, 12, 13, 14, 15, 2), (0, 1), (1, 3), (2, 5),
+            (7,), (4,), (), (6, 11, 14), (2, 4, 6, 8, 11, 12, 13, 14, 15, 1), (0, 3, 4), (5, 11, 15), (7, 9),
+            (2, 6, 11, 12, 13, 14, 15), (7, 9, 11, 12)]
+    states = np.zeros((len(sets), H), dtype=bool)
+    for c, on in enumerate(sets):
+        states[c, list(on)] = True
+    KM = max(len(on) for on in sets)
+    N = 3
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    suff = {}
+    model.E_step_precompute(theta, suff, my_data)
+    lpj = np.zeros((N, len(sets)))
+    lam = np.zeros((len(sets), KM, KM))
+    kappa = np.zeros((N, len(sets), KM))
+    cnt = np.zeros((N, 3), dtype=np.int64)
+    for n in range(N):
+        my_data["this_y"] = Y[n]
+        my_data["this_x_infr"] = my_data["x_infr"][n]
+        suff["this_states"] = states
+        for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"):
+            suff[key] = 0
+        with np.errstate(all="ignore"):
+            lpj[n] = model.log_pseudo_joint(theta, suff, my_data)
+        cnt[n] = [suff["reset_lpj_isnan"], suff["reset_lpj_smaller_eps_lpj"], suff["reset_lpj_isinf"]]
+        for c, on in enumerate(sets):            # what the statistics loop reads from `storage` (sssc.py:566-575)
+            if not on:
+                continue
+            ent = suff["storage"][str((model.s_ids * states[c]).sum())]
+            k = len(on)
+            lam[c, :k, :k] = ent["lambda_s"]
+            kappa[n, c, :k] = np.dot(ent["lambda_s_W_s_sigma2_inv"], Y[n] - ent["W_s_mus_s"]) + theta["mus"][states[c]]
+    print("singular k>=3 fixture: %d of %d states at B_max, Psi_s_pinv = %d" % ((lpj[0] == 0.0).sum(), len(sets), suff["Psi_s_pinv"]))
+    np.savez_compressed(os.path.join(HERE, "lpj_sssc_singular_k3.npz"), H=np.int64(H), states=pack(states), Y=Y, lpj=lpj,
+                        lam=lam, kappa=kappa, reset_counts=cnt, psi_s_pinv=np.int64(suff["Psi_s_pinv"]),
+                        ljc=np.float64(theta["ljc"]), **theta_arrays("", theta, SSSC_KEYS))
+
+
 def make_vary_kn():
     out = {}
     cases = []
@@ -580,6 +639,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lpj":  # the direct-operator fixtures only (lpj_*.npz)
         make_lpj_fixtures()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lpj_k3":  # exactly singular Psi_A with three or more active latents (round 3)
+        make_lpj_singular_k3()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prec32":  # SSSC(precision=np.float32) (sssc.py:49), added in round 3
         make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
         sys.exit(0)
@@ -607,6 +669,7 @@ if __name__ == "__main__":
     make_step_fixture("ebsc_perm", "ebsc", 20, 24, 12, 30, seed=71, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
+    make_lpj_singular_k3()
     for nm in sorted(SHAPES):
         a, D, H, S, N, seed, ea = SHAPES[nm][:7]
         make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=(SHAPES[nm][7] if len(SHAPES[nm]) > 7 else 2), ea=ea)

@@ -80,15 +80,29 @@ def test_lpj_sssc_kat(engine):
     _close(out, g["lpj"][1], 1e-11, "single")
 
 
-def test_lpj_sssc_singular_psi(engine):
-    """States with at most two active latents whose Psi_A is EXACTLY singular (np.linalg.inv raises: a zero variance, two
-    equal rows, rows in a power-of-two ratio): the reference goes on with pinv(Psi_A) and slogdet = -inf, i.e. lpj = +inf
+@pytest.mark.parametrize("fixture,n_sing,census", [("lpj_sssc_singular.npz", 7, 1), ("lpj_sssc_singular_k3.npz", 11, 1),
+                                                   ("lpj_sssc_singular_k3.npz", 11, 0)])
+def test_lpj_sssc_singular_psi(engine, fixture, n_sing, census):
+    """States whose Psi_A is EXACTLY singular (np.linalg.inv raises: a zero variance, two equal rows, rows in a
+    power-of-two ratio, a rank-2 3 x 3 block): the reference goes on with pinv(Psi_A) and slogdet = -inf, i.e. lpj = +inf
     -> B_max with the isinf counter, and its statistics use Lam = inv(G_A / sigma2 + pinv(Psi_A)) (sssc.py:278-301).
-    lpj_sssc_singular.npz holds the reference's lpj, lambda_s and kappa_s.  Served by the state-term tables (resident
-    pass, per-datapoint operator) and by the K = 2 register path (shared sets); the statistics against the oracle's
-    restatement of the reference loop on the same K^n."""
+    The fixtures hold the reference's lpj, lambda_s and kappa_s.  At most two active latents (`lpj_sssc_singular`): served
+    by the state-term tables (resident pass, per-datapoint operator) and by the K = 2 register path (shared sets).  Three
+    to ten (`_k3`, with one M_A that is exactly singular as well): the levels pass every state on to the pivoting
+    wavefront kernel, which screens Psi_A with LAPACK's elimination and takes the pinv branches (option
+    "lpj_singular_screen", on by itself here because the tables kernel has seen a dead / a duplicated latent); census = 0:
+    the same through the level chains of the register kernels instead of the census lists + quad kernels.
+    The statistics against the oracle's restatement of the reference loop on the same K^n."""
     from oracle import evo_oracle as orc
-    g = load_golden("lpj_sssc_singular.npz")
+    g = load_golden(fixture)
+    engine.set_option("census_lists", census)
+    try:
+        _singular_psi_body(engine, orc, g, fixture, n_sing)
+    finally:
+        engine.set_option("census_lists", 1)
+
+
+def _singular_psi_body(engine, orc, g, fixture, n_sing):
     H = int(g["H"])
     states = unpack_bits(g["states"], H)
     C = states.shape[0]
@@ -103,7 +117,7 @@ def test_lpj_sssc_singular_psi(engine):
     engine.lpj_resident()
     got = engine.download_lpj()
     sing = g["lpj"][0] == 0.0
-    assert sing.sum() == 7
+    assert sing.sum() == n_sing
     assert (got[:, sing] == 0.0).all()  # B_max exactly
     _close(got[:, ~sing], g["lpj"][:, ~sing], 1e-11, "regular states beside singular ones")
     shared = engine.lpj_shared(states)  # K = 2 register path (no tables)
@@ -123,6 +137,23 @@ def test_lpj_sssc_singular_psi(engine):
         ref = want[name]
         assert np.abs(v[name] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), name
     assert int(v["reset_isinf"]) >= 1  # the +inf values were counted (_models.py:589-590)
+    if "k3" in fixture:
+        # the screen off: the Gram form's continuous limit (finite values) for the singular states above two latents
+        big = sing & (states.sum(axis=1) > 2)
+        engine.set_option("lpj_singular_screen", 0)
+        try:
+            engine.lpj_resident()
+            off = engine.download_lpj()
+        finally:
+            engine.set_option("lpj_singular_screen", 1)
+        assert (off[:, big] != 0.0).all() and np.isfinite(off).all()
+        _close(off[:, ~big], got[:, ~big], 1e-13, "states the screen does not concern")
+        engine.set_option("lpj_singular_screen", 2)  # always on: same values
+        try:
+            engine.lpj_resident()
+            _close(engine.download_lpj(), got, 0.0, "screen forced")
+        finally:
+            engine.set_option("lpj_singular_screen", 1)
 
 
 def test_reconfigure_after_masks_drops_them(engine):

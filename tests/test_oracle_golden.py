@@ -214,16 +214,18 @@ def test_lpj_sssc():
     np.testing.assert_allclose(theta["ljc"], float(g["ljc"]), rtol=1e-15)
 
 
-def test_lpj_sssc_singular_psi():
+@pytest.mark.parametrize("fixture,n_sing", [("lpj_sssc_singular.npz", 7), ("lpj_sssc_singular_k3.npz", 11)])
+def test_lpj_sssc_singular_psi(fixture, n_sing):
     """Exactly singular Psi_s (sssc.py:278-301): pinv branches, lpj = +inf -> B_max with the isinf counter, and the
-    lambda_s / kappa_s the reference's statistics loop reads from its storage -- all from the reference itself."""
-    g = load_golden("lpj_sssc_singular.npz")
+    lambda_s / kappa_s the reference's statistics loop reads from its storage -- all from the reference itself
+    (states with at most two active latents; `_k3`: three to ten, and one M_s that is exactly singular as well)."""
+    g = load_golden(fixture)
     H = int(g["H"])
     theta = {k: g[k] for k in SSSC_KEYS}
     theta["sigma2"] = np.float64(theta["sigma2"])
     states = unpack_bits(g["states"], H)
     Y = g["Y"]
-    assert int((g["lpj"][0] == 0.0).sum()) == 7  # seven of the twenty states hold an exactly singular Psi_s
+    assert int((g["lpj"][0] == 0.0).sum()) == n_sing  # states that hold an exactly singular Psi_s
     for n in range(Y.shape[0]):
         cnt = orc.sssc_precompute(theta, Y.shape[1])
         cache = {}
