@@ -156,6 +156,42 @@ def _singular_psi_body(engine, orc, g, fixture, n_sing):
             engine.set_option("lpj_singular_screen", 1)
 
 
+def test_lpj_sssc_singular_psi_incomplete_data(engine):
+    """The same exactly singular Psi_A with incomplete data (sssc.py:276: W[this_x_infr, :] -- the Gram block belongs to the
+    datapoint, every state runs on the wavefront kernel): B_max exactly for the singular states whatever their number of
+    latents, the others against the oracle's masked lpj (pinned by step_*_missing.npz)."""
+    from oracle import evo_oracle as orc
+    g = load_golden("lpj_sssc_singular_k3.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    theta = {k: np.array(g[k]) for k in ("W", "pies", "mus", "Psi")}
+    theta["sigma2"] = np.float64(g["sigma2"])
+    mask = np.random.RandomState(5).random_sample((N, D)) < 0.7
+    mask[:, :4] = True
+    engine.configure("sssc", N, D, H, C, 0, 8)
+    try:
+        engine.upload_data(Y)
+        engine.upload_masks(mask)
+        engine.upload_states(np.tile(states[None], (N, 1, 1)))
+        engine.set_params_sssc(theta["W"], theta["pies"], theta["mus"], theta["Psi"], float(theta["sigma2"]))
+        engine.lpj_resident()
+        got = engine.download_lpj()
+    finally:
+        engine.configure("sssc", 1, D, H, C, 0, 8)  # drops the masks for the tests that follow on this engine
+    sing = g["lpj"][0] == 0.0
+    want = np.zeros((N, C))
+    for n in range(N):
+        th = dict(theta)
+        cnt = orc.sssc_precompute(th, D, mask)
+        with np.errstate(all="ignore"):
+            want[n] = orc.sssc_lpj(th, states, Y[n], cnt, {}, obs=mask[n])
+    assert (want[:, sing] == 0.0).all() and (got[:, sing] == 0.0).all()
+    _close(got[:, ~sing], want[:, ~sing], 1e-11, "regular states, incomplete data")
+
+
 def test_reconfigure_after_masks_drops_them(engine):
     """Round-2 abort (gpurun_out/r2_tests1.txt: `Fatal Python error: Aborted` at the first synchronisation after the lpj
     pass of a shape test that followed the missing-data tests on the shared engine): evoamd_configure kept mask_infr /
