@@ -263,7 +263,9 @@ __device__ __forceinline__ void quad_solve(const SsscArgs &a, const int t, const
       vq = fma(-fv, rp, vq);
     }
 #pragma unroll
-    for (int r = 0; r < K; r++) {
+    for (int r = (MODE == 0 ? p + 1 : 0); r < K; r++) {
+      // (lpj: the determinant and the bordered row's Schur complement are complete after the FORWARD elimination -- the
+      // rows above the pivot are never read again; the statistics need Lam_A = T^-1 Psi_A, i.e. Gauss-Jordan)
       if (r == p) continue;
       const double f = qb_sel(Tc[r][jj], owner);  // multiplier of row r (the pivot row is scaled to T[p][p] = 1)
 #pragma unroll
