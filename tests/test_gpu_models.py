@@ -518,6 +518,72 @@ def test_es3c_tile_aligned_shapes_against_oracle(engine, D, H, S, N, device_mste
                                        err_msg="%s step %d" % (k, t))
 
 
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_es3c_step_with_duplicated_latent_against_oracle(engine, device_mstep):
+    """Full EM steps from a Theta whose Psi holds a duplicated latent (5 a copy of 2: exactly singular Psi_A for every
+    state that holds both, sssc.py:278-301) on a K^n dense enough that such states carry three to nine latents: candidates (level chains), selection, statistics and the Theta update all run in the kernels' exact mode
+    (lpj_singular_screen) during the first step; the second step starts from the generic Psi the update produced.
+    Oracle = oracle.evo_oracle.sssc_step, whose pinv branches are pinned by lpj_sssc_singular*.npz."""
+    from oracle import evo_oracle as orc
+    from evo_amd.models import SSSC
+    from evo_amd.variational import init_states
+    D, H, S, N = 20, 16, 24, 60
+    rng = np.random.RandomState(12)
+    gen = {"W": rng.normal(size=(D, H)), "pies": np.full(H, 3.0 / H), "mus": rng.normal(size=H) + 1.0,
+           "Psi": np.eye(H), "sigma2": np.float64(0.5)}
+    np.random.seed(5)
+    Y = orc.sssc_generate(gen, N)[0]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    np.random.seed(6)
+    theta0 = orc.sssc_standard_init(Y, H)
+    A = rng.normal(size=(H, H)) * 0.2
+    Psi = np.eye(H) + A @ A.T + rng.normal(size=(H, H)) * 0.02  # dense, not symmetric (SURVEY Q2)
+    for h in (2, 5):  # latent 5 a copy of latent 2, both decoupled from the rest and with unit variance: the block
+        Psi[h, :] = 0.0   # [[1, 1], [1, 1]] makes the elimination's zero pivot exact whatever else a state holds (a copy
+        Psi[:, h] = 0.0   # with generic entries is singular for LAPACK only where pivot * fl(1 / pivot) happens to be 1)
+    Psi[np.ix_((2, 5), (2, 5))] = 1.0
+    theta0["Psi"] = Psi
+    np.random.seed(7)
+    suff_a = init_states(N, S, H, "fit", "randflip", 6, 2, 1, p_init_Kn=4.0 / H)
+    np.random.seed(7)
+    suff_o = orc.init_states(N, S, H, "fit", "randflip", 6, 2, 1, p_init_Kn=4.0 / H)
+    assert np.array_equal(suff_a["ss"], suff_o["ss"])
+    both = suff_o["ss"][:, :, 2] & suff_o["ss"][:, :, 5]
+    assert (both & (suff_o["ss"].sum(axis=2) >= 3)).sum() >= 20  # singular states above two latents are in K^n
+    model = SSSC(D, H, S, engine=engine, device_mstep=device_mstep)
+    th_a = {k: np.array(v) for k, v in theta0.items()}
+    th_o = {k: np.array(v) for k, v in theta0.items()}
+    th_a["sigma2"], th_o["sigma2"] = np.float64(th_a["sigma2"]), np.float64(th_o["sigma2"])
+    np.random.seed(100)
+    Fa, nua, nsa, th_a = model.step(th_a, suff_a, my_data)
+    np.random.seed(100)
+    with np.errstate(all="ignore"):
+        Fo, nuo, nso, th_o, _ = orc.sssc_step(th_o, suff_o, Y)
+    # the singular states of a datapoint all sit at B_max = 0.0: WHICH of them a tie keeps is NumPy's unspecified
+    # partition order in the reference and the lowest index here (DESIGN 4, vary_Kn tie rule) -- F, the counters and the
+    # sorted lpj rows do not depend on it
+    np.testing.assert_allclose(Fa, Fo, rtol=1e-9, err_msg="F")
+    assert (nua, nsa) == (nuo, nso)
+    assert (suff_o["lpj"] == 0.0).sum() >= 20  # B_max entries: singular states were selected
+    np.testing.assert_allclose(np.sort(suff_a["lpj"], axis=1), np.sort(suff_o["lpj"], axis=1), rtol=1e-9, atol=1e-9)
+    assert suff_a["reset_lpj_isinf"] > 0  # counted like lpj_reset_check does (_models.py:589-590)
+    # statistics + Theta update of the K^n the GPU kept, against the oracle's loop on that same K^n
+    th_c = orc.check_params({k: np.array(v) for k, v in theta0.items()}, orc.SSSC_POLICY)
+    th_c["sigma2"] = np.float64(th_c["sigma2"])
+    suff_c = {"ss": suff_a["ss"].copy(), "lpj": np.empty((N, S)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool),
+              "Mprime": suff_a["Mprime"]}
+    with np.errstate(all="ignore"):
+        acc = orc.sssc_EM_accumulate(th_c, suff_c, Y, use_storage=False, evolve=False)
+        th_ref = orc.sssc_update(th_c, acc, N, D, H, ("W", "pies", "mus", "sigma2", "Psi"))
+    for k in ("W", "pies", "mus", "Psi", "sigma2"):
+        ref = np.asarray(th_ref[k])
+        np.testing.assert_allclose(th_a[k], ref, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    # and the next step runs from the generic Psi that update produced
+    np.random.seed(101)
+    F2, _, _, th_a = model.step(th_a, suff_a, my_data)
+    assert np.isfinite(F2) and all(np.isfinite(np.asarray(th_a[k])).all() for k in ("W", "pies", "mus", "Psi", "sigma2"))
+
+
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 @pytest.mark.parametrize("device_mstep", [False, True])
 def test_reconstruction_against_reference(engine, algo, device_mstep):
