@@ -1026,13 +1026,33 @@ __global__ __launch_bounds__(64) void gjs32_first_kernel(GjMats m, int n, double
   const double *__restrict__ A = m.a[mat];
   double *__restrict__ d0 = d0_all + (size_t)mat * n;
   double *__restrict__ Pinv = Pinv_all + (size_t)mat * 2 * GJS32 * GJS32;
-  for (int k = l; k < n; k += 64) d0[k] = A[(size_t)k * n + k];
-  for (int e = l; e < GJS32 * GJS32; e += 64) {  // identity padding beyond the matrix
-    const int r = e >> 5, cc = e & 31;
-    Mb[r][cc] = (r < n && cc < n) ? A[(size_t)r * n + cc] : ((r == cc) ? 1.0 : 0.0);
+  // every load of this kernel in ONE round trip (the diagonal loop used to wait for each of its n / 64 strided loads in
+  // turn: beside the forked contraction, whose traffic stretches a round trip to several us, the kernel took 77 us)
+  constexpr int DV = 16;  // n <= 1024 from registers
+  double dv[DV], mv[GJS32 * GJS32 / 64];
+#pragma unroll
+  for (int j = 0; j < DV; j++) {
+    const int k = l + 64 * j;
+    dv[j] = (k < n) ? A[(size_t)k * n + k] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < GJS32 * GJS32 / 64; j++) {  // identity padding beyond the matrix
+    const int e = l + 64 * j, r = e >> 5, cc = e & 31;
+    mv[j] = (r < n && cc < n) ? A[(size_t)r * n + cc] : ((r == cc) ? 1.0 : 0.0);
   }
   const double dA = (i < n) ? A[(size_t)i * n + i] : 1.0;
   const double dB = (16 + i < n) ? A[(size_t)(16 + i) * n + 16 + i] : 1.0;
+#pragma unroll
+  for (int j = 0; j < DV; j++) {
+    const int k = l + 64 * j;
+    if (k < n) d0[k] = dv[j];
+  }
+  for (int k = l + 64 * DV; k < n; k += 64) d0[k] = A[(size_t)k * n + k];
+#pragma unroll
+  for (int j = 0; j < GJS32 * GJS32 / 64; j++) {
+    const int e = l + 64 * j;
+    Mb[e >> 5][e & 31] = mv[j];
+  }
   lds_wave_fence();
   const bool ok = inv32_wave(Mb, T, dA, dB, Pinv);
   if (!ok && l == 0) status[0] = 3.0;
