@@ -134,6 +134,11 @@ def stats_kernels(cfg):
     return ["void bsc_stats_kernel<%d>" % hwt, "colsum_partial_kernel", "bsc_finish_kernel"]
 
 
+def traffic_key(args):
+    """profiles/rNN_<key>_pmc_traffic.json: the counters belong to a workload, i.e. config + state variant."""
+    return args.config + ("dense" if args.dense_states else "")
+
+
 def pmc_traffic(config, kernels):
     """HBM bytes per pass = sum over `kernels` of (bytes per launch x launches per pass) from the committed
     rocprofv3 counter passes (profiles/r02_<config>_pmc_traffic.json, written by tools/profile_bench.sh: separate
@@ -141,7 +146,7 @@ def pmc_traffic(config, kernels):
     one launch of the first kernel of the list; the conditional overflow levels count with their own launch
     frequency.  None if the file is absent."""
     d = None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (rnd, config))
         try:
             with open(path) as f:
@@ -177,6 +182,14 @@ def layout_bytes_lpj(cfg, N):
     B = Y W (H doubles, replaces y_n in the Gram form) and per state one 8-byte digest (count + first
     active latents, replaces the ceil(H/8) bit words) plus the 8-byte lpj written."""
     return N * (cfg["H"] * (4 if cfg.get("f32") else 8) + cfg["S"] * (8 + 8))
+
+
+def layout_bytes_stats(cfg, N):
+    """Compulsory bytes of the statistics pass in THIS layout: per datapoint the B row, per state digest + lpj (16 bytes),
+    and the dense moment rows it writes for the contraction ([Es | Ez] for ES3C, Es -- float in the float32 mode -- for EBSC)."""
+    w = 4 if cfg.get("f32") else 8
+    rows = 2 * cfg["H"] * 8 if cfg["algo"] == "es3c" else cfg["H"] * w
+    return N * (cfg["H"] * w + cfg["S"] * 16 + rows)
 
 
 def gemm_flops_per_iteration(cfg, N, executed=False):
@@ -494,8 +507,6 @@ def main():
     from evo_amd.models import BSC, SSSC
 
     eng = Engine()  # LOCAL_RANK selects the GPU
-    if args.dense_states:  # 10..28 pairs of second moments per state instead of <= 1: room for them in the pair bins (7.7 GB)
-        eng.set_option("pair_bins_scale", 12)
     for kv in args.option:
         name, _, val = kv.partition("=")
         eng.set_option(name, int(val))
@@ -522,12 +533,14 @@ def main():
         F, nu, nsub, theta = model.step(theta, suff, my_data)
     # Timed region: HIP events only around the two roofline spans (every timed span costs ~10 us of stream
     # time, so the per-kernel classes are measured in a separate instrumented pass below).
-    eng.timing(["lpj_pass", "stats_pass"])
+    eng.timing(["lpj_pass", "stats_pass"] + (["allreduce"] if world > 1 else []))
     eng.timing_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps * iters):
         F, nu, nsub, theta = model.step(theta, suff, my_data)
+    eng.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank alone (its queue drained), before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -535,6 +548,38 @@ def main():
     log("timed region %.3f s" % dt)
     lpj_ms, lpj_n = eng.kernel_time_ms("lpj_pass")
     st_ms, st_n = eng.kernel_time_ms("stats_pass")
+    # per-rank view of the timed loop in rank 0's line (a first multi-GPU run must be diagnosable from it): every rank fills
+    # its slot of a zero vector, the sum is the gather
+    per_rank = None
+    if world > 1:
+        ar_ms, ar_n = eng.kernel_time_ms("allreduce")
+        mine = np.zeros((world, 5))
+        mine[rank] = [1e3 * dt_own / (args.steps * iters), lpj_ms, st_ms, ar_ms * (ar_n / max(1.0, float(st_n))), n_loc]
+        allr = comm.allreduce_array(mine)
+        per_rank = {"ms_per_em_iteration_own_queue": [round(v, 5) for v in allr[:, 0]],
+                    "lpj_pass_ms": [round(v, 5) for v in allr[:, 1]], "stats_pass_ms": [round(v, 5) for v in allr[:, 2]],
+                    "allreduce_ms_per_iteration": [round(v, 5) for v in allr[:, 3]], "datapoints": [int(v) for v in allr[:, 4]],
+                    "note": "allreduce_ms_per_iteration = HIP-event span(s) around the RCCL all-reduce(s) of the packed accumulator "
+                            "on each rank's stream: from the rank's own statistics being done to the sum being delivered, i.e. "
+                            "waiting for the slowest rank + the collective; the SMALLEST entry is the closest to the collective "
+                            "itself (the last rank to arrive waits for nobody)"}
+    # the reference's step() returns Theta^new as host arrays every epoch: the same loop with the per-iteration download
+    eager_ms = None
+    if not args.eager_theta and not args.host_mstep:
+        eager_iters = max(10, min(50, args.steps * iters // 4))
+        model.lazy_theta = False
+        for _ in range(3):
+            F2, nu2, nsub2, theta = model.step(theta, suff, my_data)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(eager_iters):
+            F2, nu2, nsub2, theta = model.step(theta, suff, my_data)
+        barrier()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / eager_iters
+        if world > 1:
+            eager_ms = comm.allreduce_max(eager_ms)
+        model.lazy_theta = True
+        F2, nu2, nsub2, theta = model.step(theta, suff, my_data)
     n_gt2 = float(getattr(model, "last_dpar", {}).get("n_gt2", float("nan")))
     F_timed, nu_timed, nsub_timed = F, nu, nsub
     # instrumented pass (not part of `value`): per-class device time of a few more iterations
@@ -574,7 +619,7 @@ def main():
             ach = (alg_bytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
             return {"bound": "hbm", "kernel": what, "kernels_in_span": kernels,
                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(args.config, kernels),
+                    "traffic": pmc_traffic(traffic_key(args), kernels),
                     "traffic_note": "HBM bytes per pass, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, read "
                                     "side corrected for gfx950 (2 x FETCH_SIZE: an upper bound for kernels whose loads are 8 bytes per lane), "
                                     "summed over the kernels of the span; profiles/r03_* (r02_* where a config was not re-profiled)",
@@ -600,6 +645,15 @@ def main():
         r_st = roof(st_ms, st_n, stats_kernels(cfg), "whole statistics pass over the resident K^n (scatter kernel + overflow "
                     "levels + column sums + finish; the MFMA contraction is priced under `mfma`)")
         tr = r_st.get("traffic")
+        lay_st = layout_bytes_stats(cfg, n_loc)
+        r_st["layout_bytes_per_launch"] = lay_st
+        r_st["frac_of_layout_bytes"] = (lay_st / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if st_ms > 0 else 0.0
+        if tr is None and lay_st < alg_bytes:
+            # no counters for this workload and the layout moves fewer bytes than SURVEY 8d prices: the algorithmic-byte
+            # fraction would flatter the kernel (c5 float32 mode: 0.99) -- the headline fraction prices the layout bytes
+            r_st["frac_algorithmic_bytes_over_roof"] = r_st["frac"]
+            r_st["frac"] = r_st["frac_of_layout_bytes"]
+            r_st["frac_basis"] = "layout bytes (no PMC counters committed for this workload; below the algorithmic bytes of SURVEY 8d)"
         if tr is not None and tr < alg_bytes:
             # the digest layout moves fewer bytes than SURVEY 8d prices (H = 1024: 8-byte digests for 128-byte bit words):
             # a fraction of algorithmic bytes then flatters the kernel -- the headline fraction prices the measured traffic
@@ -634,6 +688,9 @@ def main():
                        "D": cfg["D"], "H": cfg["H"], "S": cfg["S"],
                        "step": "%d full EM iterations" % iters, "em_iterations_per_step": iters,
                        "em_iterations_timed": total_iters, "ms_per_em_iteration": 1e3 * dt / total_iters,
+                       "ms_per_em_iteration_eager_theta": eager_ms,
+                       "eager_theta_note": "the same loop with Theta^new copied to host arrays every iteration, as the reference's "
+                                           "step() returns it (a short second loop after the timed region; not `value`)",
                        "timed_region_s": dt, "world_size_rccl": comm.size,
                        "ea": "fit/randflip 10 parents x 1 child x 1 gen",
                        "states": "p_init_Kn=8/H (dense stress variant)" if args.dense_states else "p_init_Kn=1/H (init_states default)",
@@ -677,6 +734,8 @@ def main():
                            "frac": fl / (t_ms * 1e-3) / 1e12 / peak,
                            "flops_per_iteration_nominal": fl_nom,
                            "frac_nominal": fl_nom / (t_ms * 1e-3) / 1e12 / peak}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -20,7 +20,7 @@ KERNEL_IDS = {
     "lpj_resident": 0, "lpj_candidates": 1, "lpj_overflow": 2, "row_lse": 3, "vary_kn": 4,
     "stats": 5, "stats_overflow": 6, "gemm_f64": 7, "evolve": 8, "misc": 9, "mstep_device": 10,
     "lpj_pass": 11, "stats_pass": 12, "lpj_k3_4": 13, "lpj_k5_8": 14, "lpj_k9plus": 15,
-    "stats_k3_4": 16, "stats_k5_8": 17, "stats_k9plus": 18,
+    "stats_k3_4": 16, "stats_k5_8": 17, "stats_k9plus": 18, "allreduce": 19, "estep_fused": 20,
 }
 
 _c_dp = ctypes.POINTER(ctypes.c_double)
@@ -69,6 +69,7 @@ SIGNATURES = {
     "evoamd_gemm_tn": (_I, [_vp, _c_dp, _c_dp, _c_dp, _I64, _I, _I, _I]),
     "evoamd_get_params_bsc": (_I, [_vp, _c_dp, _c_dp, _c_dp]),
     "evoamd_get_params_sssc": (_I, [_vp, _c_dp, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "evoamd_restore_theta_backup": (_I, [_vp]),
     "evoamd_free_energy": (_I, [_vp, _c_dp, _I64, _I, _c_dp]),
     "evoamd_set_estep_counts": (_I, [_vp, _DBL, _DBL]),
     "evoamd_comm_unique_id": (_I, [_c_u8p]),

@@ -10,6 +10,20 @@ typedef long long i64;
 #define EVO_F64_TINY (2.2250738585072014e-308) // np.finfo(float64).tiny == eps_pjc_sum (sssc.py:36)
 #define EVO_WAVE 64
 
+// error word err[0] of the ES3C kernels: 1 more than SSSC_KCAP active latents, 2 exactly singular system, 4 a skipped
+// level's list was not empty, and (round 4) 16 a list was full and states were dropped, 8 a list entry / latent index handed
+// through LDS was out of range (it is clamped before it becomes an address: an ordering bug fails a test, not the box)
+#define EVO_ERR_BAD_ENTRY 8
+#define EVO_ERR_LIST_FULL 16
+// A value that is about to become an address after a trip through LDS or a work list: inside [0, bound) or replaced by 0
+// with the error bit raised (one compare per use).
+__device__ __forceinline__ int guard_index(int v, long long bound, int *__restrict__ err) {
+  if (v < 0 || (long long)v >= bound) {
+    atomicOr(err, EVO_ERR_BAD_ENTRY);
+    return 0;
+  }
+  return v;
+}
 // clamp flag bits (per datapoint, per lpj call): _models.py:581-594
 #define EVO_FLAG_NAN 1u
 #define EVO_FLAG_NEGINF 2u

@@ -130,6 +130,8 @@ enum {  // internal kernel ids (see evoamd_kernel_name)
   KID_STATS_K34,   // ... and of the statistics pass
   KID_STATS_K58,
   KID_STATS_K9P,
+  KID_ALLREDUCE,    // the RCCL all-reduce(s) of the packed accumulator: local statistics done -> sum delivered
+  KID_ESTEP_FUSED,  // the fused per-datapoint E-step kernel (lpj of K^n -> candidates -> their lpj -> vary_Kn -> census)
   KID_COUNT
 };
 
@@ -172,6 +174,8 @@ struct evoamd_ctx {
  int bins_scale = 3;  // option "pair_bins_scale" (read by evoamd_configure): entry capacity of the pair bins in units of N x S
                        // (3: every resident state a pair, with a margin of three -- a sparse K^n; a K^n of 5..8 latents per
                        // state leaves 10..28 pairs per state: the dense bench asks for 12 = 7.7 GB at the north-star shape)
+  int bins_scale_cur = 0;  // what the bins are allocated for right now (ensure_bins_capacity re-cuts them when K^n densifies)
+  int bins_auto = 1;       // option "pair_bins_auto": grow the bins from the census of the last statistics pass
   int bins_nwg = 2048;  // option "pair_bins_nwg" (read by evoamd_configure): producer workgroups = private regions per bin
   int bsc_wave_opt = 1;  // option "bsc_stats_wave": EBSC statistics on the wave-per-datapoint kernel (0: round-1 kernel)
   int gemm_ws_opt = 1;  // option "gemm_workspace": stream-K partial tiles through a workspace + reduce kernel (0: f64 atomics)
@@ -250,6 +254,11 @@ struct evoamd_ctx {
   double *h_theta = nullptr;  // host mailbox (kernels_mstep.hpp: mailbox_kernel): seq | err | tail | dpar | Theta
   double *h_theta_dev = nullptr;  // the same memory as the device sees it
   bool h_theta_fresh = false;
+  // lazy Theta (evoamd_mstep_device with bit 64): the parameters the E-step ran with, saved on the device before the
+  // update overwrites them -- what evoamd_restore_theta_backup re-installs when the update turns out singular
+  double *theta_bak = nullptr;
+  size_t theta_bak_n = 0;
+  bool theta_bak_valid = false;
   unsigned long long mbox_seq = 0;
   unsigned *mbox_counter = nullptr;
   int *h_err = nullptr;
@@ -307,6 +316,7 @@ struct evoamd_ctx {
   int stats_flat = 0;   // option "stats_flat": census mode, states with <= 2 latents on the thread-per-state kernel instead of
                         // the wave-per-datapoint one.  Measured (c4, steady state): 504-539 vs 584 us for the kernel, but the
                         // quad levels then share 256 bin regions instead of 2048 (107 vs 69 us) and N / 8 shards lose: off
+  int debug_poison_list = 0;  // option "debug_poison_list" (tests): the next census gets an out-of-range entry
   int census_skip = 0;  // levels that passes over the CURRENT census did not launch (checked when it is rebuilt)
   size_t list_words = 0;  // capacity of each overflow list (ints)
   // scratch for single / shared evaluations
@@ -506,7 +516,7 @@ static void free_all(evoamd_ctx *c) {
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
                   c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf,
-                  c->clist, c->clist_n, c->ovf_rec};
+                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -604,6 +614,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->bins_nwg = value;
     return 0;
   }
+  if (strcmp(name, "pair_bins_auto") == 0) {
+    c->bins_auto = value != 0;
+    return 0;
+  }
   if (strcmp(name, "pair_bins_min") == 0) {
     c->bins_min = value;
     return 0;
@@ -658,6 +672,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "stats_chunks") == 0) {
     if (value < 1 || value > 16) return fail(EVOAMD_E_INVALID, "stats_chunks: 1 .. 16");
     c->stats_chunks = value;
+    return 0;
+  }
+  if (strcmp(name, "debug_poison_list") == 0) {
+    c->debug_poison_list = value != 0;
     return 0;
   }
   if (strcmp(name, "state_digest") == 0) {
@@ -715,6 +733,73 @@ static AccLayout acc_layout(const evoamd_ctx *c) {
     a.tail = a.y2 + D;
   }
   return a;
+}
+
+// Pair bins of the statistics pass (pair_bins.hpp): 2 rf folded rows x H columns per LDS tile; `scale` = entry capacity in
+// units of N x S 32-byte entries.  An optimisation, not a requirement: if the regions do not fit beside the rest, the
+// statistics kernels use their global-atomic paths.
+static int alloc_pair_bins(evoamd_ctx *c, int scale) {
+  const i64 N = c->N;
+  const int H = c->H, S = c->S;
+  if (c->pbins.ent) (void)hipFree(c->pbins.ent);
+  if (c->pbins.gcnt) (void)hipFree(c->pbins.gcnt);
+  if (c->pbins.part) (void)hipFree(c->pbins.part);
+  c->pbins = PairBins{};
+  c->bins_scale_cur = 0;
+  if (H >= 2 && H <= 1024) {
+    PairBins pb = {};
+    pb.rf = std::max(1, PB_TILE / (2 * H));
+    const int nfold = (H - 1 + 1) / 2;
+    pb.nb = (int)cdiv(nfold, pb.rf);
+    // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
+    // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
+    pb.nwg = c->bins_nwg;
+    // reduce workgroups per bin: 4 (8 from 8 M resident states on), and enough of them that bins x workgroups fill
+    // the chip -- H = 128 has 4 bins, H = 256 has 16: with 4 workgroups each the reduce ran on 16 / 64 of 256 CUs
+    pb.nsh = std::max((i64)N * S >= (i64)8 << 20 ? 8 : 4, std::min(PB_NSH_MAX, 256 / std::max(1, pb.nb)));
+    pb.cap = (int)std::max<i64>(64, (i64)scale * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
+    const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
+    const bool got = hipMalloc((void **)&pb.ent, ne * sizeof(double4)) == hipSuccess &&
+                     hipMalloc((void **)&pb.part, (size_t)pb.nb * pb.nsh * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
+                     hipMalloc((void **)&pb.gcnt, (size_t)pb.nb * pb.nwg * sizeof(int)) == hipSuccess;
+    if (got) {
+      HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
+      c->pbins = pb;
+      c->bins_scale_cur = scale;
+    } else {
+      (void)hipGetLastError();
+      if (pb.ent) (void)hipFree(pb.ent);
+      if (pb.part) (void)hipFree(pb.part);
+      if (pb.gcnt) (void)hipFree(pb.gcnt);
+    }
+  }
+  return 0;
+}
+
+// The bins were sized at configure time for a sparse K^n (every state a pair, x 3).  A state with k active latents leaves
+// k (k - 1) / 2 entries; once the census of the last statistics pass (dpar[DP_NGT*], on the host since the last mailbox)
+// says the K^n has outgrown the regions, they are re-cut BEFORE the next pass instead of letting it fall onto the atomic
+// fallback (a silent performance cliff: the dense-state variant needed pair_bins_scale = 12 set by hand).  Grows only.
+static int ensure_bins_capacity(evoamd_ctx *c) {
+  if (c->model != EVOAMD_MODEL_SSSC || !c->need_known || !c->pbins.ent || c->bins_auto == 0) return 0;
+  const double NS = (double)c->N * c->S;
+  const double n34 = c->res_cnt[0] - c->res_cnt[1], n58 = c->res_cnt[1] - c->res_cnt[2];
+  // (3..4 latents: up to 6 pairs, 5..8: up to 28; the states above eight go through the wavefront kernel's atomics)
+  const double entries = (NS - c->res_cnt[0]) + 6.0 * n34 + 28.0 * n58;
+  int want = (int)std::ceil(3.0 * 1.25 * entries / NS);  // margin 3 like the default, 25 % head room for the next iterations
+  if (want > 64) want = 64;
+  if (want <= c->bins_scale_cur) return 0;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+  const int before = c->bins_scale_cur;
+  int r = alloc_pair_bins(c, want);
+  if (r) return r;
+  if (!c->pbins.ent) {  // does not fit: back to what there was (or the atomics if even that is gone now)
+    r = alloc_pair_bins(c, before);
+    if (r) return r;
+    c->bins_auto = 0;
+  }
+  return 0;
 }
 
 extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int H, int S, int S_perm,
@@ -851,39 +936,8 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     }
   }
   {
-    // pair bins of the statistics pass: 2 rf folded rows x H columns per LDS tile
-    if (c->pbins.ent) (void)hipFree(c->pbins.ent);
-    if (c->pbins.gcnt) (void)hipFree(c->pbins.gcnt);
-    if (c->pbins.part) (void)hipFree(c->pbins.part);
-    c->pbins = PairBins{};
-    if (H >= 2 && H <= 1024) {
-      PairBins pb = {};
-      pb.rf = std::max(1, PB_TILE / (2 * H));
-      const int nfold = (H - 1 + 1) / 2;
-      pb.nb = (int)cdiv(nfold, pb.rf);
-      // producer workgroups: a resident-sized grid (8 per CU); every one owns a region per bin, sized for all
-      // of its states being pairs spread evenly over the bins x 3 (the overflow kernels append behind the main one)
-      pb.nwg = c->bins_nwg;
-      // reduce workgroups per bin: 4 (8 from 8 M resident states on), and enough of them that bins x workgroups fill
-      // the chip -- H = 128 has 4 bins, H = 256 has 16: with 4 workgroups each the reduce ran on 16 / 64 of 256 CUs
-      pb.nsh = std::max((i64)N * S >= (i64)8 << 20 ? 8 : 4, std::min(PB_NSH_MAX, 256 / std::max(1, pb.nb)));
-      pb.cap = (int)std::max<i64>(64, (i64)c->bins_scale * cdiv((i64)N * S, (i64)pb.nb * pb.nwg));
-      const size_t ne = (size_t)pb.nb * pb.nwg * pb.cap;
-      // an optimisation, not a requirement: if the regions (96 bytes per resident state) do not fit beside the
-      // rest, the statistics kernels use their global-atomic paths
-      const bool got = hipMalloc((void **)&pb.ent, ne * sizeof(double4)) == hipSuccess &&
-                       hipMalloc((void **)&pb.part, (size_t)pb.nb * pb.nsh * 3 * 2 * pb.rf * H * sizeof(double)) == hipSuccess &&
-                       hipMalloc((void **)&pb.gcnt, (size_t)pb.nb * pb.nwg * sizeof(int)) == hipSuccess;
-      if (got) {
-        HIP_TRY(hipMemsetAsync(pb.gcnt, 0, (size_t)pb.nb * pb.nwg * sizeof(int), c->stream));
-        c->pbins = pb;
-      } else {
-        (void)hipGetLastError();
-        if (pb.ent) (void)hipFree(pb.ent);
-        if (pb.part) (void)hipFree(pb.part);
-        if (pb.gcnt) (void)hipFree(pb.gcnt);
-      }
-    }
+    int rb = alloc_pair_bins(c, c->bins_scale);
+    if (rb) return rb;
   }
   if (c->h_acc) (void)hipHostFree(c->h_acc);
   if (c->h_par) (void)hipHostFree(c->h_par);
@@ -932,6 +986,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   if (c->tmpWt) (void)hipFree(c->tmpWt);  // sized by (H, D): rebuilt on demand
   c->tmpWt = nullptr;
   c->yhat_valid = c->stats_rows_valid = false;
+  c->theta_bak_valid = false;
   c->lists_clean = c->need_known = c->cand_from_device = false;  // fresh (uninitialised) overflow counters
   return 0;
 }
@@ -1681,9 +1736,18 @@ static int ensure_census(evoamd_ctx *c) {
   unsigned grid = cdiv(total, CENSUS_T * CENSUS_PPT);
   if (grid > (unsigned)(8 * c->n_cu)) grid = (unsigned)(8 * c->n_cu);
   SpanGuard g(c, KID_MISC);
-  census_kernel<<<grid, CENSUS_T, 0, c->stream>>>(c->dig, total, c->clist, (i64)c->clist_words, c->clist_n, (int)list_cap(total));
+  census_kernel<<<grid, CENSUS_T, 0, c->stream>>>(c->dig, total, c->clist, (i64)c->clist_words, c->clist_n, (int)list_cap(total), c->err);
   HIP_TRY(hipGetLastError());
   DBG_SYNC(c, "census");
+  if (c->debug_poison_list) {  // test hook: entry 0 of shard 0 of the 3..4 list becomes an out-of-range (n, state) pair
+    c->debug_poison_list = 0;
+    const int bad[1] = {0x7FFFFFF0}, one[1] = {1};
+    HIP_TRY(hipMemcpyAsync(c->clist, bad, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->clist_n, one, sizeof(int), hipMemcpyHostToDevice, c->stream));  // (at least that one entry)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->kn_gen++;  // the poisoned census is rebuilt before anything else reads it
+    return 0;
+  }
   c->census_gen = c->kn_gen;
   return 0;
 }
@@ -1905,6 +1969,8 @@ static int check_err(evoamd_ctx *c) {
   if (e[0]) {
     HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), c->stream));
     if (e[0] & 4) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow level was skipped although its list was not empty");
+    if (e[0] & EVO_ERR_LIST_FULL) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow list was full, states were dropped");
+    if (e[0] & EVO_ERR_BAD_ENTRY) return fail(EVOAMD_E_INVALID, "internal: an ES3C list entry or latent index read back from LDS was out of range");
     if (e[0] & 1) return fail(EVOAMD_E_KLIMIT, "ES3C: a state has more than %d active latents", SSSC_KCAP);
     return fail(EVOAMD_E_SINGULAR, "ES3C: exactly singular k x k system (the reference takes pinv here)");
   }
@@ -2299,6 +2365,7 @@ static int join_fork(evoamd_ctx *c) {
   if (c->ar_gemm_pending) {  // second piece of the split all-reduce (stats_compute sent the rest before the inverses)
     c->ar_gemm_pending = false;
     const AccLayout a = acc_layout(c);
+    SpanGuard g(c, KID_ALLREDUCE);
     RCCL_TRY(g_rccl.AllReduce(c->acc + a.sWp, c->acc + a.sWp, (size_t)(a.y2 - a.sWp), /*ncclDouble*/ 8, /*ncclSum*/ 0,
                               c->comm, c->stream));
   }
@@ -2343,6 +2410,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     if (rj) return rj;
   }
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int rb = ensure_bins_capacity(c);
+    if (rb) return rb;
+  }
   const AccLayout a = acc_layout(c);
   const i64 N = c->N;
   const int H = c->H, D = c->D;
@@ -2365,7 +2436,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   int nchunks = 1;
   if (!masked && !gemm_timed && c->overlap_gemm != 0 && c->stats_chunks > 1 && (gemm_flops >= 8e9 || c->overlap_gemm == 2))
     nchunks = std::min<int>(c->stats_chunks, nblk);
-  const bool census = census_mode(c) && !masked;
+  // census lists need the 4-wave statistics kernel (rows of four datapoints + column sums in LDS: 11 H doubles); larger
+  // H -- or a waves-per-workgroup measurement option -- takes the round-2 level chains, decided BEFORE any level runs
+  const int stats_wv = (c->stats_waves == 4 || c->stats_waves == 8 || c->stats_waves == 16)
+                           ? c->stats_waves
+                           : ((size_t)(4 * 2 + 3) * H * sizeof(double) <= 150 * 1024 ? 4 : 1);
+  const bool census = census_mode(c) && !masked && stats_wv == 4;
   if (census) nchunks = 1;  // the census lists cover the whole shard
   const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
   nchunks = (int)cdiv(N, rows_per_chunk);
@@ -2783,7 +2859,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     SpanGuard g(c, KID_MISC);
     tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
                                           c->model == EVOAMD_MODEL_SSSC ? (census ? c->clist_n : c->list_n) : nullptr,
-                                          LIST_SHARDS, skipped, c->census, census ? 1 : 0);
+                                          LIST_SHARDS, skipped, c->census, census ? 1 : 0,
+                                          (census && c->model == EVOAMD_MODEL_SSSC) ? c->list_n : nullptr, c->pending_skip);
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "stats contraction + tail");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
@@ -2795,10 +2872,12 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   }
   if (c->comm && c->gemm_forked) {
     // [xs | xss | xsz | xszsz] and [y2 | tail] now; [Wp | s_sz | sz_sz] when the contraction has joined
+    SpanGuard g(c, KID_ALLREDUCE);
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)a.sWp, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
     RCCL_TRY(g_rccl.AllReduce(c->acc + a.y2, c->acc + a.y2, (size_t)(c->acc_n - a.y2), 8, 0, c->comm, c->stream));
     c->ar_gemm_pending = true;
   } else if (c->comm) {
+    SpanGuard g(c, KID_ALLREDUCE);
     RCCL_TRY(g_rccl.AllReduce(c->acc, c->acc, (size_t)c->acc_n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
   }
   c->stats_rows_valid = true;
@@ -3144,9 +3223,63 @@ static int mailbox_errors(evoamd_ctx *c) {
   if (e[0]) {
     HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), c->stream));
     if (e[0] & 4) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow level was skipped although its list was not empty");
+    if (e[0] & EVO_ERR_LIST_FULL) return fail(EVOAMD_E_INVALID, "internal: an ES3C overflow list was full, states were dropped");
+    if (e[0] & EVO_ERR_BAD_ENTRY) return fail(EVOAMD_E_INVALID, "internal: an ES3C list entry or latent index read back from LDS was out of range");
     if (e[0] & 1) return fail(EVOAMD_E_KLIMIT, "ES3C: a state has more than %d active latents", SSSC_KCAP);
     return fail(EVOAMD_E_SINGULAR, "ES3C: exactly singular k x k system (the reference takes pinv here)");
   }
+  return 0;
+}
+
+// Segments of the parameters on the device (W | Psi | mus | pies | scalar block) for theta_backup_kernel
+static CopySegs theta_segs(evoamd_ctx *c) {
+  CopySegs s = {};
+  s.ptr[0] = c->W;
+  s.n[0] = (long long)c->D * c->H;
+  if (c->model == EVOAMD_MODEL_SSSC) {
+    s.ptr[1] = c->Psi;
+    s.n[1] = (long long)c->H * c->H;
+    s.ptr[2] = c->mus;
+    s.n[2] = c->H;
+    s.ptr[3] = c->pies;
+    s.n[3] = c->H;
+  }
+  s.ptr[4] = c->dpar;
+  s.n[4] = DP_COUNT;
+  return s;
+}
+
+// lazy Theta: the host has no copy of the parameters the E-step ran with, and the update overwrites them in place.
+// One launch (3 MB at the north-star shape, ~3 us) keeps them until the update is known to be well posed.
+static int backup_theta(evoamd_ctx *c) {
+  const CopySegs s = theta_segs(c);
+  size_t n = 0;
+  for (int k = 0; k < 5; k++) n += (size_t)s.n[k];
+  if (n > c->theta_bak_n) {
+    ALLOC(c->theta_bak, n);
+    c->theta_bak_n = n;
+  }
+  theta_backup_kernel<<<(unsigned)std::min<size_t>(256, cdiv((i64)n, 256 * 8)), 256, 0, c->stream>>>(c->theta_bak, s, 0);
+  HIP_TRY(hipGetLastError());
+  c->theta_bak_valid = true;
+  return 0;
+}
+
+extern "C" int evoamd_restore_theta_backup(evoamd_ctx *c) {
+  REQUIRE(c && c->configured, "configure first");
+  REQUIRE(c->theta_bak && c->theta_bak_valid, "no parameter backup (evoamd_mstep_device keeps one when Theta stays on the device)");
+  HIP_TRY(hipSetDevice(c->device));
+  int r = join_fork(c);
+  if (r) return r;
+  theta_backup_kernel<<<256, 256, 0, c->stream>>>(c->theta_bak, theta_segs(c), 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  // the raw parameters are back; everything derived from them (G, tables, B = Y W) is rebuilt by the next set_params
+  c->gen++;
+  c->h_theta_fresh = false;
+  c->B_valid = false;
+  c->have_params = true;  // evoamd_get_params_* may read them
+  c->prefetch_gen = ~0ull;
   return 0;
 }
 
@@ -3161,6 +3294,11 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   learn_mask &= 31;
   if (want_rec && !c->yhat_valid) {  // under the Theta the E-step used, i.e. before the update
     r = compute_reconstruction(c);   // (incomplete data: the statistics pass formed it already)
+    if (r) return r;
+  }
+  c->theta_bak_valid = false;
+  if (learn_mask && theta_home) {
+    r = backup_theta(c);
     if (r) return r;
   }
   if (learn_mask) {
@@ -3438,6 +3576,6 @@ extern "C" const char *evoamd_kernel_name(int kid) {
   static const char *names[KID_COUNT] = {"lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse",  "vary_kn",
                                          "stats",        "stats_overflow", "gemm_f64",     "evolve",   "misc", "mstep_device",
                                          "lpj_pass",     "stats_pass",     "lpj_k3_4",     "lpj_k5_8", "lpj_k9plus",
-                                         "stats_k3_4",   "stats_k5_8",     "stats_k9plus"};
+                                         "stats_k3_4",   "stats_k5_8",     "stats_k9plus", "allreduce",    "estep_fused"};
   return (kid >= 0 && kid < KID_COUNT) ? names[kid] : "?";
 }

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
                                                    unsigned *__restrict__ flags, i64 nflags3, i64 nper,
                                                    int *__restrict__ err, int *__restrict__ list_n, int nshards,
                                                    int skipped_mask, const double *__restrict__ census,
-                                                   int census_lists = 0) {
+                                                   int census_lists = 0, int *__restrict__ fly_n = nullptr,
+                                                   int fly_skip = 0) {
   __shared__ int cnt[3];
   __shared__ int lvl[3];
   const int t = threadIdx.x;
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
   // which the next pass over K^n reads again: not cleared here
   if (list_n && !census_lists)
     for (int i = t; i < 4 * nshards; i += 256) list_n[i] = 0;
+  // census mode: the quad levels' hand-over (list 3) and the 16-latent wavefront launch (list 2) still appended to the
+  // ON-THE-FLY lists during the pass; their counters are cleared here (a second statistics pass without a chain in
+  // between would serve the stale entries again) and a list nobody served must have stayed empty
+  if (fly_n) clear_lists_checked(fly_n, 4 * nshards, fly_skip, err);
   if (t == 0) {
     tail[0] = dpar[DP_FS];
     tail[1] = dpar[DP_ECNT0];

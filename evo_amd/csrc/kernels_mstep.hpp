@@ -1255,6 +1255,28 @@ __global__ __launch_bounds__(256) void mailbox_kernel(double *__restrict__ out, 
   }
 }
 
+// Theta the E-step ran with, kept on the device while the update overwrites it (lazy_theta: the host holds no copy):
+// up to five segments packed back to back into `out` (W | Psi | mus | pies | scalar block), or back from it (restore).
+struct CopySegs {
+  double *ptr[5];
+  long long n[5];
+};
+__global__ __launch_bounds__(256) void theta_backup_kernel(double *__restrict__ bak, CopySegs segs, int restore) {
+  const long long stride = (long long)gridDim.x * 256;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long base = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    for (long long i = t; i < segs.n[k]; i += stride) {
+      if (restore)
+        segs.ptr[k][i] = bak[base + i];
+      else
+        bak[base + i] = segs.ptr[k][i];
+    }
+    base += segs.n[k];
+  }
+}
+
 // out (rows x cols) = in^T (cols x rows)
 __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ in, int rows_in, int cols_in,
                                                         double *__restrict__ out) {

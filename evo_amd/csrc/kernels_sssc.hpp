@@ -255,7 +255,7 @@ struct ListOut {
 // global counter and an atomic per wave, 57 us sharded per wave, vs 15 us without any append.
 template <int BS>
 __device__ __forceinline__ void block_append(const ListOut &lo, int shard, int value, bool over, int *buf /* LDS BS */,
-                                             int *ctl /* LDS 2 */) {
+                                             int *ctl /* LDS 2 */, int *err = nullptr) {
   if (threadIdx.x == 0) ctl[0] = 0;
   __syncthreads();
   const u64 mask = __ballot(over);
@@ -275,7 +275,10 @@ __device__ __forceinline__ void block_append(const ListOut &lo, int shard, int v
   if (threadIdx.x == 0) ctl[1] = atomicAdd(&lo.counts[shard], n);
   __syncthreads();
   const int start = ctl[1];
-  if (start < 0 || start + n > lo.cap) return;  // cannot happen with list_cap(); never write past the shard
+  if (start < 0 || start + n > lo.cap) {  // cannot happen with list_cap() and clean counters; never write past the shard
+    if (err && threadIdx.x == 0) atomicOr(err, EVO_ERR_LIST_FULL);  // ... but a dropped state must not go unnoticed
+    return;
+  }
   const i64 dst = (i64)shard * lo.cap + start;
   for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
 }
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
     int c = 0, ktot = 0;
     const u64 *sp = nullptr;
     if (live) {
-      e = li.items ? (i64)list_fetch(li, prefix, t) : t;
+      e = li.items ? (i64)guard_index(list_fetch(li, prefix, t), a.N * (i64)a.C, a.err) : t;
       const unsigned eu = (unsigned)e;  // N*C < 2^31 (checked by evoamd_configure)
       n = (i64)(eu / (unsigned)a.C);
       c = (int)(eu - (unsigned)n * (unsigned)a.C);
@@ -524,10 +527,10 @@ __global__ __launch_bounds__(BS) void sssc_small_kernel(SsscArgs a, ListIn li, L
       }
     }
     const bool over = live && ktot > K;
-    block_append<BS>(lo, (int)(round & (LIST_SHARDS - 1)), (int)e, over, ovf_buf, ovf_ctl);
+    block_append<BS>(lo, (int)(round & (LIST_SHARDS - 1)), (int)e, over, ovf_buf, ovf_ctl, a.err);
     if (exact) {  // uniform
       const bool hard = live && !over && ktot > 2;
-      block_append<BS>(hard_out, (int)(round & (LIST_SHARDS - 1)), (int)e, hard, ovf_buf, ovf_ctl);
+      block_append<BS>(hard_out, (int)(round & (LIST_SHARDS - 1)), (int)e, hard, ovf_buf, ovf_ctl, a.err);
       if (hard) continue;
     }
     if (!live || over) continue;  // no barrier below this point in the iteration
@@ -669,10 +672,14 @@ __device__ __forceinline__ void append_begin(const ListOut &lo, int shard, int v
   append_begin<BS, 1>(lo, shard, v, o, buf, ctl);
 }
 template <int BS>
-__device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl) {
+__device__ __forceinline__ void append_end(const ListOut &lo, int shard, const int *buf, const int *ctl, int *err = nullptr) {
   lds_barrier();
   const int n = ctl[0], start = ctl[1];
-  if (n == 0 || start < 0 || start + n > lo.cap) return;  // never write past the shard
+  if (n == 0) return;
+  if (start < 0 || start + n > lo.cap) {  // never write past the shard; report the dropped states
+    if (err && threadIdx.x == 0) atomicOr(err, EVO_ERR_LIST_FULL);
+    return;
+  }
   const i64 dst = (i64)shard * lo.cap + start;
   for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
 }
@@ -826,7 +833,7 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
       }
     }
   }
-  if (APPEND) append_end<BS>(lo, shard, ovf_buf, ovf_ctl);
+  if (APPEND) append_end<BS>(lo, shard, ovf_buf, ovf_ctl, a.err);
 }
 
 // Main statistics pass over the resident K^n (sssc.py:553-611), states with |A| <= 2 (the others go to the
@@ -880,7 +887,10 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
     base = __shfl(base, 0, 64);
     for (int i = lane; i < ocnt; i += 64) {
       const int pos = base + i;
-      if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = obuf[wave][i];
+      if (pos >= 0 && pos < lo.cap)
+        lo.items[(i64)shard * lo.cap + pos] = obuf[wave][i];
+      else
+        atomicOr(a.err, EVO_ERR_LIST_FULL);
     }
     ocnt = 0;
     lds_wave_fence();
@@ -1130,7 +1140,10 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
             const int e = (int)(n * a.C + c0 + 64 * u + lane);
             if (o_direct) {
               const int pos = obase + my_off[u];
-              if (pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = e;
+              if (pos >= 0 && pos < lo.cap)
+                lo.items[(i64)shard * lo.cap + pos] = e;
+              else
+                atomicOr(a.err, EVO_ERR_LIST_FULL);
             } else {
               obuf[wave][ocnt + my_off[u]] = e;
             }
@@ -1307,7 +1320,8 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
   const i64 total1 = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
   const i64 total = total1 + (li2.items ? (i64)list_prefix(li2, prefix2) : 0);
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
-    const i64 e = t >= total1 ? (i64)list_fetch(li2, prefix2, t - total1) : (li.items ? (i64)list_fetch(li, prefix, t) : t);
+    const i64 e = t >= total1 ? (i64)guard_index(list_fetch(li2, prefix2, t - total1), a.N * (i64)a.C, a.err)
+                              : (li.items ? (i64)guard_index(list_fetch(li, prefix, t), a.N * (i64)a.C, a.err) : t);
     const i64 n = e / a.C;
     const int c = (int)(e - n * a.C);
     if (a.counts && c >= a.counts[n]) continue;  // uniform

@@ -29,7 +29,8 @@
 // consecutive states per round in LDS and reserves its range with one returning atomic per level (kernels_sssc.hpp:
 // a counter sustains ~90 of them per us, hence the shards).
 __global__ __launch_bounds__(CENSUS_T) void census_kernel(const u64 *__restrict__ dig, i64 total, int *__restrict__ items,
-                                                          i64 list_stride, int *__restrict__ counts, int cap) {
+                                                          i64 list_stride, int *__restrict__ counts, int cap,
+                                                          int *__restrict__ err) {
   constexpr int PER = CENSUS_T * CENSUS_PPT;
   __shared__ int buf[3][PER];
   __shared__ int cnt[3], start[3];
@@ -69,7 +70,11 @@ __global__ __launch_bounds__(CENSUS_T) void census_kernel(const u64 *__restrict_
 #pragma unroll
     for (int L = 0; L < 3; L++) {
       const int n = cnt[L], s0 = start[L];
-      if (n == 0 || s0 < 0 || s0 + n > cap) continue;  // never past the shard (list_cap() makes room for every chunk)
+      if (n == 0) continue;
+      if (s0 < 0 || s0 + n > cap) {  // never past the shard (list_cap() makes room for every chunk) -- and never silently
+        if (threadIdx.x == 0) atomicOr(err, EVO_ERR_LIST_FULL);
+        continue;
+      }
       int *dst = items + (i64)L * list_stride + (i64)shard * cap + s0;
       for (int i = threadIdx.x; i < n; i += CENSUS_T) dst[i] = buf[L][i];
     }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
       const i64 te = base + wave * 16 + q;
       bool live = te < total;
       int e = 0;
-      if (live) e = list_fetch(li, prefix, te);
+      if (live) e = guard_index(list_fetch(li, prefix, te), a.N * (i64)a.C, a.err);
       const unsigned eu = (unsigned)e;
       const i64 n = (i64)(eu / (unsigned)a.C);
       const int c = (int)(eu - (unsigned)n * (unsigned)a.C);
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
         if (scan) {
           k = run;  // (== dig_k where there is a digest)
 #pragma unroll
-          for (int i = 0; i < K; i++) idx[i] = (i < k && i < K) ? idx_sh[wave][q][i] : 0;
+          for (int i = 0; i < K; i++) idx[i] = (i < k && i < K) ? guard_index(idx_sh[wave][q][i], H, a.err) : 0;
         }
         lds_wave_fence();
       }
@@ -396,7 +401,12 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
             if (lane == leader) b0 = atomicAdd(&lo.counts[shard], __popcll(om));
             b0 = __shfl(b0, leader, 64);
             const int pos = b0 + __popcll(om & ((1ull << lane) - 1ull));
-            if (over && t == 0 && pos >= 0 && pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = e;
+            if (over && t == 0) {
+              if (pos >= 0 && pos < lo.cap)
+                lo.items[(i64)shard * lo.cap + pos] = e;
+              else
+                atomicOr(a.err, EVO_ERR_LIST_FULL);
+            }
           } else if (over && t == 0) {
             atomicOr(a.err, 4);  // a census list never holds such a state
           }
@@ -444,12 +454,13 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
       // (the datapoint of an idle quad is row 0: every address stays valid)
       int e0 = (MODE == 0) ? stage_l[wave].e[q] : stage[MODE == 1 ? wave : 0].e[q];
       if (MODE == 1 && ks == 0) e0 = 0;
-      const unsigned eu = e0 < 0 ? 0u : (unsigned)e0;
+      const unsigned eu = e0 < 0 ? 0u : (unsigned)guard_index(e0, a.N * (i64)a.C, a.err);  // (read back from LDS)
       const i64 nn = (i64)(eu / (unsigned)a.C);
       quad_solve<C, MODE>(a, t, ks, idx, cidx, a.Bm + nn * H, a.yy[nn], val, hard, kap_all, Lam);
     }
     hard = (hard || exact) && ks > 0;  // (a state with k = 0 never reaches a list; ks == 0 <=> idle quad)
-    const int e_mine = (MODE == 0) ? stage_l[wave].e[q] : stage[MODE == 1 ? wave : 0].e[q];
+    int e_mine = (MODE == 0) ? stage_l[wave].e[q] : stage[MODE == 1 ? wave : 0].e[q];
+    if (e_mine >= 0) e_mine = guard_index(e_mine, a.N * (i64)a.C, a.err);  // (read back from LDS: the record slot n S + c)
     {  // states that need row exchanges: the pivoting wavefront kernel's list
       const u64 hm = __ballot(hard && t == 0);
       if (hm != 0ull) {
@@ -459,7 +470,12 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
         if (lane == leader) b0 = atomicAdd(&hard_out.counts[shard], __popcll(hm));
         b0 = __shfl(b0, leader, 64);
         const int pos = b0 + __popcll(hm & ((1ull << lane) - 1ull));
-        if (hard && t == 0 && pos >= 0 && pos < hard_out.cap) hard_out.items[(i64)shard * hard_out.cap + pos] = e_mine;
+        if (hard && t == 0) {
+          if (pos >= 0 && pos < hard_out.cap)
+            hard_out.items[(i64)shard * hard_out.cap + pos] = e_mine;
+          else
+            atomicOr(a.err, EVO_ERR_LIST_FULL);
+        }
       }
     }
     if constexpr (MODE == 0) {
@@ -518,7 +534,7 @@ __global__ __launch_bounds__(256, (C == 1 ? (MODE == 0 ? 4 : 3) : 2)) void sssc_
         const int kq = st.ks[qq];
         if (i < kq && cc < kq) {
           const double w = st.qn[qq], kc = st.kap[qq][cc];
-          const int hi = st.lat[qq][i], hc = st.lat[qq][cc];
+          const int hi = guard_index(st.lat[qq][i], H, a.err), hc = guard_index(st.lat[qq][cc], H, a.err);
           const double vv = w * fma(st.kap[qq][i], kc, st.lam[qq][i][cc]);
           if (i == cc) {
             unsafeAtomicAdd(&cs_diag[hc], vv);

@@ -299,6 +299,10 @@ class Engine:
         check(self.lib.evoamd_get_params_sssc(self._h, dptr(W), dptr(pies), dptr(mus), dptr(Psi), ctypes.byref(s2)))
         return {"W": W, "pies": pies, "mus": mus, "Psi": Psi, "sigma2": np.float64(s2.value)}
 
+    def restore_theta_backup(self):
+        """Re-install the parameters the last E-step ran with (kept on the device by mstep_device(theta_to_host=False))."""
+        check(self.lib.evoamd_restore_theta_backup(self._h))
+
     def free_energy_sum(self, lpj):
         lpj = as_f64(lpj)
         out = ctypes.c_double()

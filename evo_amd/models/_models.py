@@ -430,6 +430,12 @@ class Model:
         to the device (the failed update overwrote it), the statistics are summed again from the unchanged
         K^n / lpj, and the reference's host formulas, fallbacks and np.random draws included, give Theta^new."""
         eng = self.engine
+        if isinstance(model_params, LazyTheta) and not model_params.materialised:
+            # lazy Theta: the host holds no copy of the Theta the E-step ran with, and the loader would download what
+            # the failed update left behind.  The library kept the old parameters on the device: bring THOSE back.
+            eng.restore_theta_backup()
+            model_params._loader = None
+            dict.update(model_params, self._pull_params(dpar))  # (E_step_precompute below rewrites the derived keys)
         self.E_step_precompute(model_params, my_suff_stat, my_data)
         if self._incomplete and do_reconstruction:
             eng.set_option("reconstruct_in_stats", 1)

@@ -106,6 +106,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * N x S entries of 32 bytes (a K^n of mostly 5..8 active latents needs ~12; entries beyond the capacity fall back to atomics).
  * "pair_bins_nwg" (256 .. 2048 in steps of 256, default 2048; read by the next evoamd_configure): producer workgroups of
  * the statistics pass = private regions per pair bin (fewer, longer regions for the reduce pass to read).
+ * "pair_bins_auto" (0/1, default 1): the statistics pass re-cuts the pair bins (grows "pair_bins_scale", up to 64) when the
+ * census of the previous pass -- states with 3..4 / 5..8 active latents leave up to 6 / 28 entries each -- says the K^n has
+ * outgrown them, instead of overflowing onto the atomic fallback; 0: the configured capacity stays.
  * "pair_bins_min" (default 256): with "pair_bins" = 1 the bins are used from this many x 1024 resident states (N S) on.
  * "bsc_stats_wave" (0/1, default 1): EBSC statistics on the wave-per-datapoint kernel (next datapoint prefetched, Wq pairs
  * through the pair bins, column sums in the kernel); 0: the one-shot kernel + column-sum pass.
@@ -144,7 +147,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * (lists appended by the main kernels, K = 4 / K = 8 register kernels, wavefront kernel).
  * "sk_spare" (-1 = automatic (default), 0 .. 32): workgroups per XCD that the long-K contraction does not launch while it
  * runs on the second stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free
- * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8). */
+ * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8).
+ * "debug_poison_list" (one-shot, tests): the next census of the resident K^n gets an out-of-range entry.  Every list entry
+ * and every latent index that crosses LDS is range-checked before it becomes an address, so the pass that reads the entry
+ * ends in EVOAMD_E_INVALID ("... out of range") instead of a memory fault; the census is rebuilt afterwards. */
 int evoamd_set_option(evoamd_ctx *ctx, const char *name, int value);
 
 /* ---- problem geometry -------------------------------------------------------------- */
@@ -323,6 +329,12 @@ int evoamd_gemm_tn(evoamd_ctx *ctx, const double *A, const double *B, double *C,
 int evoamd_get_params_bsc(evoamd_ctx *ctx, double *W, double *pi, double *sigma);
 int evoamd_get_params_sssc(evoamd_ctx *ctx, double *W, double *pies, double *mus, double *Psi,
                            double *sigma2);
+/* evoamd_mstep_device with bit 64 (Theta^new stays on the device) keeps the parameters the E-step ran with in a device
+ * backup while the update overwrites them in place.  This call re-installs that backup -- what the caller needs when the
+ * update returns EVOAMD_E_SINGULAR and it wants to finish the step with the reference's host formulas and fallbacks
+ * (sssc.py:692-708, bsc.py:236-250), which start from the OLD Theta.  evoamd_get_params_* then reads them; the derived
+ * tables are rebuilt by the next evoamd_set_params_*. */
+int evoamd_restore_theta_backup(evoamd_ctx *ctx);
 /* Fs only (sum_n logsumexp) of an arbitrary host lpj matrix (N,C) -- exact-likelihood path. */
 int evoamd_free_energy(evoamd_ctx *ctx, const double *lpj, int64_t N, int C, double *Fs_out);
 /* Adds the E-step scalars produced outside evoamd_stats (e.g. host-side vary_Kn counts)
@@ -361,7 +373,10 @@ enum {
   EVOAMD_K_STATS_K3_4 = 16,    /* the same levels of the statistics pass */
   EVOAMD_K_STATS_K5_8 = 17,
   EVOAMD_K_STATS_K9PLUS = 18,
-  EVOAMD_K_COUNT = 19
+  EVOAMD_K_ALLREDUCE = 19,     /* RCCL all-reduce(s) of the packed accumulator (sssc.py:671-691 / bsc.py:230-274 in one call): from
+                                  this rank's statistics being done to the sum being delivered, i.e. wait for the slowest rank + transfer */
+  EVOAMD_K_ESTEP_FUSED = 20,   /* fused per-datapoint E-step kernel (option "fused_estep") */
+  EVOAMD_K_COUNT = 21
 };
 /* on = bit mask of kernel classes to time (bit k = class k; -1 = all, 0 = off).  Each timed span
  * records two HIP events on the compute stream, which costs about 10 us of stream time per span:

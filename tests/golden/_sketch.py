@@ -54,3 +54,23 @@ def lpj_rows(lpj):
 
 def array_sha1(A):
     return hashlib.sha1(np.ascontiguousarray(A).tobytes()).hexdigest()
+
+
+def bars_recovered(W, W_gen, thresh=0.9):
+    """Number of generating fields (columns of W_gen, D x H) matched by DISTINCT learned columns of W with a cosine
+    similarity above `thresh` (greedy over the similarity matrix, best pairs first) -- the bars test's success measure
+    (examples/bars-test: learned W against the ground-truth bars)."""
+    W, W_gen = np.asarray(W, dtype=np.float64), np.asarray(W_gen, dtype=np.float64)
+    a = W / np.maximum(np.linalg.norm(W, axis=0, keepdims=True), 1e-300)
+    b = W_gen / np.maximum(np.linalg.norm(W_gen, axis=0, keepdims=True), 1e-300)
+    sim = np.abs(b.T @ a)  # (H_gen, H); the sign of a spike-and-slab field is not identified (mu = 0, z -> -z)
+    found = 0
+    sim = sim.copy()
+    for _ in range(sim.shape[0]):
+        i, j = np.unravel_index(np.argmax(sim), sim.shape)
+        if sim[i, j] < thresh:
+            break
+        found += 1
+        sim[i, :] = -np.inf
+        sim[:, j] = -np.inf
+    return found

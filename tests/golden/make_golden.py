@@ -420,6 +420,53 @@ def make_full_F():
     np.savez_compressed(os.path.join(HERE, "full_F.npz"), **out)
 
 
+def make_learn_bars(n_seeds=6, n_iter=40):
+    """Learning-level fixture (the reference validates by TRAINING -- bars recovery and F -> L_gen,
+    examples/bars-test/main.py:123-135, 156-162).  The bars set-up of SURVEY 8c(ii) (H = 10, D = 25, N = 500, S = 32,
+    fit / randflip 10 x 1 x 1), EBSC and ES3C, `n_seeds` seeds, `n_iter` EM iterations each, run by the reference itself:
+    per seed the F trajectory, the exact log-likelihood under the generating Theta (free_energy(full=True)), the learned W
+    and how many bars it recovered.  The GPU test trains the same data sets in the configuration bench.py times
+    (rng="device", device M-step) and compares distributions; it needs no reference run."""
+    H, D, N, S = 10, 25, 500, 32
+    out = {"n_seeds": np.int64(n_seeds), "n_iter": np.int64(n_iter), "H": np.int64(H), "D": np.int64(D), "N": np.int64(N),
+           "S": np.int64(S)}
+    Wg = 10.0 * bars(H)
+    for algo in ("ebsc", "es3c"):
+        Fs, Ls, Ws, rec, shas = [], [], [], [], []
+        for seed in range(n_seeds):
+            np.random.seed(1000 + seed)
+            if algo == "ebsc":
+                model = BSC(D, H, S)
+                gen = {"W": Wg.copy(), "pi": 2.0 / H, "sigma": 1.0}
+            else:
+                model = SSSC(D, H, S)
+                gen = {"W": Wg.copy(), "pies": np.ones(H) * 2.0 / H, "sigma2": np.array(1.0),
+                       "mus": np.ones(H) * 0.0, "Psi": np.eye(H) * 1.0}
+            Y = model.generate_data(gen, N)["y"]
+            gen = model.check_params(gen)
+            my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 10, 1, 1)
+            L_gen = model.free_energy(my_data, {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in gen.items()},
+                                      suff, full=True)
+            F_tr = []
+            for _ in range(n_iter):
+                F, nu, nsub, theta = model.step(theta, suff, my_data)
+                F_tr.append(F)
+            Fs.append(F_tr)
+            Ls.append(L_gen)
+            Ws.append(np.array(theta["W"]))
+            rec.append(_sketch.bars_recovered(theta["W"], Wg))
+            shas.append(hashlib.sha1(Y.tobytes()).hexdigest())
+            print(algo, "seed", seed, "L_gen %.4f" % L_gen, "F_end %.4f" % F_tr[-1], "bars", rec[-1], flush=True)
+        out[algo + "_F"] = np.array(Fs)
+        out[algo + "_L_gen"] = np.array(Ls)
+        out[algo + "_W"] = np.array(Ws)
+        out[algo + "_bars"] = np.array(rec, dtype=np.int64)
+        out[algo + "_Y_sha1"] = np.array(shas)
+    np.savez_compressed(os.path.join(HERE, "learn_bars.npz"), **out)
+
+
 def make_recon_fixture(name, algo, D, H, S, N, seed, n_steps=2):
     """model.step(..., do_reconstruction=True) on complete data (the image-denoising use,
     examples/image-denoising/main.py:100-110,162-169): my_data["x"] marks the entries that keep their
@@ -621,6 +668,9 @@ SHAPES = {  # name: (algo, D, H, S, N, seed, ea) -- BASELINE.json configs[1..4] 
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "learn":  # learning-level fixture (round 4): bars training runs of the reference
+        make_learn_bars()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "missing":  # only the incomplete-data fixture (added later)
         make_missing_fixture()
         sys.exit(0)
@@ -670,6 +720,7 @@ if __name__ == "__main__":
     make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
     make_lpj_singular_k3()
+    make_learn_bars()
     for nm in sorted(SHAPES):
         a, D, H, S, N, seed, ea = SHAPES[nm][:7]
         make_shape_fixture(nm, a, D, H, S, N, seed, n_steps=(SHAPES[nm][7] if len(SHAPES[nm]) > 7 else 2), ea=ea)

@@ -608,3 +608,91 @@ def test_inverse_above_blocked_limit(engine):
     Ai, Gi, _ = engine.inverse(A, G)
     assert np.abs(Ai @ A - np.eye(n)).max() < 1e-8
     assert np.abs(Gi @ G - np.eye(n)).max() < 1e-7
+
+
+def test_stats_twice_in_exact_mode(engine):
+    """in census mode the statistics pass appended to the on-the-fly lists (the quad levels' hand-over, the
+    16-latent wavefront launch) but marked their counters clean, so a SECOND statistics pass with no chain in between
+    served the stale entries again and added their moments twice.  Exact mode (screen = 2) sends every state above two
+    latents through those lists: two evoamd_stats calls in a row must give the same accumulator."""
+    g = load_golden("lpj_sssc_singular_k3.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    engine.set_option("lpj_singular_screen", 2)
+    try:
+        engine.configure("sssc", N, D, H, C, 0, 8)
+        engine.upload_data(Y)
+        engine.upload_states(np.tile(states[None], (N, 1, 1)))
+        engine.set_params_sssc(g["W"], g["pies"], g["mus"], g["Psi"], float(g["sigma2"]))
+        engine.lpj_resident()
+        a1 = engine.stats().copy()
+        a2 = engine.stats().copy()   # what _step_device_singular / reconstruct() do: statistics again, no chain between
+        a3 = engine.stats().copy()
+    finally:
+        engine.set_option("lpj_singular_screen", 1)
+    # (the last 8 entries are the E-step tail: the clamp counters of the lpj pass are consumed by the first call)
+    m1, m2, m3 = a1[:-8], a2[:-8], a3[:-8]
+    scale = max(1.0, float(np.abs(m1).max()))
+    assert np.abs(m2 - m1).max() <= 1e-12 * scale
+    assert np.abs(m3 - m1).max() <= 1e-12 * scale
+    assert a1[-8] == a2[-8] == a3[-8]  # Fs
+
+
+def test_stats_large_H_falls_back_to_chains(engine):
+    """above H = 1745 the 4-wave statistics kernel's LDS rows do not fit and the census lists cannot be used by
+    the statistics pass; it must take the round-2 chains (decided before any level runs) instead of failing."""
+    from oracle import evo_oracle as orc
+    rng = np.random.RandomState(11)
+    N, D, H, S = 12, 24, 1800, 10
+    Y = rng.normal(size=(N, D))
+    W = rng.normal(size=(D, H))
+    pies = rng.uniform(0.1, 0.4, H)
+    mus = rng.normal(size=H)
+    A = rng.normal(size=(H, 6)) * 0.05
+    Psi = np.eye(H) + A @ A.T
+    ss = np.zeros((N, S, H), dtype=bool)
+    for n in range(N):
+        for s in range(S):
+            k = 1 + (s % 5)  # 1 .. 5 active latents: every level
+            ss[n, s, rng.choice(H, k, replace=False)] = True
+    theta = {"W": W, "pies": pies, "mus": mus, "Psi": Psi, "sigma2": np.float64(1.3)}
+    engine.configure("sssc", N, D, H, S, 0, 4)
+    engine.upload_data(Y)
+    engine.upload_states(ss)
+    engine.set_params_sssc(W, pies, mus, Psi, 1.3)
+    engine.lpj_resident()
+    lpj = engine.download_lpj()
+    v = engine.acc_views(engine.stats())
+    suff = {"ss": ss, "lpj": np.empty((N, S)), "S_perm": 0, "incl": np.zeros((0, H), dtype=bool), "Mprime": S}
+    want = orc.sssc_EM_accumulate(dict(theta), suff, Y, use_storage=False, evolve=False)
+    _close(lpj, suff["lpj"], 1e-10, "lpj at H = 1800")
+    for name in ("xpt_s", "xpt_sz", "xpt_ss", "xpt_szsz", "Wp"):
+        ref = want[name]
+        assert np.abs(v[name] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
+
+
+def test_out_of_range_list_entry_is_an_error_not_a_fault(engine):
+    """list entries and latent indices that cross LDS are range-checked before they become addresses.
+    A census list with an out-of-range (datapoint, state) entry must end in the error word, not in a GPU memory fault;
+    the context stays usable and the rebuilt census gives the right values."""
+    from evo_amd._lib import EvoAmdError
+    g = load_golden("lpj_sssc.npz")
+    H = int(g["H"])
+    states = unpack_bits(g["states"], H)
+    C = states.shape[0]
+    Y = g["Y"]
+    N, D = Y.shape
+    engine.configure("sssc", N, D, H, C, 0, 8)
+    engine.upload_data(Y)
+    engine.upload_states(np.tile(states[None], (N, 1, 1)))
+    engine.set_params_sssc(g["W"], g["pies"], g["mus"], g["Psi"], float(g["sigma2"]))
+    engine.set_option("debug_poison_list", 1)
+    engine.lpj_resident()
+    with pytest.raises(EvoAmdError, match="out of range"):
+        engine.stats()
+    engine.lpj_resident()  # fresh census
+    _close(engine.download_lpj(), g["lpj"], 1e-11, "after the poisoned pass")
+    engine.stats()

@@ -990,6 +990,59 @@ def test_lazy_theta_is_the_same_theta(engine, algo):
 
 
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_lazy_theta_singular_update_restores_the_estep_theta(engine, algo):
+    """with lazy_theta=True the host holds no copy of the Theta an E-step ran with, and the device update
+    overwrites it in place -- the singular-update fallback used to download what the FAILED update had left behind and
+    ran the statistics and the reference's host formulas on that.  Now the library keeps the E-step's parameters in a
+    device backup and the fallback re-installs them.  Two lazy steps, then a step whose device update is reported
+    singular (forced: the real update has run and overwritten Theta, which is exactly the state the fallback meets):
+    F and Theta^new must equal the eager run, whose fallback reads the host copy."""
+    from evo_amd import engine as eng_mod
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.models._models import LazyTheta
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(14)
+    D, H, S, N = 20, 24, 12, 300
+    Y = rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+    out = []
+    real = engine.mstep_device
+    for lazy in (False, True):
+        np.random.seed(9)
+        model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=5, device_mstep=True, lazy_theta=lazy)
+        theta = model.check_params(model.standard_init(my_data))
+        suff = init_states(N, S, H, "fit", "randflip", 4, 1, 1)
+        calls = {"n": 0}
+
+        def forced(to_learn, reconstruct=False, theta_to_host=True):
+            tail, d = real(to_learn, reconstruct=reconstruct, theta_to_host=theta_to_host)
+            calls["n"] += 1
+            if calls["n"] == 3:
+                raise eng_mod.SingularUpdate("forced by the test", tail, d)
+            return tail, d
+
+        engine.mstep_device = forced
+        try:
+            Fs = []
+            for it in range(3):
+                if lazy and it == 2:
+                    assert isinstance(theta, LazyTheta) and not theta.materialised  # the case the finding is about
+                np.random.seed(100 + it)  # the host formulas may draw (pinv + noise)
+                F, nu, nsub, theta = model.step(theta, suff, my_data)
+                Fs.append(F)
+        finally:
+            del engine.mstep_device
+        out.append((Fs, {k: np.array(v) for k, v in theta.items()}))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-12)
+    for k in (BSC_KEYS if algo == "ebsc" else SSSC_KEYS):
+        np.testing.assert_allclose(out[1][1][k], out[0][1][k], rtol=1e-9, atol=1e-12, err_msg=k)
+    # ... and a further step from the fallback's Theta runs (fresh upload, precompute, no stale prefetched pass)
+    F4 = model.step(theta, suff, my_data)[0]
+    assert np.isfinite(F4)
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 def test_device_mstep_absorbs_singular_update(engine, algo):
     """A latent that occurs in no state of any K^n makes the M-step's H x H system exactly singular.  The
     reference absorbs it (lstsq min-norm solution, bsc.py:237; inv -> LinAlgError -> pinv + noise,
