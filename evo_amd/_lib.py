@@ -55,6 +55,7 @@ SIGNATURES = {
     "evoamd_lpj_single": (_I, [_vp, _c_dp, _c_u8p, _I, _c_dp, _c_i32p]),
     "evoamd_vary_kn": (_I, [_vp, _I, _c_dp]),
     "evoamd_evolve_randflip": (_I, [_vp, _I, _I, _U64, _I]),
+    "evoamd_estep": (_I, [_vp, _I, _I, _U64, _I, _I, ctypes.POINTER(_I)]),
     "evoamd_evolve_states": (_I, [_vp, _I, _I, _I, _I, _I, _U64, _DBL, _DBL]),
     "evoamd_download_candidates": (_I, [_vp, _c_u8p, _c_i32p, _c_dp]),
     "evoamd_acc_size": (_I64, [_vp]),

@@ -22,6 +22,7 @@
 #include "kernels_mstep.hpp"
 #include "kernels_sssc.hpp"
 #include "kernels_sssc_quad.hpp"
+#include "kernels_fused.hpp"
 
 // ---------------------------------------------------------------------------------------
 // error handling
@@ -316,6 +317,14 @@ struct evoamd_ctx {
   int stats_flat = 0;   // option "stats_flat": census mode, states with <= 2 latents on the thread-per-state kernel instead of
                         // the wave-per-datapoint one.  Measured (c4, steady state): 504-539 vs 584 us for the kernel, but the
                         // quad levels then share 256 bin regions instead of 2048 (107 vs 69 us) and N / 8 shards lose: off
+  // fused per-datapoint E-step (kernels_fused.hpp): option "fused_estep" 0 never / 1 when K^n is sparse enough (default) /
+  // 2 whenever the shape allows it; rowF / rowcnt = per-datapoint free-energy term and counters, defer = datapoints the
+  // FAST instantiation left to the FULL one (N items + the counter behind them)
+  int fused_opt = 1;
+  double *rowF = nullptr;
+  int *rowcnt = nullptr, *defer = nullptr;
+  bool last_estep_fused = false;
+  long fused_calls = 0, unfused_calls = 0;
   int debug_poison_list = 0;  // option "debug_poison_list" (tests): the next census gets an out-of-range entry
   int census_skip = 0;  // levels that passes over the CURRENT census did not launch (checked when it is rebuilt)
   size_t list_words = 0;  // capacity of each overflow list (ints)
@@ -504,6 +513,14 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<4, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     HIP_TRY(hipFuncSetAttribute((const void *)sssc_small_kernel<8, 1, 2, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
   }
+  {
+    const void *fk[] = {(const void *)sssc_estep_fused_kernel<1, false>,  (const void *)sssc_estep_fused_kernel<1, true>,
+                        (const void *)sssc_estep_fused_kernel<2, false>,  (const void *)sssc_estep_fused_kernel<2, true>,
+                        (const void *)sssc_estep_fused_kernel<4, false>,  (const void *)sssc_estep_fused_kernel<4, true>,
+                        (const void *)sssc_estep_fused_kernel<8, false>,  (const void *)sssc_estep_fused_kernel<8, true>,
+                        (const void *)sssc_estep_fused_kernel<16, false>, (const void *)sssc_estep_fused_kernel<16, true>};
+    for (const void *fp : fk) HIP_TRY(hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
   *out = c;
   return 0;
 }
@@ -516,7 +533,7 @@ static void free_all(evoamd_ctx *c) {
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
                   c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf,
-                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak};
+                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak, c->rowF, c->rowcnt, c->defer};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -672,6 +689,11 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "stats_chunks") == 0) {
     if (value < 1 || value > 16) return fail(EVOAMD_E_INVALID, "stats_chunks: 1 .. 16");
     c->stats_chunks = value;
+    return 0;
+  }
+  if (strcmp(name, "fused_estep") == 0) {
+    if (value < 0 || value > 2) return fail(EVOAMD_E_INVALID, "fused_estep: 0 (never), 1 (automatic) or 2 (whenever the shape allows it)");
+    c->fused_opt = value;
     return 0;
   }
   if (strcmp(name, "debug_poison_list") == 0) {
@@ -916,6 +938,10 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->mus, (size_t)H);
     ALLOC(c->pilbar_v, (size_t)H);
     ALLOC(c->pies, (size_t)H);
+    ALLOC(c->rowF, (size_t)N);
+    ALLOC(c->rowcnt, (size_t)N);
+    ALLOC(c->defer, (size_t)N + 1);
+    c->last_estep_fused = false;
     c->list_words = 0;
     int rl = ensure_lists(c, (i64)N * SC);
     if (rl) return rl;
@@ -1884,10 +1910,12 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     // (four-lanes-per-state kernel) -> list 3 = the pivoting wavefront kernel, which also takes the states the quads
     // pass on and therefore always runs behind them
     SpanGuard g(c, KID_LPJ_OVF);
-    // (3..4 latents of a chain: the K = 4 thread-per-state register kernel -- 58 us against 77 us of the quad kernel
-    // on the ~400k listed candidates of the north-star shape; its lists are long enough to fill whole waves)
+    // (3..4 latents of a chain: the quad kernel too since round 4 -- the K = 4 thread-per-state register kernel was faster
+    // on the ~400k listed candidates of the north-star shape (58 against 77 us), but it eliminates with row exchanges, so a
+    // candidate's lpj changed in the last bits when it became a resident state; now every state with 3..4 latents has ONE
+    // arithmetic, the one the fused per-datapoint E-step (kernels_fused.hpp) uses as well)
     if (need[0])
-      sssc_small_kernel<4, 0, TAG, 256><<<level_grid(c, 0, TAG, total, 1024, 256), 256, 0, c->stream>>>(a, i1, o2, PairBins{}, o3);
+      sssc_quad_kernel<1, 0, TAG><<<quad_grid(c, 0, TAG, total, 2048), 256, 0, c->stream>>>(a, i1, o2, o3, PairBins{}, nullptr);
     DBG_SYNC(c, "sssc lpj chain 3..4");
     if (need[1]) sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, i2, o3, o3, PairBins{}, nullptr);
     DBG_SYNC(c, "sssc lpj chain 5..8");
@@ -2250,6 +2278,138 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
   int r = eval_candidates(c);
   if (r) return r;
   c->have_cand = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole E-step of the device-RNG path in ONE call (sssc.py:510-552 / _models.py:497-538 for every datapoint):
+// lpj of K^n, randflip children of n_parents selected parents, their lpj, vary_Kn.  Where the shape allows it (ES3C,
+// complete data, digests, S_perm = 0, at most 64 children, H <= 1024) and K^n is sparse enough, ONE fused kernel does it
+// per datapoint (kernels_fused.hpp); otherwise the separate passes run -- same results bit for bit.
+// ---------------------------------------------------------------------------------------
+static bool fused_shape_ok(const evoamd_ctx *c, int n_parents, int n_children) {
+  return c->model == EVOAMD_MODEL_SSSC && c->S_perm == 0 && !c->mask_infr && c->use_digest && c->dig && census_mode(c) &&
+         c->H <= 1024 && c->H >= 2 && n_parents * n_children <= 64 && n_parents * n_children <= c->Cmax && c->rowF && c->defer;
+}
+
+static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime) {
+  int r = ensure_B(c);
+  if (r) return r;
+  Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, 0, c->flags, KID_LPJ_RES, 0};
+  FusedArgs f = {};
+  f.a = sssc_args(c, b);
+  f.states = c->states;
+  f.dig = c->dig;
+  f.lpj = c->lpj;
+  f.S = c->S;
+  f.n_parents = n_parents;
+  f.n_children = n_children;
+  f.fit_parents = fit_parents;
+  f.Mprime = Mprime;
+  f.seed = seed;
+  f.rowmax = c->rowmax;
+  f.rowsum = c->rowsum;
+  f.rowF = c->rowF;
+  f.rowcnt = c->rowcnt;
+  f.flags_res = c->flags;
+  f.flags_cand = c->flags + c->N;
+  f.defer_items = c->defer;
+  f.defer_count = c->defer + c->N;
+  f.defer_cap = (int)c->N;
+  f.cand = c->cand;
+  f.Cmax = c->Cmax;
+  f.kc_big = 16;
+  const int SPL = c->S <= 64 ? 1 : (c->S <= 128 ? 2 : (c->S <= 256 ? 4 : (c->S <= 512 ? 8 : 16)));
+  const size_t tab = (size_t)4 * c->H * sizeof(double);
+  HIP_TRY(hipMemsetAsync(f.defer_count, 0, sizeof(int), c->stream));
+  SpanGuard g(c, KID_ESTEP_FUSED);
+  {  // FAST: eight waves per workgroup share the staged singleton table; resident grid
+    f.lds_wave_bytes = fused_lds_wave_bytes(c->H, SPL, false, f.kc_big);
+    int W = 8;
+    size_t lds = tab + (size_t)W * f.lds_wave_bytes;
+    while (W > 1 && lds > 150 * 1024) {
+      W >>= 1;
+      lds = tab + (size_t)W * f.lds_wave_bytes;
+    }
+    REQUIRE(lds <= 150 * 1024, "fused E-step: H too large for the LDS rows");
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    per_cu = std::max(1, std::min(per_cu, 16 / W));  // four waves per SIMD
+    const unsigned grid = (unsigned)std::min<i64>(cdiv(c->N, W), (i64)c->n_cu * per_cu);
+#define FUSED_FAST(SPLV) sssc_estep_fused_kernel<SPLV, false><<<grid, 64 * W, lds, c->stream>>>(f)
+    switch (SPL) {
+      case 1: FUSED_FAST(1); break;
+      case 2: FUSED_FAST(2); break;
+      case 4: FUSED_FAST(4); break;
+      case 8: FUSED_FAST(8); break;
+      default: FUSED_FAST(16); break;
+    }
+#undef FUSED_FAST
+    HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "fused E-step (FAST)");
+  }
+  {  // FULL: the datapoints FAST left untouched (count on the device; an empty list costs one launch)
+    f.lds_wave_bytes = fused_lds_wave_bytes(c->H, SPL, true, f.kc_big);
+    int W = 4;
+    size_t lds = tab + (size_t)W * f.lds_wave_bytes;
+    while (W > 1 && lds > 150 * 1024) {
+      W >>= 1;
+      lds = tab + (size_t)W * f.lds_wave_bytes;
+    }
+    REQUIRE(lds <= 150 * 1024, "fused E-step: H too large for the LDS rows");
+    const int per_cu = std::max(1, std::min((int)((160 * 1024) / (lds + 256)), 8 / W));
+    const unsigned grid = (unsigned)std::min<i64>(cdiv(c->N, W), (i64)c->n_cu * per_cu);
+#define FUSED_FULL(SPLV) sssc_estep_fused_kernel<SPLV, true><<<grid, 64 * W, lds, c->stream>>>(f)
+    switch (SPL) {
+      case 1: FUSED_FULL(1); break;
+      case 2: FUSED_FULL(2); break;
+      case 4: FUSED_FULL(4); break;
+      case 8: FUSED_FULL(8); break;
+      default: FUSED_FULL(16); break;
+    }
+#undef FUSED_FULL
+    HIP_TRY(hipGetLastError());
+    DBG_SYNC(c, "fused E-step (FULL)");
+  }
+  fused_reduce3_kernel<<<1, R3_THREADS, 0, c->stream>>>(c->rowF, c->rowcnt, c->N, c->dpar);
+  HIP_TRY(hipGetLastError());
+  DBG_SYNC(c, "fused E-step (reduce)");
+  return 0;
+}
+
+extern "C" int evoamd_estep(evoamd_ctx *c, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime, int *fused_out) {
+  REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
+  REQUIRE(n_parents >= 1 && n_parents <= c->S && n_parents <= 64, "n_parents must be in [1, min(S, 64)]");
+  REQUIRE(n_children >= 1 && n_children <= EV_MAX_CHILDREN && n_children <= c->H, "n_children must be in [1, min(8, H)]");
+  REQUIRE(n_parents * n_children <= c->Cmax, "n_parents * n_children exceeds the configured Cmax");
+  REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
+  HIP_TRY(hipSetDevice(c->device));
+  // Sparse enough: FAST leaves every datapoint that meets a state above four latents to the low-occupancy FULL launch,
+  // and FULL holds at most 16 latents per state -- the census of the last statistics pass decides (K^n grows by at most
+  // one latent per state and iteration, and the host sees every census one iteration late at the latest)
+  bool fused = c->fused_opt != 0 && fused_shape_ok(c, n_parents, n_children);
+  if (fused && c->fused_opt == 1) fused = c->need_known && c->res_cnt[2] == 0.0 && c->res_cnt[1] <= 0.25 * (double)c->N;
+  if (fused && c->need_known && c->res_cnt[2] != 0.0) fused = false;  // (states above eight latents: the separate levels hold 64)
+  if (fused_out) *fused_out = fused ? 1 : 0;
+  if (!fused) {
+    c->unfused_calls++;
+    c->last_estep_fused = false;
+    int r = evoamd_lpj_resident(c);
+    if (r) return r;
+    r = evoamd_evolve_randflip(c, n_parents, n_children, seed, fit_parents);
+    if (r) return r;
+    return evoamd_vary_kn(c, Mprime, nullptr);
+  }
+  c->fused_calls++;
+  c->prefetch_gen = ~0ull;  // a prefetched pass over K^n (if any) is not needed
+  c->rows_fresh = false;
+  int r = launch_estep_fused(c, n_parents, n_children, seed, fit_parents, Mprime);
+  if (r) return r;
+  c->gen++;
+  c->kn_gen++;
+  c->rows_fresh = true;
+  c->have_cand = false;  // the children never left the kernel
+  c->cand_from_device = true;
+  c->last_estep_fused = true;
   return 0;
 }
 
@@ -3192,7 +3352,7 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
     int rr = refresh_after_update(c);
     if (rr) return rr;
   }
-  if (prefetch && c->prefetch_lpj && !c->mask_infr) {
+  if (prefetch && c->prefetch_lpj && !c->mask_infr && !c->last_estep_fused) {  // (a fused E-step evaluates K^n itself)
     // behind the mailbox kernel in stream order: the host is released as soon as that kernel is done
     // the host has not read this iteration's overflow counts yet (they arrive with the mailbox being polled
     // below), so res_need / res_cnt still describe the K^n of the PREVIOUS iteration: conservative levels

@@ -684,6 +684,40 @@ __device__ __forceinline__ void append_end(const ListOut &lo, int shard, const i
   for (int i = threadIdx.x; i < n; i += BS) lo.items[dst + i] = buf[i];
 }
 
+// lpj of a state with at most two active latents from the state-term tables (sssc_tables_kernel): D1t[h] = {mu, L1, G_hh,
+// Lam} of the singleton {h}, `pe` the pair entry of (idx0, idx1) (any entry when k < 2: unused), Bn the datapoint's row of
+// B = Y W (LDS or global).  Identity padding makes the k = 2 expressions exact for k < 2.  ONE function for every kernel
+// that evaluates such states -- the pass over K^n, the candidate batches and the fused per-datapoint E-step
+// (kernels_fused.hpp) -- so that a state has the same lpj bits wherever it is evaluated.
+__device__ __forceinline__ double sssc_k2_value(const int k, const int idx0, const int idx1, const double4 *D1t, const double *Bn,
+                                                const PairEntry &pe, const double yyn, const double s, int *err) {
+  double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
+  double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
+  if (k >= 1) {
+    d0 = D1t[idx0];
+    b0 = Bn[idx0];
+    L = d0.y;
+    l00 = d0.w;
+  }
+  if (k == 2) {
+    d1 = D1t[idx1];
+    b1 = Bn[idx1];
+    g01 = pe.g01;
+    L = pe.L;
+    l00 = pe.l00;
+    l01 = pe.l01;
+    l10 = pe.l10;
+    l11 = pe.l11;
+    // L = +inf with a finite Lam: Psi_A exactly singular -- the reference's own lpj = +inf -> B_max (tables kernel)
+    if (pair_singular_L(pe.L) && pair_singular_lam(pe.l00)) atomicOr(err, 2);
+  }
+  const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
+  const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
+  const double rr = yyn - d0.x * (b0 + v0) - d1.x * (b1 + v1);
+  const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
+  return L - 0.5 * s * (rr - s * quad);
+}
+
 // Main lpj pass in natural order.  A workgroup owns BS consecutive (n, state) pairs, i.e. at most
 // BS / C + 2 consecutive datapoints.  What bounds this pass is neither HBM nor arithmetic but the
 // dependent-latency chain of a workgroup times the number of workgroups a CU can hold (measured at
@@ -796,34 +830,9 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
   for (int p = 0; p < PPT; p++) {
     if (live[p] && !over[p]) {
       const int k = ktot[p];
-      const double *Bn = Bs + (size_t)nloc[p] * a.H;                  // LDS (STAGEB)
-      const double *Bg = a.Bm + (n_first + nloc[p]) * (i64)a.H;       // global (!STAGEB)
-      // identity padding makes the k = 2 expressions exact for k < 2
-      double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
-      double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
-      if (k >= 1) {
-        d0 = D1t[idx0[p]];
-        b0 = STAGEB ? Bn[idx0[p]] : Bg[idx0[p]];
-        L = d0.y;
-        l00 = d0.w;
-      }
-      if (k == 2) {
-        d1 = D1t[idx1[p]];
-        b1 = STAGEB ? Bn[idx1[p]] : Bg[idx1[p]];
-        g01 = pe[p].g01;
-        L = pe[p].L;
-        l00 = pe[p].l00;
-        l01 = pe[p].l01;
-        l10 = pe[p].l10;
-        l11 = pe[p].l11;
-        // L = +inf with a finite Lam: Psi_A exactly singular -- the reference's own lpj = +inf -> B_max (tables kernel)
-        if (pair_singular_L(pe[p].L) && pair_singular_lam(pe[p].l00)) atomicOr(a.err, 2);
-      }
-      const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
-      const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
-      const double rr = yyn[p] - d0.x * (b0 + v0) - d1.x * (b1 + v1);
-      const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
-      const double val = L - 0.5 * s * (rr - s * quad);
+      const double *Bn = STAGEB ? Bs + (size_t)nloc[p] * a.H              // LDS
+                                : a.Bm + (n_first + nloc[p]) * (i64)a.H;  // global
+      const double val = sssc_k2_value(k, idx0[p], idx1[p], D1t, Bn, pe[p], yyn[p], s, a.err);
       unsigned fl = 0;
       const i64 n = n_first + nloc[p];
       a.lpj_out[n * a.ldo + a.col0 + c[p]] = clamp_lpj(val, fl);
@@ -1207,11 +1216,22 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 }
 
 // ---- exact mode of the wavefront kernel (sssc_exact_mode): one wave, k x k matrices in LDS (row-major, stride k) ----
+// WG64: the wave is a whole 64-thread workgroup (sssc_big_kernel) and orders its LDS traffic with lds_barrier(); false: one
+// wave of a larger workgroup (the fused per-datapoint E-step, kernels_fused.hpp) -- a wave's LDS operations execute in
+// order, so a compiler-visible wait for the LDS queue is the whole barrier.
+template <bool WG64>
+__device__ __forceinline__ void big_bar() {
+  if (WG64)
+    lds_barrier();
+  else
+    lds_wave_fence();
+}
 // LU with partial pivoting of M: true when an exactly zero pivot turns up, which is what makes np.linalg.inv raise
 // LinAlgError (dgetrf's info > 0; sssc.py:280).  dgetf2's arithmetic: the first entry of largest magnitude is the pivot
 // (idamax), the column below it is scaled by the RECIPROCAL of the pivot.  Exact for the structural cases -- zero rows,
 // equal rows, exactly dependent small-integer blocks; a matrix whose elimination leaves rounding noise is regular for
 // LAPACK and for this.  M is destroyed; fv: k doubles of scratch.
+template <bool WG64 = true>
 __device__ __forceinline__ bool wave_lu_exactly_singular(double *M, double *fv, int k, int lane) {
   for (int p = 0; p < k; p++) {
     const double v = (lane >= p && lane < k) ? fabs(M[lane * k + p]) : -1.0;
@@ -1224,16 +1244,16 @@ __device__ __forceinline__ bool wave_lu_exactly_singular(double *M, double *fv, 
       M[p * k + lane] = M[piv * k + lane];
       M[piv * k + lane] = t1;
     }
-    lds_barrier();
+    big_bar<WG64>();
     const double r = __ddiv_rn(1.0, M[p * k + p]);
     if (lane > p && lane < k) fv[lane] = M[lane * k + p] * r;
-    lds_barrier();
+    big_bar<WG64>();
     const int mm = k - p - 1;
     for (int q = lane; q < mm * mm; q += 64) {
       const int i = p + 1 + q / mm, j = p + 1 + q % mm;
       M[i * k + j] = fma(-fv[i], M[p * k + j], M[i * k + j]);
     }
-    lds_barrier();
+    big_bar<WG64>();
   }
   return false;
 }
@@ -1242,6 +1262,7 @@ __device__ __forceinline__ bool wave_lu_exactly_singular(double *M, double *fv, 
 // sssc.py:281/300), by one-sided Jacobi: the columns of A are rotated until they are mutually orthogonal, V collects the
 // rotations, so A_in = A_out V^T with A_out's columns = sigma_j u_j and pinv = sum_j v_j a_j^T / sigma_j^2.  Lane i owns
 // row i of A and of V (no barrier inside the sweeps).  A and V are destroyed; out may not alias them.
+template <bool WG64 = true>
 __device__ __forceinline__ void wave_pinv(double *A, double *V, double *out, int k, int lane) {
   const bool mine = lane < k;
   if (mine)
@@ -1278,14 +1299,237 @@ __device__ __forceinline__ void wave_pinv(double *A, double *V, double *out, int
     const bool keep = sqrt(s2) > 1e-15 * sqrt(smax2);
     if (mine) A[lane * k + j] = keep ? a / s2 : 0.0;
   }
-  lds_barrier();
+  big_bar<WG64>();
   if (mine)
     for (int l = 0; l < k; l++) {
       double acc = 0.0;
       for (int j = 0; j < k; j++) acc = fma(V[lane * k + j], A[l * k + j], acc);
       out[lane * k + l] = acc;
     }
-  lds_barrier();
+  big_bar<WG64>();
+}
+
+// The wavefront-per-state evaluation: LDS of one state, sized for kc latents (4 kc^2 + 5 kc doubles + kc ints, big_lds()).
+struct BigLds {
+  double *Tm, *Pm, *Gm, *bv, *muv, *vv, *wv, *fv, *Vm;
+  int *idx;
+  __device__ __forceinline__ void carve(double *lds, int kc) {
+    Tm = lds;
+    Pm = Tm + kc * kc;
+    Gm = Pm + kc * kc;
+    bv = Gm + kc * kc;
+    muv = bv + kc;
+    vv = muv + kc;
+    wv = vv + kc;
+    fv = wv + kc;
+    Vm = fv + kc;  // exact mode only: the rotations of wave_pinv
+    idx = (int *)(Vm + kc * kc);
+  }
+};
+
+// Active latents of the state at `sp` into L.idx (the first kc of them, ascending); returns their number.
+// lane w loads word w (one round trip for the whole state), the loop broadcasts them.
+__device__ __forceinline__ int big_scan(const u64 *sp, int HW, int kc, int *idx, int lane) {
+  int k = 0;
+  u64 myword = 0ull;
+  if (HW <= 64) myword = (lane < HW) ? sp[lane] : 0ull;
+  for (int w = 0; w < HW; w++) {
+    u64 bits;
+    if (HW <= 64) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
+      bits = ((u64)hi << 32) | lo;
+    } else {
+      bits = sp[w];
+    }
+    const bool on = (bits >> (63 - lane)) & 1ull;
+    const u64 m = __ballot(on);
+    const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
+    if (on && pos < kc) idx[pos] = w * 64 + lane;
+    k += __popcll(m);
+  }
+  return k;
+}
+
+// Everything between the latents (L.idx[0..k), k <= kc) and the tails of the two modes: gathers, v, rr, the exact-mode
+// screen of Psi_A, T = I + Psi_A G_A / sigma2, LU with partial pivoting, back substitution.  Returns
+//   0  solved: MODE 0 -> `val` = lpj (not clamped); MODE 1 -> L.wv = Lam v (kappa = wv / sigma2 + mu), L.Pm = Lam, L.muv
+//   2  MODE 0, exact mode, Psi_A exactly singular: lpj = +inf (the caller clamps it to B_max and counts it)
+// Bn: the datapoint's row of B = Y W (global or LDS); n: the datapoint (mask rows of incomplete data).
+template <int MODE, bool WG64>
+__device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const int k, const BigLds &L, const int lane,
+                                         const bool exact, const double *Bn, const double yyn, double &val) {
+  double *Tm = L.Tm, *Pm = L.Pm, *Gm = L.Gm, *bv = L.bv, *muv = L.muv, *vv = L.vv, *wv = L.wv, *fv = L.fv, *Vm = L.Vm;
+  const int *idx = L.idx;
+  big_bar<WG64>();
+  double pb = 0.0;
+  if (lane < k) {
+    const int h = idx[lane];
+    bv[lane] = Bn[h];
+    muv[lane] = a.mus[h];
+    pb = a.pil_bar[h];
+  }
+  pb = wave_sum(pb);
+  for (int q = lane; q < k * k; q += 64) {
+    const int i = q / k, j = q - i * k;
+    const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
+    Gm[q] = gp.x;
+    Pm[q] = gp.y;
+  }
+  if (a.mask) {
+    // incomplete data: G_A of THIS datapoint, W_obs^T W_obs restricted to A -- k (k + 1) / 2 masked dot
+    // products over D, lanes over the observables (rows of W^T are contiguous)
+    big_bar<WG64>();
+    const uint8_t *mrow = a.mask + n * a.D;
+    for (int i = 0; i < k; i++) {
+      const double *wi = a.Wt + (i64)idx[i] * a.D;
+      for (int j = i; j < k; j++) {
+        const double *wj = a.Wt + (i64)idx[j] * a.D;
+        double sdot = 0.0;
+        for (int d = lane; d < a.D; d += 64)
+          if (mrow[d]) sdot = fma(wi[d], wj[d], sdot);
+        sdot = wave_sum(sdot);
+        if (lane == 0) {
+          Gm[i * k + j] = sdot;
+          Gm[j * k + i] = sdot;
+        }
+      }
+    }
+  }
+  big_bar<WG64>();
+  double rr_part = 0.0;
+  if (lane < k) {
+    double s = bv[lane];
+    for (int j = 0; j < k; j++) s -= Gm[lane * k + j] * muv[j];
+    vv[lane] = s;
+    rr_part = muv[lane] * (bv[lane] + s);
+  }
+  const double rr = yyn - wave_sum(rr_part);
+  big_bar<WG64>();
+  bool psing = false;
+  if (exact && k > 0) {  // is Psi_A exactly singular (np.linalg.inv raises, sssc.py:280)?
+    for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
+    big_bar<WG64>();
+    psing = wave_lu_exactly_singular<WG64>(Tm, fv, k, lane);
+    big_bar<WG64>();
+  }
+  bool solved = false;
+  if (psing) {
+    // the reference goes on with pinv(Psi_A) and slogdet(Psi_A) = -inf: C_det = -inf, lpj = +inf, which lpj_reset_check
+    // turns into B_max (sssc.py:281-305, _models.py:589); its statistics read Lam = inv(M_A), M_A = G_A / sigma2 +
+    // pinv(Psi_A) -- pinv(M_A) when that is exactly singular too (sssc.py:296-300) -- and kappa = mu + Lam v / sigma2
+    if (MODE == 0) return 2;  // uniform
+    for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
+    big_bar<WG64>();
+    wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
+    for (int q = lane; q < k * k; q += 64) {
+      const double mq = a.s2inv * Gm[q] + Pm[q];
+      Gm[q] = mq;  // M_A (G_A is not read again)
+      Tm[q] = mq;
+    }
+    big_bar<WG64>();
+    const bool msing = wave_lu_exactly_singular<WG64>(Tm, fv, k, lane);
+    big_bar<WG64>();
+    for (int q = lane; q < k * k; q += 64) Tm[q] = Gm[q];
+    big_bar<WG64>();
+    if (msing) {
+      wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
+      if (lane < k) {
+        double s = 0.0;
+        for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+        wv[lane] = s;
+      }
+      solved = true;
+    } else {  // the elimination below with M_A in the place of T and the identity in the place of Psi_A: Pm = inv(M_A)
+      for (int q = lane; q < k * k; q += 64) Pm[q] = (q / k == q % k) ? 1.0 : 0.0;
+      if (lane < k) wv[lane] = vv[lane];
+    }
+  } else {
+    if (lane < k) {
+      double s = 0.0;
+      for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+      wv[lane] = s;
+    }
+    for (int q = lane; q < k * k; q += 64) {
+      const int i = q / k, j = q - i * k;
+      double tt = 0.0;
+      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
+      Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+    }
+  }
+  big_bar<WG64>();
+  // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
+  bool singular = false;
+  for (int p = 0; p < (solved ? 0 : k); p++) {
+    // pivot: |column p| with 63 - row in the low 6 mantissa bits, one DPP max-reduce
+    double key = -1.0;
+    if (lane >= p && lane < k) {
+      const unsigned long long bits =
+          ((unsigned long long)__double_as_longlong(fabs(Tm[lane * k + p])) & ~0x3FULL) | (unsigned long long)(63 - lane);
+      key = __longlong_as_double((long long)bits);
+    }
+    key = wave_max(key);
+    const int piv = 63 - (int)((unsigned long long)__double_as_longlong(key) & 0x3FULL);
+    if (piv != p) {
+      if (lane < k) {
+        const double t1 = Tm[p * k + lane];
+        Tm[p * k + lane] = Tm[piv * k + lane];
+        Tm[piv * k + lane] = t1;
+        if (MODE == 1) {
+          const double t2 = Pm[p * k + lane];
+          Pm[p * k + lane] = Pm[piv * k + lane];
+          Pm[piv * k + lane] = t2;
+        }
+      }
+      if (lane == 0) {
+        const double t3 = wv[p];
+        wv[p] = wv[piv];
+        wv[piv] = t3;
+      }
+    }
+    big_bar<WG64>();
+    const double d = Tm[p * k + p];
+    if (d == 0.0) singular = true;
+    const double r = fast_rcp(d);
+    if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
+    big_bar<WG64>();
+    const int m = k - p - 1;
+    for (int q = lane; q < m * m; q += 64) {
+      const int i = p + 1 + q / m, j = p + 1 + q % m;
+      Tm[i * k + j] -= fv[i] * Tm[p * k + j];
+    }
+    if (MODE == 1) {
+      for (int q = lane; q < m * k; q += 64) {
+        const int i = p + 1 + q / k, j = q % k;
+        Pm[i * k + j] -= fv[i] * Pm[p * k + j];
+      }
+    }
+    if (lane > p && lane < k) wv[lane] -= fv[lane] * wv[p];
+    big_bar<WG64>();
+  }
+  double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
+  const double logdet = wave_sum(ld);
+  // ---- back substitution, column oriented
+  for (int p = (solved ? 0 : k) - 1; p >= 0; p--) {
+    const double r = fast_rcp(Tm[p * k + p]);
+    if (lane == 0) wv[p] *= r;
+    if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
+    big_bar<WG64>();
+    if (lane < p) wv[lane] -= Tm[lane * k + p] * wv[p];
+    if (MODE == 1) {
+      for (int q = lane; q < p * k; q += 64) {
+        const int i = q / k, j = q % k;
+        Pm[i * k + j] -= Tm[i * k + p] * Pm[p * k + j];
+      }
+    }
+    big_bar<WG64>();
+  }
+  if (singular && lane == 0) atomicOr(a.err, 2);
+  if (MODE == 0) {
+    const double quad = wave_sum((lane < k) ? vv[lane] * wv[lane] : 0.0);
+    val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
+  }
+  return 0;
 }
 
 // One wavefront (64-thread workgroup) per listed pair, the k x k system in LDS, lanes over matrix
@@ -1305,16 +1549,8 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int prefix2[LIST_SHARDS + 1];
   extern __shared__ double lds[];
-  double *Tm = lds;
-  double *Pm = Tm + kc * kc;
-  double *Gm = Pm + kc * kc;
-  double *bv = Gm + kc * kc;
-  double *muv = bv + kc;
-  double *vv = muv + kc;
-  double *wv = vv + kc;
-  double *fv = wv + kc;
-  double *Vm = fv + kc;  // exact mode only: the rotations of wave_pinv
-  int *idx = (int *)(Vm + kc * kc);
+  BigLds L;
+  L.carve(lds, kc);
   const int lane = threadIdx.x;
   const bool exact = sssc_exact_mode(a);
   const i64 total1 = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
@@ -1327,31 +1563,16 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     if (a.counts && c >= a.counts[n]) continue;  // uniform
     const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
     lds_barrier();
-    int k = 0;
-    // lane w loads word w (one round trip for the whole state), the loop broadcasts them
-    u64 myword = 0ull;
-    if (a.HW <= 64) myword = (lane < a.HW) ? sp[lane] : 0ull;
-    for (int w = 0; w < a.HW; w++) {
-      u64 bits;
-      if (a.HW <= 64) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
-        bits = ((u64)hi << 32) | lo;
-      } else {
-        bits = sp[w];
-      }
-      const bool on = (bits >> (63 - lane)) & 1ull;
-      const u64 m = __ballot(on);
-      const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
-      if (on && pos < kc) idx[pos] = w * 64 + lane;
-      k += __popcll(m);
-    }
+    const int k = big_scan(sp, a.HW, kc, L.idx, lane);
     if (k > kc) {  // uniform
       if (lane == 0) {
         if (lo.items) {
           const int shard = (int)(t & (LIST_SHARDS - 1));
           const int pos = atomicAdd(&lo.counts[shard], 1);
-          if (pos < lo.cap) lo.items[(i64)shard * lo.cap + pos] = (int)e;
+          if (pos < lo.cap)
+            lo.items[(i64)shard * lo.cap + pos] = (int)e;
+          else
+            atomicOr(a.err, EVO_ERR_LIST_FULL);
         } else {
           atomicOr(a.err, 1);
           if (MODE == 0) a.lpj_out[n * a.ldo + a.col0 + c] = EVO_F64_MIN;
@@ -1366,193 +1587,22 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       if (q == 0.0) continue;  // uniform
       qn = q / (a.rowsum[n] + EVO_F64_TINY);
     }
-    lds_barrier();
-    const double *Bn = a.Bm + n * a.H;
-    double pb = 0.0;
-    if (lane < k) {
-      const int h = idx[lane];
-      bv[lane] = Bn[h];
-      muv[lane] = a.mus[h];
-      pb = a.pil_bar[h];
-    }
-    pb = wave_sum(pb);
-    for (int q = lane; q < k * k; q += 64) {
-      const int i = q / k, j = q - i * k;
-      const double2 gp = a.GP[(i64)idx[i] * a.H + idx[j]];
-      Gm[q] = gp.x;
-      Pm[q] = gp.y;
-    }
-    if (a.mask) {
-      // incomplete data: G_A of THIS datapoint, W_obs^T W_obs restricted to A -- k (k + 1) / 2 masked dot
-      // products over D, lanes over the observables (rows of W^T are contiguous)
-      lds_barrier();
-      const uint8_t *mrow = a.mask + n * a.D;
-      for (int i = 0; i < k; i++) {
-        const double *wi = a.Wt + (i64)idx[i] * a.D;
-        for (int j = i; j < k; j++) {
-          const double *wj = a.Wt + (i64)idx[j] * a.D;
-          double sdot = 0.0;
-          for (int d = lane; d < a.D; d += 64)
-            if (mrow[d]) sdot = fma(wi[d], wj[d], sdot);
-          sdot = wave_sum(sdot);
-          if (lane == 0) {
-            Gm[i * k + j] = sdot;
-            Gm[j * k + i] = sdot;
-          }
-        }
-      }
-    }
-    lds_barrier();
-    double rr_part = 0.0;
-    if (lane < k) {
-      double s = bv[lane];
-      for (int j = 0; j < k; j++) s -= Gm[lane * k + j] * muv[j];
-      vv[lane] = s;
-      rr_part = muv[lane] * (bv[lane] + s);
-    }
-    const double rr = a.yy[n] - wave_sum(rr_part);
-    lds_barrier();
-    bool psing = false;
-    if (exact && k > 0) {  // is Psi_A exactly singular (np.linalg.inv raises, sssc.py:280)?
-      for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
-      lds_barrier();
-      psing = wave_lu_exactly_singular(Tm, fv, k, lane);
-      lds_barrier();
-    }
-    bool solved = false;
-    if (psing) {
-      // the reference goes on with pinv(Psi_A) and slogdet(Psi_A) = -inf: C_det = -inf, lpj = +inf, which lpj_reset_check
-      // turns into B_max (sssc.py:281-305, _models.py:589); its statistics read Lam = inv(M_A), M_A = G_A / sigma2 +
-      // pinv(Psi_A) -- pinv(M_A) when that is exactly singular too (sssc.py:296-300) -- and kappa = mu + Lam v / sigma2
-      if (MODE == 0) {
-        if (lane == 0) {
-          unsigned fl = 0;
-          a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(__builtin_inf(), fl);
-          atomicOr(&a.flags[n], fl);
-          atomicOr(&a.err[1], 1);
-        }
-        continue;  // uniform
-      }
-      for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
-      lds_barrier();
-      wave_pinv(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
-      for (int q = lane; q < k * k; q += 64) {
-        const double mq = a.s2inv * Gm[q] + Pm[q];
-        Gm[q] = mq;  // M_A (G_A is not read again)
-        Tm[q] = mq;
-      }
-      lds_barrier();
-      const bool msing = wave_lu_exactly_singular(Tm, fv, k, lane);
-      lds_barrier();
-      for (int q = lane; q < k * k; q += 64) Tm[q] = Gm[q];
-      lds_barrier();
-      if (msing) {
-        wave_pinv(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
-        if (lane < k) {
-          double s = 0.0;
-          for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
-          wv[lane] = s;
-        }
-        solved = true;
-      } else {  // the elimination below with M_A in the place of T and the identity in the place of Psi_A: Pm = inv(M_A)
-        for (int q = lane; q < k * k; q += 64) Pm[q] = (q / k == q % k) ? 1.0 : 0.0;
-        if (lane < k) wv[lane] = vv[lane];
-      }
-    } else {
-      if (lane < k) {
-        double s = 0.0;
-        for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
-        wv[lane] = s;
-      }
-      for (int q = lane; q < k * k; q += 64) {
-        const int i = q / k, j = q - i * k;
-        double tt = 0.0;
-        for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
-        Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
-      }
-    }
-    lds_barrier();
-    // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
-    bool singular = false;
-    for (int p = 0; p < (solved ? 0 : k); p++) {
-      // pivot: |column p| with 63 - row in the low 6 mantissa bits, one DPP max-reduce
-      double key = -1.0;
-      if (lane >= p && lane < k) {
-        const unsigned long long bits =
-            ((unsigned long long)__double_as_longlong(fabs(Tm[lane * k + p])) & ~0x3FULL) | (unsigned long long)(63 - lane);
-        key = __longlong_as_double((long long)bits);
-      }
-      key = wave_max(key);
-      const int piv = 63 - (int)((unsigned long long)__double_as_longlong(key) & 0x3FULL);
-      if (piv != p) {
-        if (lane < k) {
-          const double t1 = Tm[p * k + lane];
-          Tm[p * k + lane] = Tm[piv * k + lane];
-          Tm[piv * k + lane] = t1;
-          if (MODE == 1) {
-            const double t2 = Pm[p * k + lane];
-            Pm[p * k + lane] = Pm[piv * k + lane];
-            Pm[piv * k + lane] = t2;
-          }
-        }
-        if (lane == 0) {
-          const double t3 = wv[p];
-          wv[p] = wv[piv];
-          wv[piv] = t3;
-        }
-      }
-      lds_barrier();
-      const double d = Tm[p * k + p];
-      if (d == 0.0) singular = true;
-      const double r = fast_rcp(d);
-      if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
-      lds_barrier();
-      const int m = k - p - 1;
-      for (int q = lane; q < m * m; q += 64) {
-        const int i = p + 1 + q / m, j = p + 1 + q % m;
-        Tm[i * k + j] -= fv[i] * Tm[p * k + j];
-      }
-      if (MODE == 1) {
-        for (int q = lane; q < m * k; q += 64) {
-          const int i = p + 1 + q / k, j = q % k;
-          Pm[i * k + j] -= fv[i] * Pm[p * k + j];
-        }
-      }
-      if (lane > p && lane < k) wv[lane] -= fv[lane] * wv[p];
-      lds_barrier();
-    }
-    double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
-    const double logdet = wave_sum(ld);
-    // ---- back substitution, column oriented
-    for (int p = (solved ? 0 : k) - 1; p >= 0; p--) {
-      const double r = fast_rcp(Tm[p * k + p]);
-      if (lane == 0) wv[p] *= r;
-      if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
-      lds_barrier();
-      if (lane < p) wv[lane] -= Tm[lane * k + p] * wv[p];
-      if (MODE == 1) {
-        for (int q = lane; q < p * k; q += 64) {
-          const int i = q / k, j = q % k;
-          Pm[i * k + j] -= Tm[i * k + p] * Pm[p * k + j];
-        }
-      }
-      lds_barrier();
-    }
-    if (singular && lane == 0) atomicOr(a.err, 2);
+    double val = 0.0;
+    const int rc = big_solve<MODE, true>(a, n, k, L, lane, exact, a.Bm + n * a.H, a.yy[n], val);
     if (MODE == 0) {
-      const double quad = wave_sum((lane < k) ? vv[lane] * wv[lane] : 0.0);
       if (lane == 0) {
-        const double val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
         unsigned fl = 0;
-        a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(val, fl);
+        a.lpj_out[n * a.ldo + a.col0 + c] = clamp_lpj(rc == 2 ? __builtin_inf() : val, fl);
         if (fl) {
           atomicOr(&a.flags[n], fl);
           atomicOr(&a.err[1], 1);
         }
       }
     } else {
+      double *Pm = L.Pm, *fv = L.fv;
+      const int *idx = L.idx;
       if (lane < k) {
-        const double kap = wv[lane] * a.s2inv + muv[lane];
+        const double kap = L.wv[lane] * a.s2inv + L.muv[lane];
         fv[lane] = kap;
         unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
         unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);

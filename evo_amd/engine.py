@@ -209,6 +209,14 @@ class Engine:
         check(self.lib.evoamd_evolve_randflip(self._h, int(n_parents), int(n_children), int(seed) & (2 ** 64 - 1),
                                               1 if fit_parents else 0))
 
+    def estep(self, n_parents, n_children, seed, fit_parents, Mprime):
+        """lpj of K^n -> randflip children -> their lpj -> vary_Kn in one library call (one fused kernel where the shape
+        allows it, else the separate passes; same results).  Returns True when the fused kernel ran."""
+        fused = ctypes.c_int(0)
+        check(self.lib.evoamd_estep(self._h, int(n_parents), int(n_children), int(seed) & (2 ** 64 - 1),
+                                    1 if fit_parents else 0, int(Mprime), ctypes.byref(fused)))
+        return bool(fused.value)
+
     MUTATIONS = {"randflip": 0, "sparseflip": 1, "cross": 2, "cross_randflip": 3, "cross_sparseflip": 4}
 
     def evolve_states(self, mutation, n_parents, n_children, n_generations, seed, fit_parents=True, sparseness=0.0,

@@ -383,12 +383,7 @@ class Model:
         if model_params is not self._dev_theta:  # new host Theta: clamp, precompute, upload
             model_params = self.check_params(model_params)
             self.E_step_precompute(model_params, my_suff_stat, my_data)
-        eng.lpj_resident()
-        if self.rng == "reference":
-            self._candidates_reference(eng, model_params, my_suff_stat, my_data)
-        else:
-            self._candidates_device(eng, my_suff_stat, model_params)
-        eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
+        self._estep_kernels(eng, model_params, my_suff_stat, my_data)
         self._n_steps += 1
         if self._incomplete and do_reconstruction:
             # y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211): formed inside the statistics pass
@@ -603,6 +598,29 @@ class Model:
     _MUTATION_NAMES = {eas.randflip: "randflip", eas.sparseflip: "sparseflip", eas.cross: "cross",
                        eas.cross_randflip: "cross_randflip", eas.cross_sparseflip: "cross_sparseflip"}
 
+    def _device_seed(self):
+        return (self.seed * 1000003 + self._n_steps) * max(1, self.comm.size) + self.comm.rank
+
+    def _estep_kernels(self, eng, model_params, my_suff_stat, my_data):
+        """The body of the reference's per-datapoint E-step loop (_models.py:497-538 / sssc.py:510-552) for all datapoints
+        of this rank: lpj of K^n -> evolve_states -> lpj of the new states -> vary_Kn.  rng="device" with the examples'
+        EA (randflip, one generation) is ONE library call, which runs the fused wave-per-datapoint kernel where the shape
+        allows it (csrc/kernels_fused.hpp) and the separate passes otherwise -- same K^n, same lpj bits."""
+        mut = my_suff_stat.get("mutation_algorithm")
+        if (self.rng == "device" and mut is eas.randflip and my_suff_stat["n_generations"] == 1
+                and my_suff_stat["n_children"] <= 8 and my_suff_stat["parent_selection"] in (eas.fitparents, eas.randparents)):
+            n_par = min(my_suff_stat["n_parents"], self.S)
+            self.last_estep_fused = eng.estep(n_par, my_suff_stat["n_children"], self._device_seed(),
+                                              my_suff_stat["parent_selection"] is eas.fitparents, my_suff_stat["Mprime"])
+            return
+        self.last_estep_fused = False
+        eng.lpj_resident()
+        if self.rng == "reference":
+            self._candidates_reference(eng, model_params, my_suff_stat, my_data)
+        else:
+            self._candidates_device(eng, my_suff_stat, model_params)
+        eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
+
     def _candidates_device(self, eng, my_suff_stat, model_params):
         """evolve_states (eas.py:153-313) on the device, every operator and any number of generations."""
         mut = my_suff_stat["mutation_algorithm"]
@@ -611,7 +629,7 @@ class Model:
         fit = my_suff_stat["parent_selection"] is eas.fitparents
         if not fit and my_suff_stat["parent_selection"] is not eas.randparents:
             raise NotImplementedError("rng='device' knows fitparents and randparents")
-        seed = (self.seed * 1000003 + self._n_steps) * max(1, self.comm.size) + self.comm.rank
+        seed = self._device_seed()
         n_par = min(my_suff_stat["n_parents"], self.S)
         if mut is eas.randflip and my_suff_stat["n_generations"] == 1 and my_suff_stat["n_children"] <= 8:
             eng.evolve_randflip(n_par, my_suff_stat["n_children"], seed, fit)  # the examples' default: fast path
@@ -625,12 +643,7 @@ class Model:
         ``sync_host`` (always in rng="reference" mode)."""
         eng = self._prepare(my_suff_stat, my_data)
         self.E_step_precompute(model_params, my_suff_stat, my_data)
-        eng.lpj_resident()
-        if self.rng == "reference":
-            self._candidates_reference(eng, model_params, my_suff_stat, my_data)
-        else:
-            self._candidates_device(eng, my_suff_stat, model_params)
-        eng.vary_kn(my_suff_stat["Mprime"], want_sums=False)
+        self._estep_kernels(eng, model_params, my_suff_stat, my_data)
         self._n_steps += 1
         if self._incomplete and _reconstruct:
             # incomplete data: y_reconstructed feeds this very M-step's Wp (bsc.py:184-189,211), so the

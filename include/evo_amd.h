@@ -148,6 +148,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "sk_spare" (-1 = automatic (default), 0 .. 32): workgroups per XCD that the long-K contraction does not launch while it
  * runs on the second stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free
  * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8).
+ * "fused_estep" (0 / 1 / 2, default 1): evoamd_estep runs the fused per-datapoint kernel never / when the census of the last
+ * statistics pass says K^n is sparse (no state above eight latents, states above four in at most a quarter of the datapoints)
+ * / whenever the shape allows it.
  * "debug_poison_list" (one-shot, tests): the next census of the resident K^n gets an out-of-range entry.  Every list entry
  * and every latent index that crosses LDS is range-checked before it becomes an address, so the pass that reads the entry
  * ends in EVOAMD_E_INVALID ("... out of range") instead of a memory fault; the census is rebuilt afterwards. */
@@ -335,6 +338,15 @@ int evoamd_get_params_sssc(evoamd_ctx *ctx, double *W, double *pies, double *mus
  * (sssc.py:692-708, bsc.py:236-250), which start from the OLD Theta.  evoamd_get_params_* then reads them; the derived
  * tables are rebuilt by the next evoamd_set_params_*. */
 int evoamd_restore_theta_backup(evoamd_ctx *ctx);
+/* The whole E-step of the device-RNG path in one call -- the body of the reference's per-datapoint loop
+ * (evo/models/_models.py:497-538, evo/models/sssc.py:510-552) for every datapoint of the shard: lpj of the resident K^n
+ * (log_pseudo_joint), evolve_states with fitparents / randparents + randflip x 1 generation (evo/variational/eas.py:153-313),
+ * lpj of the children, vary_Kn (evo/variational/utils.py:231-337); K^n, lpj rows and the row statistics of the M-step are
+ * updated in place, the free-energy term and the counters go to the scalar block.  Equivalent to evoamd_lpj_resident +
+ * evoamd_evolve_randflip + evoamd_vary_kn with the same arguments, bit for bit; where the shape allows it (ES3C, complete
+ * data, digests, S_perm = 0, <= 64 children, H <= 1024; option "fused_estep") ONE kernel does it with a wave per datapoint.
+ * *fused_out (may be NULL): 1 if the fused kernel ran. */
+int evoamd_estep(evoamd_ctx *ctx, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime, int *fused_out);
 /* Fs only (sum_n logsumexp) of an arbitrary host lpj matrix (N,C) -- exact-likelihood path. */
 int evoamd_free_energy(evoamd_ctx *ctx, const double *lpj, int64_t N, int C, double *Fs_out);
 /* Adds the E-step scalars produced outside evoamd_stats (e.g. host-side vary_Kn counts)
