@@ -1407,7 +1407,7 @@ extern "C" int evoamd_set_params_bsc(evoamd_ctx *c, const double *W, double pi, 
   HIP_TRY(hipMemcpyAsync(c->W, wt, (size_t)c->D * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
   c->B_valid = false;
   if (!c->bsc_direct) {
-    int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D);  // G = W^T W
+    int r = launch_gemm_tn(c, c->W, c->H, c->W, c->H, c->G, c->H, c->H, c->H, c->D, /*deterministic=*/true);  // G = W^T W (no split-K atomics: the same Theta gives the same G, tables and lpj bits every time)
     if (r) return r;
     extract_diag_kernel<<<cdiv(c->H, 256), 256, 0, c->stream>>>(c->G, c->H, c->diag);
     if (c->have_data) {
@@ -1478,7 +1478,7 @@ extern "C" int evoamd_set_params_sssc(evoamd_ctx *c, const double *W, const doub
     HIP_TRY(hipMemcpyAsync(c->mus, hmu, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->pilbar_v, hpb, (size_t)H * sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
-  int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D);  // G = W^T W
+  int r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, /*deterministic=*/true);  // G = W^T W (no split-K atomics: the same Theta gives the same G, tables and lpj bits every time)
   if (r) return r;
   DBG_SYNC(c, "set_params_sssc: G = W^T W");
   sssc_tables_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->G, c->Psi, c->mus, c->pilbar_v, c->dpar, H, c->D1,

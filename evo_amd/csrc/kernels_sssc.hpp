@@ -691,6 +691,7 @@ __device__ __forceinline__ void append_end(const ListOut &lo, int shard, const i
 // (kernels_fused.hpp) -- so that a state has the same lpj bits wherever it is evaluated.
 __device__ __forceinline__ double sssc_k2_value(const int k, const int idx0, const int idx1, const double4 *D1t, const double *Bn,
                                                 const PairEntry &pe, const double yyn, const double s, int *err) {
+#pragma clang fp contract(off)
   double4 d0 = make_double4(0.0, 0.0, 0.0, 0.0), d1 = make_double4(0.0, 0.0, 0.0, 0.0);  // mu, L1, G_hh, Lam
   double b0 = 0.0, b1 = 0.0, g01 = 0.0, L = 0.0, l00 = 0.0, l01 = 0.0, l10 = 0.0, l11 = 0.0;
   if (k >= 1) {
@@ -711,11 +712,15 @@ __device__ __forceinline__ double sssc_k2_value(const int k, const int idx0, con
     // L = +inf with a finite Lam: Psi_A exactly singular -- the reference's own lpj = +inf -> B_max (tables kernel)
     if (pair_singular_L(pe.L) && pair_singular_lam(pe.l00)) atomicOr(err, 2);
   }
-  const double v0 = b0 - d0.z * d0.x - g01 * d1.x;
-  const double v1 = b1 - g01 * d0.x - d1.z * d1.x;
-  const double rr = yyn - d0.x * (b0 + v0) - d1.x * (b1 + v1);
-  const double quad = v0 * (l00 * v0 + l01 * v1) + v1 * (l10 * v0 + l11 * v1);
-  return L - 0.5 * s * (rr - s * quad);
+  // Every product-sum is an explicit fma and implicit contraction is off: which products the compiler fuses would
+  // otherwise depend on the kernel the function is inlined into, and the fused E-step must reproduce the separate
+  // passes bit for bit (round 4; measured before: 8-12 % of the values differed in the last bit between two kernels).
+  const double v0 = fma(-g01, d1.x, fma(-d0.z, d0.x, b0));
+  const double v1 = fma(-d1.z, d1.x, fma(-g01, d0.x, b1));
+  const double rr = fma(-d1.x, b1 + v1, fma(-d0.x, b0 + v0, yyn));
+  const double t0 = fma(l01, v1, l00 * v0), t1 = fma(l11, v1, l10 * v0);
+  const double quad = fma(v1, t1, v0 * t0);
+  return fma(-0.5 * s, fma(-s, quad, rr), L);
 }
 
 // Main lpj pass in natural order.  A workgroup owns BS consecutive (n, state) pairs, i.e. at most
@@ -1359,6 +1364,7 @@ __device__ __forceinline__ int big_scan(const u64 *sp, int HW, int kc, int *idx,
 template <int MODE, bool WG64>
 __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const int k, const BigLds &L, const int lane,
                                          const bool exact, const double *Bn, const double yyn, double &val) {
+#pragma clang fp contract(off)  // (explicit fma only: the same bits in every kernel this is inlined into)
   double *Tm = L.Tm, *Pm = L.Pm, *Gm = L.Gm, *bv = L.bv, *muv = L.muv, *vv = L.vv, *wv = L.wv, *fv = L.fv, *Vm = L.Vm;
   const int *idx = L.idx;
   big_bar<WG64>();
@@ -1400,7 +1406,7 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
   double rr_part = 0.0;
   if (lane < k) {
     double s = bv[lane];
-    for (int j = 0; j < k; j++) s -= Gm[lane * k + j] * muv[j];
+    for (int j = 0; j < k; j++) s = fma(-Gm[lane * k + j], muv[j], s);
     vv[lane] = s;
     rr_part = muv[lane] * (bv[lane] + s);
   }
@@ -1423,7 +1429,7 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
     big_bar<WG64>();
     wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
     for (int q = lane; q < k * k; q += 64) {
-      const double mq = a.s2inv * Gm[q] + Pm[q];
+      const double mq = fma(a.s2inv, Gm[q], Pm[q]);
       Gm[q] = mq;  // M_A (G_A is not read again)
       Tm[q] = mq;
     }
@@ -1436,7 +1442,7 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
       wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
       if (lane < k) {
         double s = 0.0;
-        for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+        for (int j = 0; j < k; j++) s = fma(Pm[lane * k + j], vv[j], s);
         wv[lane] = s;
       }
       solved = true;
@@ -1447,14 +1453,14 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
   } else {
     if (lane < k) {
       double s = 0.0;
-      for (int j = 0; j < k; j++) s += Pm[lane * k + j] * vv[j];
+      for (int j = 0; j < k; j++) s = fma(Pm[lane * k + j], vv[j], s);
       wv[lane] = s;
     }
     for (int q = lane; q < k * k; q += 64) {
       const int i = q / k, j = q - i * k;
       double tt = 0.0;
-      for (int l = 0; l < k; l++) tt += Pm[i * k + l] * Gm[l * k + j];
-      Tm[q] = ((i == j) ? 1.0 : 0.0) + a.s2inv * tt;
+      for (int l = 0; l < k; l++) tt = fma(Pm[i * k + l], Gm[l * k + j], tt);
+      Tm[q] = fma(a.s2inv, tt, (i == j) ? 1.0 : 0.0);
     }
   }
   big_bar<WG64>();
@@ -1496,15 +1502,15 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
     const int m = k - p - 1;
     for (int q = lane; q < m * m; q += 64) {
       const int i = p + 1 + q / m, j = p + 1 + q % m;
-      Tm[i * k + j] -= fv[i] * Tm[p * k + j];
+      Tm[i * k + j] = fma(-fv[i], Tm[p * k + j], Tm[i * k + j]);
     }
     if (MODE == 1) {
       for (int q = lane; q < m * k; q += 64) {
         const int i = p + 1 + q / k, j = q % k;
-        Pm[i * k + j] -= fv[i] * Pm[p * k + j];
+        Pm[i * k + j] = fma(-fv[i], Pm[p * k + j], Pm[i * k + j]);
       }
     }
-    if (lane > p && lane < k) wv[lane] -= fv[lane] * wv[p];
+    if (lane > p && lane < k) wv[lane] = fma(-fv[lane], wv[p], wv[lane]);
     big_bar<WG64>();
   }
   double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
@@ -1515,11 +1521,11 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
     if (lane == 0) wv[p] *= r;
     if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
     big_bar<WG64>();
-    if (lane < p) wv[lane] -= Tm[lane * k + p] * wv[p];
+    if (lane < p) wv[lane] = fma(-Tm[lane * k + p], wv[p], wv[lane]);
     if (MODE == 1) {
       for (int q = lane; q < p * k; q += 64) {
         const int i = q / k, j = q % k;
-        Pm[i * k + j] -= Tm[i * k + p] * Pm[p * k + j];
+        Pm[i * k + j] = fma(-Tm[i * k + p], Pm[p * k + j], Pm[i * k + j]);
       }
     }
     big_bar<WG64>();

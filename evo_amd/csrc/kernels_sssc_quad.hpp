@@ -127,6 +127,7 @@ template <int C, int MODE>
 __device__ __forceinline__ void quad_solve(const SsscArgs &a, const int t, const int k, const int (&idx)[4 * C],
                                            const int (&cidx)[C], const double *__restrict__ Bn, const double yyn,
                                            double &val, bool &hard, double (&kap_all)[4 * C], double (&Lam)[4 * C][C]) {
+#pragma clang fp contract(off)  // explicit fma only: the same bits in the list kernels and in the fused E-step (kernels_fused.hpp)
   constexpr int K = 4 * C;
   const double s = a.s2inv;
   const int H = a.H;
