@@ -592,7 +592,7 @@ def main():
     kernel_ms = {}
     for name in ("lpj_resident", "lpj_candidates", "lpj_overflow", "row_lse", "vary_kn", "stats", "stats_overflow",
                  "gemm_f64", "evolve", "misc", "mstep_device", "lpj_pass", "stats_pass", "lpj_k3_4", "lpj_k5_8", "lpj_k9plus",
-                 "stats_k3_4", "stats_k5_8", "stats_k9plus"):
+                 "stats_k3_4", "stats_k5_8", "stats_k9plus", "estep_fused", "allreduce"):
         avg, n = eng.kernel_time_ms(name)
         if n:
             kernel_ms[name] = {"avg_ms": round(avg, 6), "launches_per_iteration": n / prof_iters}
@@ -609,6 +609,7 @@ def main():
     eng.timing(False)
     F, nu, nsub = F_timed, nu_timed, nsub_timed
 
+    estep_diag = eng.estep_counters() if cfg["algo"] == "es3c" else None
     if rank == 0:
         total_iters = args.steps * iters
         evals = float(cfg["N"]) * cfg["S"] * total_iters
@@ -699,6 +700,7 @@ def main():
                                 "lazy view (resident on the device; downloaded when read, never in the timed loop)",
                        "sharding": "np.array_split over N (evo/utils/parallel.py:102-112), one packed RCCL all-reduce per iteration",
                        "free_energy_last": F, "S_nunique_last": nu, "S_sub_last": nsub, "setup_s": round(t_setup, 1),
+                       "estep": estep_diag,
                        "kernel_ms": kernel_ms,
                        "kernel_ms_note": "per-class HIP-event times from %d extra instrumented iterations after the timed region" % prof_iters},
             "roofline": r_lpj, "roofline_stats": r_st,

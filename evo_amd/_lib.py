@@ -56,6 +56,7 @@ SIGNATURES = {
     "evoamd_vary_kn": (_I, [_vp, _I, _c_dp]),
     "evoamd_evolve_randflip": (_I, [_vp, _I, _I, _U64, _I]),
     "evoamd_estep": (_I, [_vp, _I, _I, _U64, _I, _I, ctypes.POINTER(_I)]),
+    "evoamd_estep_counters": (_I, [_vp, ctypes.POINTER(_I64)]),
     "evoamd_evolve_states": (_I, [_vp, _I, _I, _I, _I, _I, _U64, _DBL, _DBL]),
     "evoamd_download_candidates": (_I, [_vp, _c_u8p, _c_i32p, _c_dp]),
     "evoamd_acc_size": (_I64, [_vp]),

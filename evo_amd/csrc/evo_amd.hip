@@ -323,6 +323,7 @@ struct evoamd_ctx {
   int fused_opt = 1;
   double *rowF = nullptr;
   int *rowcnt = nullptr, *defer = nullptr;
+  double *fpart = nullptr;  // 3 x 1024 chain sums of fused_reduce3_kernel
   bool last_estep_fused = false;
   long fused_calls = 0, unfused_calls = 0;
   int debug_poison_list = 0;  // option "debug_poison_list" (tests): the next census gets an out-of-range entry
@@ -533,7 +534,7 @@ static void free_all(evoamd_ctx *c) {
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
                   c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf,
-                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak, c->rowF, c->rowcnt, c->defer};
+                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak, c->rowF, c->rowcnt, c->defer, c->fpart};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -940,7 +941,9 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
     ALLOC(c->pies, (size_t)H);
     ALLOC(c->rowF, (size_t)N);
     ALLOC(c->rowcnt, (size_t)N);
-    ALLOC(c->defer, (size_t)N + 1);
+    ALLOC(c->defer, 2 * ((size_t)N + 1) + 2);  // two lists of N datapoints, each with its counter behind it; + the reduce kernel's arrival counter
+    HIP_TRY(hipMemsetAsync(c->defer, 0, (2 * ((size_t)N + 1) + 2) * sizeof(int), c->stream));
+    ALLOC(c->fpart, (size_t)3 * R3_THREADS);
     c->last_estep_fused = false;
     c->list_words = 0;
     int rl = ensure_lists(c, (i64)N * SC);
@@ -2313,64 +2316,66 @@ static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint
   f.rowcnt = c->rowcnt;
   f.flags_res = c->flags;
   f.flags_cand = c->flags + c->N;
-  f.defer_items = c->defer;
-  f.defer_count = c->defer + c->N;
-  f.defer_cap = (int)c->N;
+  f.list_cap = (int)c->N;
   f.cand = c->cand;
   f.Cmax = c->Cmax;
-  f.kc_big = 16;
+  int *list1 = c->defer, *cnt1 = c->defer + c->N, *list2 = c->defer + c->N + 1, *cnt2 = c->defer + 2 * c->N + 1;
   const int SPL = c->S <= 64 ? 1 : (c->S <= 128 ? 2 : (c->S <= 256 ? 4 : (c->S <= 512 ? 8 : 16)));
   const size_t tab = (size_t)4 * c->H * sizeof(double);
-  HIP_TRY(hipMemsetAsync(f.defer_count, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(cnt1, 0, sizeof(int), c->stream));
+  HIP_TRY(hipMemsetAsync(cnt2, 0, sizeof(int), c->stream));
+  // the census of the new K^n is built by the kernels themselves: a level that no pass over the OLD census launched must
+  // have had an empty list; then fresh counters (what ensure_census does in front of census_kernel)
+  check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
+  c->census_skip = 0;
+  f.cen_items = c->clist;
+  f.cen_n = c->clist_n;
+  f.cen_stride = (i64)c->clist_words;
+  f.cen_cap = (int)list_cap(c->N * (i64)c->S);
   SpanGuard g(c, KID_ESTEP_FUSED);
-  {  // FAST: eight waves per workgroup share the staged singleton table; resident grid
-    f.lds_wave_bytes = fused_lds_wave_bytes(c->H, SPL, false, f.kc_big);
-    int W = 8;
-    size_t lds = tab + (size_t)W * f.lds_wave_bytes;
-    while (W > 1 && lds > 150 * 1024) {
-      W >>= 1;
-      lds = tab + (size_t)W * f.lds_wave_bytes;
+  // three launches of one body: FAST over all datapoints, FULL with LDS for 16 latents per state over what FAST left,
+  // FULL with LDS for up to SSSC_KCAP latents over what that left (the lists live on the device: an empty one costs a launch)
+  for (int stage = 0; stage < 3; stage++) {
+    const bool full = stage > 0;
+    f.in_items = stage == 0 ? nullptr : (stage == 1 ? list1 : list2);
+    f.in_count = stage == 0 ? nullptr : (stage == 1 ? cnt1 : cnt2);
+    f.out_items = stage == 0 ? list1 : (stage == 1 ? list2 : nullptr);
+    f.out_count = stage == 0 ? cnt1 : (stage == 1 ? cnt2 : nullptr);
+    int W = stage == 0 ? 4 : (stage == 1 ? 4 : 1);
+    f.kc_big = stage == 2 ? SSSC_KCAP : 16;
+    f.stage_d1 = stage < 2;
+    f.lds_wave_bytes = fused_lds_wave_bytes(SPL, full, f.kc_big);
+    auto lds_of = [&](int w) { return (f.stage_d1 ? tab : 0) + (size_t)w * f.lds_wave_bytes; };
+    while (stage == 2 && lds_of(1) > 150 * 1024 && f.kc_big > 16) {  // (S = 1024: the rows leave room for fewer latents)
+      f.kc_big -= 4;
+      f.lds_wave_bytes = fused_lds_wave_bytes(SPL, full, f.kc_big);
     }
+    while (W > 1 && lds_of(W) > 150 * 1024) W >>= 1;
+    const size_t lds = lds_of(W);
     REQUIRE(lds <= 150 * 1024, "fused E-step: H too large for the LDS rows");
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    per_cu = std::max(1, std::min(per_cu, 16 / W));  // four waves per SIMD
+    per_cu = std::max(1, std::min(per_cu, 8 / W));  // two waves per SIMD (256 registers: the scratch traffic of a tighter budget cost 10x)
     const unsigned grid = (unsigned)std::min<i64>(cdiv(c->N, W), (i64)c->n_cu * per_cu);
-#define FUSED_FAST(SPLV) sssc_estep_fused_kernel<SPLV, false><<<grid, 64 * W, lds, c->stream>>>(f)
+#define FUSED_LAUNCH(SPLV)                                                               \
+  do {                                                                                   \
+    if (full)                                                                            \
+      sssc_estep_fused_kernel<SPLV, true><<<grid, 64 * W, lds, c->stream>>>(f);          \
+    else                                                                                 \
+      sssc_estep_fused_kernel<SPLV, false><<<grid, 64 * W, lds, c->stream>>>(f);         \
+  } while (0)
     switch (SPL) {
-      case 1: FUSED_FAST(1); break;
-      case 2: FUSED_FAST(2); break;
-      case 4: FUSED_FAST(4); break;
-      case 8: FUSED_FAST(8); break;
-      default: FUSED_FAST(16); break;
+      case 1: FUSED_LAUNCH(1); break;
+      case 2: FUSED_LAUNCH(2); break;
+      case 4: FUSED_LAUNCH(4); break;
+      case 8: FUSED_LAUNCH(8); break;
+      default: FUSED_LAUNCH(16); break;
     }
-#undef FUSED_FAST
+#undef FUSED_LAUNCH
     HIP_TRY(hipGetLastError());
-    DBG_SYNC(c, "fused E-step (FAST)");
+    DBG_SYNC(c, stage == 0 ? "fused E-step (FAST)" : (stage == 1 ? "fused E-step (FULL, 16 latents)" : "fused E-step (FULL, KCAP latents)"));
   }
-  {  // FULL: the datapoints FAST left untouched (count on the device; an empty list costs one launch)
-    f.lds_wave_bytes = fused_lds_wave_bytes(c->H, SPL, true, f.kc_big);
-    int W = 4;
-    size_t lds = tab + (size_t)W * f.lds_wave_bytes;
-    while (W > 1 && lds > 150 * 1024) {
-      W >>= 1;
-      lds = tab + (size_t)W * f.lds_wave_bytes;
-    }
-    REQUIRE(lds <= 150 * 1024, "fused E-step: H too large for the LDS rows");
-    const int per_cu = std::max(1, std::min((int)((160 * 1024) / (lds + 256)), 8 / W));
-    const unsigned grid = (unsigned)std::min<i64>(cdiv(c->N, W), (i64)c->n_cu * per_cu);
-#define FUSED_FULL(SPLV) sssc_estep_fused_kernel<SPLV, true><<<grid, 64 * W, lds, c->stream>>>(f)
-    switch (SPL) {
-      case 1: FUSED_FULL(1); break;
-      case 2: FUSED_FULL(2); break;
-      case 4: FUSED_FULL(4); break;
-      case 8: FUSED_FULL(8); break;
-      default: FUSED_FULL(16); break;
-    }
-#undef FUSED_FULL
-    HIP_TRY(hipGetLastError());
-    DBG_SYNC(c, "fused E-step (FULL)");
-  }
-  fused_reduce3_kernel<<<1, R3_THREADS, 0, c->stream>>>(c->rowF, c->rowcnt, c->N, c->dpar);
+  fused_reduce3_kernel<<<FR3_BLOCKS, R3_THREADS / FR3_BLOCKS, 0, c->stream>>>(c->rowF, c->rowcnt, c->N, c->dpar, c->fpart,
+                                                                              (unsigned *)(c->defer + 2 * (c->N + 1)));
   HIP_TRY(hipGetLastError());
   DBG_SYNC(c, "fused E-step (reduce)");
   return 0;
@@ -2383,12 +2388,10 @@ extern "C" int evoamd_estep(evoamd_ctx *c, int n_parents, int n_children, uint64
   REQUIRE(n_parents * n_children <= c->Cmax, "n_parents * n_children exceeds the configured Cmax");
   REQUIRE(Mprime >= 1 && Mprime <= c->S, "Mprime must be in [1, S]");
   HIP_TRY(hipSetDevice(c->device));
-  // Sparse enough: FAST leaves every datapoint that meets a state above four latents to the low-occupancy FULL launch,
-  // and FULL holds at most 16 latents per state -- the census of the last statistics pass decides (K^n grows by at most
-  // one latent per state and iteration, and the host sees every census one iteration late at the latest)
+  // Sparse enough: FAST leaves every datapoint that meets a state above four latents to the low-occupancy FULL launches
+  // -- the census of the last statistics pass says how many states there are above four
   bool fused = c->fused_opt != 0 && fused_shape_ok(c, n_parents, n_children);
-  if (fused && c->fused_opt == 1) fused = c->need_known && c->res_cnt[2] == 0.0 && c->res_cnt[1] <= 0.25 * (double)c->N;
-  if (fused && c->need_known && c->res_cnt[2] != 0.0) fused = false;  // (states above eight latents: the separate levels hold 64)
+  if (fused && c->fused_opt == 1) fused = c->need_known && c->res_cnt[1] <= 0.25 * (double)c->N;
   if (fused_out) *fused_out = fused ? 1 : 0;
   if (!fused) {
     c->unfused_calls++;
@@ -2406,10 +2409,28 @@ extern "C" int evoamd_estep(evoamd_ctx *c, int n_parents, int n_children, uint64
   if (r) return r;
   c->gen++;
   c->kn_gen++;
+  c->census_gen = c->kn_gen;  // the fused kernels listed the new K^n on the way
   c->rows_fresh = true;
   c->have_cand = false;  // the children never left the kernel
   c->cand_from_device = true;
   c->last_estep_fused = true;
+  return 0;
+}
+
+extern "C" int evoamd_estep_counters(evoamd_ctx *c, int64_t out[4]) {
+  REQUIRE(c && c->configured && out, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  out[0] = c->fused_calls;
+  out[1] = c->unfused_calls;
+  out[2] = out[3] = 0;
+  if (c->defer) {
+    int h[2] = {0, 0};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&h[0], c->defer + c->N, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&h[1], c->defer + 2 * c->N + 1, sizeof(int), hipMemcpyDeviceToHost));
+    out[2] = h[0];
+    out[3] = h[1];
+  }
   return 0;
 }
 

@@ -19,7 +19,9 @@
 //         from their digests.  A datapoint that meets anything else (a state above four latents, a state whose elimination
 //         needs row exchanges, exact mode with a state above two latents) is left UNTOUCHED and its index appended to a list.
 //   FULL  serves that list with everything the separate kernels have: bit words, the 5..8 quad form, the pivoting
-//         wavefront form (up to 16 latents here).  Low occupancy, few datapoints.
+//         wavefront form -- with LDS for 16 latents per state first (four waves per workgroup); a datapoint that meets a
+//         denser state moves on to a second list, served by a launch with LDS for SSSC_KCAP latents (one wave per
+//         workgroup).  Low occupancy, few datapoints.
 // Complete data, digests, S_perm = 0, randflip x 1 generation, at most 64 children per datapoint (the examples' 10).
 #pragma once
 #include "kernels_evolve.hpp"
@@ -35,8 +37,19 @@ struct FusedArgs {
   double *rowmax, *rowsum, *rowF;   // (N) each: max_s lpj, sum_s exp(lpj - max), logsumexp of the new row
   int *rowcnt;                      // (N): #new unique children | #swapped << 16  (variational/utils.py:336-337)
   unsigned *flags_res, *flags_cand; // (N) clamp flags of the two lpj "calls" of a datapoint (_models.py:581-594)
-  int *defer_items, *defer_count;   // FAST appends / FULL reads: datapoints FAST did not touch
-  int defer_cap;
+  // datapoints an instantiation cannot serve are left UNTOUCHED and appended to out_*; in_* (FULL) is the list the launch
+  // before appended.  FAST: natural order -> list 1; FULL with 16 latents of LDS per state: list 1 -> list 2; FULL with 64
+  // (one wave per workgroup): list 2 -> nothing (a state above that raises the same error as the separate kernels)
+  const int *in_items, *in_count;
+  int *out_items, *out_count;
+  int list_cap;
+  int stage_d1;                     // singleton table staged in LDS (else read through the caches)
+  // census of the NEW K^n (kernels_sssc_quad.hpp: census_kernel's lists, built here on the way): three lists (3..4, 5..8,
+  // more than 8 active latents) of LIST_SHARDS x cen_cap entries e = n S + s, counters cen_n[level LIST_SHARDS + shard];
+  // a datapoint appends to shard n % LIST_SHARDS, which holds at most ceil(N / LIST_SHARDS) S entries
+  int *cen_items, *cen_n;
+  i64 cen_stride;
+  int cen_cap;
   u64 *cand;                        // FULL: (N, Cmax, HW) children's bit words (scratch)
   int Cmax;
   int kc_big;                       // FULL: latents the pivoting form holds (LDS: big_lds(kc_big) per wave)
@@ -94,12 +107,16 @@ __device__ __forceinline__ u64 load_sc0(const u64 *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// dynamic LDS: [H double4 singleton table] + waves x fused_lds_wave_bytes
-__host__ __device__ inline int fused_lds_wave_bytes(int H, int SPL, bool full, int kc_big) {
-  int b = H * 8;                       // rowB
-  b += 64 * 8 * 3;                     // vres, cdig, new_v
-  b += ((SPL + 1) * 64 * 2 + 7) / 8 * 8;  // lst (u16)
+// dynamic LDS: [H double4 singleton table] + waves x fused_lds_wave_bytes.  Per wave: the datapoint's lpj row and digests
+// (SPL x 64 each), the children's digests and lpj (64 each), the accepted swaps, the level lists; FULL adds the latents of
+// a 5..8 pass and the k x k system of the pivoting form.  (The B row is NOT staged: the ~2 S gathers per 4 KB row hit the
+// caches, and without it sixteen waves per CU fit -- this kernel lives on latency hiding, not on LDS bandwidth.)
+__host__ __device__ inline int fused_lds_wave_bytes(int SPL, bool full, int kc_big) {
+  int b = SPL * 64 * 8 * 2;            // rowL, rowD
+  b += 64 * 8 * 3;                     // cdig, cval, new_v
+  b += ((SPL + 1) * 64 * 2 + 7) / 8 * 8 * 2;  // lst, hlst (u16)
   b += 64 * 4 * 3;                     // sel, new_i, old_i
+  b += 32 * 4;                         // dbuf: deferred datapoints waiting for ONE reservation per 32
   if (full) {
     b += (16 * 8 + 16) * 4;                                            // idxb, kcnt: latents of 16 states with 5..8
     b += (4 * kc_big * kc_big + 5 * kc_big) * 8 + ((kc_big * 4 + 7) / 8) * 8;  // BigLds
@@ -108,255 +125,253 @@ __host__ __device__ inline int fused_lds_wave_bytes(int H, int SPL, bool full, i
 }
 
 template <int SPL, bool FULL>
-__global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(FusedArgs f) {
+__global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
   SsscArgs &a = f.a;
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double fsm[];
+  constexpr int SP = SPL * 64;
+  constexpr int LSTB = ((SPL + 1) * 64 * 2 + 7) / 8 * 8;
   const int H = a.H, HW = a.HW, S = f.S;
   const int lane = lane_id(), wave = wave_id_uniform(), W = (int)(blockDim.x >> 6);
   double4 *d1s = (double4 *)fsm;
-  char *wb = (char *)(fsm + (size_t)4 * H) + (size_t)wave * f.lds_wave_bytes;
-  double *rowB = (double *)wb;
-  double *vres = rowB + H;
-  u64 *cdig = (u64 *)(vres + 64);
-  double *new_v = (double *)(cdig + 64);
+  char *wb = (char *)(fsm + (f.stage_d1 ? (size_t)4 * H : 0)) + (size_t)wave * f.lds_wave_bytes;
+  double *rowL = (double *)wb;            // lpj of the resident states (clamped), slot s
+  u64 *rowD = (u64 *)(rowL + SP);         // their digests (0 beyond S)
+  u64 *cdig = rowD + SP;                  // children: digests ...
+  double *cval = (double *)(cdig + 64);   // ... and lpj (clamped)
+  double *new_v = cval + 64;
   unsigned short *lst = (unsigned short *)(new_v + 64);
-  int *sel = (int *)((char *)lst + ((SPL + 1) * 64 * 2 + 7) / 8 * 8);
+  unsigned short *hlst = (unsigned short *)((char *)lst + LSTB);
+  int *sel = (int *)((char *)hlst + LSTB);
   int *new_i = sel + 64, *old_i = new_i + 64;
-  int *idxb = old_i + 64;  // FULL only: latents (8 each) and counts of the 16 states of a 5..8 pass
+  int *dbuf = old_i + 64;
+  int *idxb = dbuf + 32;  // FULL only: latents (8 each) and counts of the 16 states of a 5..8 pass
   int *kcnt = idxb + 16 * 8;
   BigLds BL;
   if (FULL) BL.carve((double *)(kcnt + 16), f.kc_big);
-  for (int i = threadIdx.x; i < H; i += blockDim.x) d1s[i] = a.D1[i];
-  __syncthreads();
+  const i64 count = FULL ? (i64)min(*f.in_count, f.list_cap) : a.N;
+  if (FULL && count == 0) return;  // (uniform: the usual case for the second FULL launch)
+  if (f.stage_d1) {
+    for (int i = threadIdx.x; i < H; i += blockDim.x) d1s[i] = a.D1[i];
+    __syncthreads();
+  }
+  const double4 *D1t = f.stage_d1 ? d1s : a.D1;
   const bool exact = sssc_exact_mode(a);
   const double s2 = a.s2inv;
   const int n_kids = f.n_parents * f.n_children;
   const u64 lt_mask = (1ull << lane) - 1ull;
   const int t4 = lane & 3, qd = lane >> 2;
-  const i64 count = FULL ? (i64)min(*f.defer_count, f.defer_cap) : a.N;
+  auto level_of = [](const int k) { return k > 8 ? 3 : (k > 4 ? 2 : (k > 2 ? 1 : 0)); };
+  // Deferred datapoints leave in batches: a returning atomic on ONE counter sustains ~90 per us (MI355X guide, "dequeue"),
+  // and an early K^n defers a third of the datapoints -- one atomic per datapoint was 0.5 ms of this kernel.
+  int dn = 0;  // wave-uniform: entries waiting in dbuf
+  auto flush_defer = [&]() {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(f.out_count, dn);
+    base = __shfl(base, 0, 64);
+    if (lane < dn) {
+      if (base + lane < f.list_cap)
+        f.out_items[base + lane] = dbuf[lane];
+      else
+        atomicOr(a.err, EVO_ERR_LIST_FULL);
+    }
+    dn = 0;
+    lds_wave_fence();
+  };
   for (i64 it = (i64)blockIdx.x * W + wave; it < count; it += (i64)gridDim.x * W) {
-    const i64 n = FULL ? (i64)guard_index(f.defer_items[it], a.N, a.err) : it;
+    const i64 n = FULL ? (i64)guard_index(f.in_items[it], a.N, a.err) : it;
     const u64 *dgn = f.dig + n * (i64)S;
     const u64 *st_n = f.states + n * (i64)S * HW;
     const u64 *cw_n = FULL ? f.cand + n * (i64)f.Cmax * HW : nullptr;
-    // ------------------------------------------------------------------ phase 1: lpj of the resident states
-    u64 dg[SPL];
-#pragma unroll
-    for (int q = 0; q < SPL; q++) {
-      const int s = lane + 64 * q;
-      dg[q] = dgn[s < S ? s : 0];
-    }
+    const double *Bn = a.Bm + n * (i64)H;
     const double yyn = a.yy[n];
+    unsigned fl_res = 0, fl_cand = 0;  // clamp flags raised by this lane (OR-ed over the wave at the end)
+    bool defer = false;                // wave-uniform
+    int hcnt = 0;                      // wave-uniform: states the quad levels handed on (hlst)
+    // ------------------------------------------------------------------ phase 1: lpj of the resident states
+    bool above2 = false, above4 = false;
     {
-      const double *Bg = a.Bm + n * (i64)H;
-      for (int h = lane; h < H; h += 64) rowB[h] = Bg[h];
-    }
-    double ov[SPL];
-    int lv[SPL], mypos[SPL];
-    unsigned fl_res = 0;
-    {
+      u64 dg[SPL];
       PairEntry pe[SPL];
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
-        const bool live = lane + 64 * q < S;
-        const int k = live ? dig_k(dg[q]) : 0;
-        const bool pair = live && k == 2;
-        pe[q] = a.PT[pair ? (i64)dig_idx(dg[q], 0) * H + dig_idx(dg[q], 1) : 0];
-        lv[q] = !live ? 0 : (k > 8 ? 3 : (k > 4 ? 2 : (k > 2 ? 1 : 0)));
-        mypos[q] = 0;
+        const int s = lane + 64 * q;
+        dg[q] = dgn[s < S ? s : 0];
       }
-      lds_wave_fence();
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
         const bool live = lane + 64 * q < S;
-        const int k = live ? dig_k(dg[q]) : 0;
-        ov[q] = 0.0;
+        if (!live) dg[q] = 0ull;
+        const int k = dig_k(dg[q]);
+        pe[q] = a.PT[k == 2 ? (i64)dig_idx(dg[q], 0) * H + dig_idx(dg[q], 1) : 0];
+        rowD[lane + 64 * q] = dg[q];
+        above2 = above2 || k > 2;
+        above4 = above4 || k > 4;
+      }
+#pragma unroll
+      for (int q = 0; q < SPL; q++) {
+        const bool live = lane + 64 * q < S;
+        const int k = dig_k(dg[q]);
+        double v = 0.0;
         if (live && k <= 2)
-          ov[q] = clamp_lpj(sssc_k2_value(k, dig_idx(dg[q], 0), dig_idx(dg[q], 1), d1s, rowB, pe[q], yyn, s2, a.err), fl_res);
+          v = clamp_lpj(sssc_k2_value(k, dig_idx(dg[q], 0), dig_idx(dg[q], 1), D1t, Bn, pe[q], yyn, s2, a.err), fl_res);
+        rowL[lane + 64 * q] = v;
       }
     }
-    bool defer = false;  // wave-uniform
-    // One level of listed states: compaction of the flagged slots, evaluation, values back to their owners.
-    // LVL 1: four lanes per state (3..4 latents, from the digest); LVL 2: four lanes per state, two columns each
-    // (5..8 latents, from the bit words); LVL 3: the whole wave per state, pivoting (everything else).
-    // `cand`: the slots are children (lane = child), else resident states (slot = lane + 64 q).
-    // A state that level 1 / 2 cannot eliminate without row exchanges moves to level 3 (FULL) or defers the datapoint.
-    auto eval_quads = [&](auto lvl_tag, const int cnt, const bool cand, auto &&give) {
+    lds_wave_fence();
+    // One level of listed states: lst[0 .. cnt) holds their slots (resident: s; children: the child's lane).
+    // LVL 1: four lanes per state (3..4 latents, from the digest); LVL 2: four lanes per state, two columns each (5..8
+    // latents, from the bit words).  Values go straight to the row (rowL / cval); a state the elimination cannot do
+    // without row exchanges is handed on through hlst (FULL: the pivoting form below; FAST: the datapoint is deferred).
+    auto eval_quads = [&](auto lvl_tag, const int cnt, const bool cand) {
       constexpr int LVL = decltype(lvl_tag)::value;
       constexpr int C = LVL == 2 ? 2 : 1, K = 4 * C;
-      for (int cb = 0; cb < cnt; cb += 64) {  // uniform
-        for (int pb = 0; pb < 64 && cb + pb < cnt; pb += 16) {
-          const int ei = cb + pb + qd;
-          const bool live = ei < cnt;
-          const int slot = live ? (int)(lst[ei] & 0x7FFFu) : 0;
-          int idx[K], cidx[C], ks = 0;
-          if (LVL == 1) {
-            const u64 d = !live ? 0ull : (cand ? cdig[slot] : dgn[slot]);
-            ks = live ? dig_k(d) : 0;
+      for (int pb = 0; pb < cnt; pb += 16) {  // uniform
+        const int ei = pb + qd;
+        const bool live = ei < cnt;
+        const int slot = live ? (int)lst[ei] : 0;
+        int idx[K], cidx[C], ks = 0;
+        if (LVL == 1) {
+          const u64 d = !live ? 0ull : (cand ? cdig[slot] : rowD[slot]);
+          ks = dig_k(d);
 #pragma unroll
-            for (int i = 0; i < K; i++) idx[i] = i < ks ? dig_idx(d, i) : 0;
-          } else {
-            // the latents of the pass's 16 states from their bit words, one state after the other (the whole wave scans)
-            for (int e = 0; e < 16 && cb + pb + e < cnt; e++) {
-              const int sl = (int)(lst[cb + pb + e] & 0x7FFFu);
-              const u64 *sp = cand ? cw_n + (i64)sl * HW : st_n + (i64)sl * HW;
-              int kk = 0;  // big_scan with coherent loads (children's words were written by this wave)
-              u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
-              for (int w = 0; w < HW; w++) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
-                const u64 bits = ((u64)hi << 32) | lo;
-                const bool on = (bits >> (63 - lane)) & 1ull;
-                const u64 m = __ballot(on);
-                const int pos = kk + __popcll(m & lt_mask);
-                if (on && pos < 8) idxb[e * 8 + pos] = w * 64 + lane;
-                kk += __popcll(m);
-              }
-              if (lane == 0) {
-                if (kk > 8 || kk < 5) atomicOr(a.err, EVO_ERR_BAD_ENTRY);  // the digest's count said 5..8
-                kcnt[e] = kk < 8 ? kk : 8;
-              }
-            }
-            lds_wave_fence();
-            ks = live ? kcnt[qd] : 0;
-#pragma unroll
-            for (int i = 0; i < K; i++) idx[i] = i < ks ? guard_index(idxb[qd * 8 + i], H, a.err) : 0;
-            lds_wave_fence();
-          }
-#pragma unroll
-          for (int j = 0; j < C; j++) {
-            const int cc = t4 * C + j;
-            int v = 0;
-#pragma unroll
-            for (int i = 0; i < K; i++) v = (i == cc) ? idx[i] : v;
-            cidx[j] = v;
-          }
-          double val = 0.0, kap_all[K], Lam[K][C];
-          bool hard = false;
-          quad_solve<C, 0>(a, t4, ks, idx, cidx, rowB, yyn, val, hard, kap_all, Lam);
-          hard = (hard || exact) && ks > 0;
-          if (live && t4 == 0) {
-            vres[pb + qd] = val;
-            if (hard) lst[ei] = (unsigned short)(slot | 0x8000);
-          }
-        }
-        lds_wave_fence();
-        give(cb);  // owners pick up vres[0 .. 64) = entries cb .. cb + 63
-        lds_wave_fence();
-      }
-    };
-    // compaction of the resident slots with lv == L into lst; returns the count (uniform)
-    auto compact_res = [&](const int L) {
-      int cnt = 0;
-#pragma unroll
-      for (int q = 0; q < SPL; q++) {
-        const bool on = lv[q] == L;
-        const u64 m = __ballot(on);
-        if (on) {
-          mypos[q] = cnt + __popcll(m & lt_mask);
-          lst[mypos[q]] = (unsigned short)(lane + 64 * q);
-        }
-        cnt += __popcll(m);
-      }
-      lds_wave_fence();
-      return cnt;
-    };
-    auto give_res = [&](const int L) {
-      return [&, L](const int cb) {
-#pragma unroll
-        for (int q = 0; q < SPL; q++)
-          if (lv[q] == L && mypos[q] >= cb && mypos[q] < cb + 64) {
-            if (lst[mypos[q]] & 0x8000u)
-              lv[q] = 3;  // needs the pivoting form
-            else
-              ov[q] = clamp_lpj(vres[mypos[q] - cb], fl_res);
-          }
-      };
-    };
-    // the pivoting wavefront form, one listed state after the other (FULL only)
-    auto eval_big = [&](const int cnt, const bool cand, auto &&give) {
-      for (int cb = 0; cb < cnt; cb += 64) {
-        for (int e = cb; e < cnt && e < cb + 64; e++) {
-          const int slot = (int)(lst[e] & 0x7FFFu);
-          const u64 *sp = cand ? cw_n + (i64)slot * HW : st_n + (i64)slot * HW;
-          lds_wave_fence();
-          int k = 0;
-          {
-            u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
+          for (int i = 0; i < K; i++) idx[i] = i < ks ? dig_idx(d, i) : 0;
+        } else {
+          // the latents of the pass's 16 states from their bit words, one state after the other (the whole wave scans)
+          for (int e = 0; e < 16 && pb + e < cnt; e++) {
+            const int sl = (int)lst[pb + e];
+            const u64 *sp = cand ? cw_n + (i64)sl * HW : st_n + (i64)sl * HW;
+            int kk = 0;  // (children's words were written by this wave: coherent loads)
+            const u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
             for (int w = 0; w < HW; w++) {
               const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
               const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
               const u64 bits = ((u64)hi << 32) | lo;
               const bool on = (bits >> (63 - lane)) & 1ull;
               const u64 m = __ballot(on);
-              const int pos = k + __popcll(m & lt_mask);
-              if (on && pos < f.kc_big) BL.idx[pos] = w * 64 + lane;
-              k += __popcll(m);
+              const int pos = kk + __popcll(m & lt_mask);
+              if (on && pos < 8) idxb[e * 8 + pos] = w * 64 + lane;
+              kk += __popcll(m);
+            }
+            if (lane == 0) {
+              if (kk > 8 || kk < 5) atomicOr(a.err, EVO_ERR_BAD_ENTRY);  // the digest's count said 5..8
+              kcnt[e] = kk < 8 ? kk : 8;
             }
           }
-          double val = EVO_F64_MIN;
-          if (k > f.kc_big) {  // uniform
-            if (lane == 0) atomicOr(a.err, 1);
-          } else {
-            const int rc = big_solve<0, false>(a, n, k, BL, lane, exact, rowB, yyn, val);
-            if (rc == 2) val = __builtin_inf();
-          }
-          if (lane == 0) vres[e - cb] = val;
+          lds_wave_fence();
+          ks = live ? kcnt[qd] : 0;
+#pragma unroll
+          for (int i = 0; i < K; i++) idx[i] = i < ks ? guard_index(idxb[qd * 8 + i], H, a.err) : 0;
+          lds_wave_fence();
         }
-        lds_wave_fence();
-        give(cb);
-        lds_wave_fence();
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+          const int cc = t4 * C + j;
+          int v = 0;
+#pragma unroll
+          for (int i = 0; i < K; i++) v = (i == cc) ? idx[i] : v;
+          cidx[j] = v;
+        }
+        double val = 0.0, kap_all[K], Lam[K][C];
+        bool hard = false;
+        quad_solve<C, 0>(a, t4, ks, idx, cidx, Bn, yyn, val, hard, kap_all, Lam);
+        hard = hard && ks > 0 && live;
+        if (live && t4 == 0 && !hard) {
+          if (cand)
+            cval[slot] = clamp_lpj(val, fl_cand);
+          else
+            rowL[slot] = clamp_lpj(val, fl_res);
+        }
+        const u64 hm = __ballot(hard && t4 == 0);
+        if (hm != 0ull) {  // uniform
+          if (!FULL) defer = true;
+          if (hard && t4 == 0) hlst[hcnt + __popcll(hm & lt_mask)] = (unsigned short)slot;
+          hcnt += __popcll(hm);
+        }
       }
+      lds_wave_fence();
     };
-    {
-      bool above4 = false, above2 = false;
+    // resident slots whose level (from the digest's count) is L -> lst; returns the count (uniform)
+    auto compact_res = [&](const int L, const bool all_above2) {
+      int cnt = 0;
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
-        above4 = above4 || lv[q] >= 2;
-        above2 = above2 || lv[q] >= 1;
+        const int lvq = level_of(dig_k(rowD[lane + 64 * q]));
+        const bool on = all_above2 ? lvq >= 1 : lvq == L;
+        const u64 m = __ballot(on);
+        if (on) lst[cnt + __popcll(m & lt_mask)] = (unsigned short)(lane + 64 * q);
+        cnt += __popcll(m);
       }
-      if (!FULL && (__any(above4) || (exact && __any(above2)))) defer = true;
-      if (!defer && __any(above2)) {
-        if (!(FULL && exact)) {
-          const int c1 = compact_res(1);
-          if (c1) eval_quads(std::integral_constant<int, 1>{}, c1, false, give_res(1));
-        } else {
-#pragma unroll
-          for (int q = 0; q < SPL; q++) lv[q] = lv[q] ? 3 : 0;  // exact mode: every state above two latents pivots
-        }
-        if (FULL) {
-          if (!exact) {
-            const int c2 = compact_res(2);
-            if (c2) eval_quads(std::integral_constant<int, 2>{}, c2, false, give_res(2));
+      lds_wave_fence();
+      return cnt;
+    };
+    // the pivoting wavefront form, one listed state after the other (FULL only): lst[0 .. cnt) then hlst[0 .. hcnt)
+    auto eval_big = [&](const int cnt, const bool cand) {
+      for (int e = 0; e < cnt + hcnt && !defer; e++) {
+        const int slot = e < cnt ? (int)lst[e] : (int)hlst[e - cnt];
+        const u64 *sp = cand ? cw_n + (i64)slot * HW : st_n + (i64)slot * HW;
+        lds_wave_fence();
+        int k = 0;
+        {
+          const u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
+          for (int w = 0; w < HW; w++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
+            const u64 bits = ((u64)hi << 32) | lo;
+            const bool on = (bits >> (63 - lane)) & 1ull;
+            const u64 m = __ballot(on);
+            const int pos = k + __popcll(m & lt_mask);
+            if (on && pos < f.kc_big) BL.idx[pos] = w * 64 + lane;
+            k += __popcll(m);
           }
-          const int c3 = compact_res(3);
-          if (c3)
-            eval_big(c3, false, [&](const int cb) {
-#pragma unroll
-              for (int q = 0; q < SPL; q++)
-                if (lv[q] == 3 && mypos[q] >= cb && mypos[q] < cb + 64) {
-                  const double v = vres[mypos[q] - cb];
-                  unsigned flx = 0;
-                  ov[q] = (v == EVO_F64_MIN) ? v : clamp_lpj(v, flx);  // (above kc_big: the separate kernels store finfo.min unflagged)
-                  fl_res |= flx;
-                }
-            });
-        } else {
-          bool hardq = false;
-#pragma unroll
-          for (int q = 0; q < SPL; q++) hardq = hardq || lv[q] == 3;
-          if (__any(hardq)) defer = true;
         }
+        double val = EVO_F64_MIN;
+        bool flagged = true;
+        if (k > f.kc_big) {  // uniform
+          if (f.out_items)
+            defer = true;  // on to the launch with more LDS per state
+          else if (lane == 0)
+            atomicOr(a.err, 1);
+          flagged = false;  // (above SSSC_KCAP the separate kernels store finfo.min unflagged and raise the error)
+        } else {
+          const int rc = big_solve<0, false>(a, n, k, BL, lane, exact, Bn, yyn, val);
+          if (rc == 2) val = __builtin_inf();
+        }
+        if (lane == 0) {
+          if (cand)
+            cval[slot] = flagged ? clamp_lpj(val, fl_cand) : val;
+          else
+            rowL[slot] = flagged ? clamp_lpj(val, fl_res) : val;
+        }
+      }
+      hcnt = 0;
+      lds_wave_fence();
+    };
+    if (!FULL && (__any(above4) || (exact && __any(above2)))) defer = true;
+    if (!defer && __any(above2)) {
+      if (!exact) {
+        const int c1 = compact_res(1, false);
+        if (c1) eval_quads(std::integral_constant<int, 1>{}, c1, false);
+        if (FULL) {
+          const int c2 = compact_res(2, false);
+          if (c2) eval_quads(std::integral_constant<int, 2>{}, c2, false);
+        }
+      }
+      if (FULL) {  // above eight latents + what the quad levels handed on; exact mode: every state above two latents
+        const int c3 = compact_res(3, exact);
+        if (c3 + hcnt) eval_big(c3, false);
       }
     }
     // ------------------------------------------------------------------ phase 2: parents (eas.py:138-150)
     // (evolve_randflip_kernel's arithmetic on the clamped lpj values the separate kernels read back from memory)
     if (!defer) {
+      double ov[SPL];
       double lmin = INFINITY;
 #pragma unroll
-      for (int q = 0; q < SPL; q++)
+      for (int q = 0; q < SPL; q++) {
+        ov[q] = rowL[lane + 64 * q];
         if (lane + 64 * q < S) lmin = fmin(lmin, ov[q]);
+      }
       lmin = wave_min(lmin);
       const double shift = 2.0 * fmin(lmin, 0.0);
       constexpr unsigned KEY_TAKEN = 0x7f800000u;
@@ -398,10 +413,8 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
       lds_wave_fence();
     }
     // ------------------------------------------------------------------ phase 3: children (randflip, eas.py:10-43)
-    u64 cd = 0ull;       // digest of this lane's child
-    double cv = 0.0;     // its lpj (clamped)
-    int clv = 0, cpos = 0;
-    unsigned fl_cand = 0;
+    u64 cd = 0ull;  // digest of this lane's child
+    int clv = 0;
     if (!defer) {
       const bool kid = lane < n_kids;
       if (kid) {
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
         }
         const int par = guard_index(sel[p], S, a.err);
         if (!FULL) {
-          cd = digest_toggle(dgn[par], mine);  // (FAST: every resident digest is complete)
+          cd = digest_toggle(rowD[par], mine);  // (FAST: every resident digest is complete)
         } else {
           const u64 *parw = st_n + (i64)par * HW;
           u64 *dst = f.cand + (n * (i64)f.Cmax + lane) * HW;
@@ -449,73 +462,37 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
         cdig[lane] = cd;
       }
       if (FULL) vm_wave_fence();
-      lds_wave_fence();
       // ---------------------------------------------------------------- phase 4: lpj of the children
       const int ck = kid ? dig_k(cd) : 0;
-      clv = !kid ? 0 : (ck > 8 ? 3 : (ck > 4 ? 2 : (ck > 2 ? 1 : 0)));
+      clv = !kid ? 0 : level_of(ck);
       if (exact && clv) clv = 3;
       if (!FULL && __any(clv >= 2)) defer = true;
+      if (!defer) {
+        const PairEntry pe = a.PT[(kid && ck == 2) ? (i64)dig_idx(cd, 0) * H + dig_idx(cd, 1) : 0];
+        if (kid && ck <= 2) cval[lane] = clamp_lpj(sssc_k2_value(ck, dig_idx(cd, 0), dig_idx(cd, 1), D1t, Bn, pe, yyn, s2, a.err), fl_cand);
+      }
+      lds_wave_fence();
     }
     if (!defer) {
-      const bool kid = lane < n_kids;
-      const int ck = kid ? dig_k(cd) : 0;
-      {
-        const bool pair = kid && ck == 2;
-        const PairEntry pe = a.PT[pair ? (i64)dig_idx(cd, 0) * H + dig_idx(cd, 1) : 0];
-        if (kid && ck <= 2) cv = clamp_lpj(sssc_k2_value(ck, dig_idx(cd, 0), dig_idx(cd, 1), d1s, rowB, pe, yyn, s2, a.err), fl_cand);
-      }
       auto compact_cand = [&](const int L) {
         const bool on = clv == L;
         const u64 m = __ballot(on);
-        if (on) {
-          cpos = __popcll(m & lt_mask);
-          lst[cpos] = (unsigned short)lane;
-        }
+        if (on) lst[__popcll(m & lt_mask)] = (unsigned short)lane;
         lds_wave_fence();
         return (int)__popcll(m);
       };
-      auto give_cand = [&](const int L) {
-        return [&, L](const int cb) {
-          if (clv == L && cpos >= cb && cpos < cb + 64) {
-            if (lst[cpos] & 0x8000u)
-              clv = 3;
-            else
-              cv = clamp_lpj(vres[cpos - cb], fl_cand);
-          }
-        };
-      };
-      if (__any(clv == 1)) {
-        const int c1 = compact_cand(1);
-        eval_quads(std::integral_constant<int, 1>{}, c1, true, give_cand(1));
-      }
+      if (__any(clv == 1)) eval_quads(std::integral_constant<int, 1>{}, compact_cand(1), true);
       if (FULL) {
-        if (__any(clv == 2)) {
-          const int c2 = compact_cand(2);
-          eval_quads(std::integral_constant<int, 2>{}, c2, true, give_cand(2));
-        }
-        if (__any(clv == 3)) {
-          const int c3 = compact_cand(3);
-          eval_big(c3, true, [&](const int cb) {
-            if (clv == 3 && cpos >= cb && cpos < cb + 64) {
-              const double v = vres[cpos - cb];
-              unsigned flx = 0;
-              cv = (v == EVO_F64_MIN) ? v : clamp_lpj(v, flx);
-              fl_cand |= flx;
-            }
-          });
-        }
-      } else if (__any(clv == 3)) {
-        defer = true;
+        if (__any(clv == 2)) eval_quads(std::integral_constant<int, 2>{}, compact_cand(2), true);
+        const int c3 = __any(clv == 3) ? compact_cand(3) : 0;
+        if (c3 + hcnt) eval_big(c3, true);
       }
     }
-    if (defer) {  // (FAST only) nothing of this datapoint has been written: the FULL launch does it from scratch
-      if (lane == 0) {
-        const int pos = atomicAdd(f.defer_count, 1);
-        if (pos < f.defer_cap)
-          f.defer_items[pos] = (int)n;
-        else
-          atomicOr(a.err, EVO_ERR_LIST_FULL);
-      }
+    if (defer) {  // nothing of this datapoint has been written: the next launch does it from scratch
+      if (lane == 0) dbuf[dn] = (int)n;
+      dn++;
+      lds_wave_fence();
+      if (dn == 32) flush_defer();
       continue;
     }
     // ------------------------------------------------------------------ phase 5: vary_Kn (variational/utils.py:231-337)
@@ -523,36 +500,42 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
     int n_uniq = 0, n_sub = 0;
     {
       const int cnt = n_kids;
+      const double cv = lane < cnt ? cval[lane] : 0.0;
       bool keep = false;
-      for (int c = 0; c < cnt; c++) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cd & 0xffffffffull), c);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cd >> 32), c);
-        const u64 hc = ((u64)hi << 32) | lo;
-        bool maybe = false;
+      {
+        u64 oh[SPL];
 #pragma unroll
-        for (int q = 0; q < SPL; q++) maybe = maybe || (lane + 64 * q < S && dg[q] == hc);
-        maybe = maybe || (lane < c && cd == hc);
-        bool dup = false;
-        if (dig_k(hc) <= DIG_SLOTS) {
-          dup = maybe;  // exact: the digest is the state
-        } else if (FULL && __any(maybe)) {  // rare: confirm with the words (children's words: this wave's own stores)
-          const u64 *cw = cw_n + (i64)c * HW;
-          for (int s = lane; s < S && !dup; s += 64) {
-            const u64 *sw = st_n + (i64)s * HW;
-            int w = 0;
-            while (w < HW && sw[w] == load_sc0(cw + w)) w++;
-            dup = (w == HW);
+        for (int q = 0; q < SPL; q++) oh[q] = rowD[lane + 64 * q];
+        for (int c = 0; c < cnt; c++) {
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cd & 0xffffffffull), c);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cd >> 32), c);
+          const u64 hc = ((u64)hi << 32) | lo;
+          bool maybe = false;
+#pragma unroll
+          for (int q = 0; q < SPL; q++) maybe = maybe || (lane + 64 * q < S && oh[q] == hc);
+          maybe = maybe || (lane < c && cd == hc);
+          bool dup = false;
+          if (dig_k(hc) <= DIG_SLOTS) {
+            dup = maybe;  // exact: the digest is the state
+          } else if (FULL && __any(maybe)) {  // rare: confirm with the words (children's words: this wave's own stores)
+            const u64 *cw = cw_n + (i64)c * HW;
+            for (int s = lane; s < S && !dup; s += 64) {
+              const u64 *sw = st_n + (i64)s * HW;
+              int w = 0;
+              while (w < HW && sw[w] == load_sc0(cw + w)) w++;
+              dup = (w == HW);
+            }
+            for (int c2 = lane; c2 < c && !dup; c2 += 64) {
+              const u64 *sw = cw_n + (i64)c2 * HW;
+              int w = 0;
+              while (w < HW && load_sc0(sw + w) == load_sc0(cw + w)) w++;
+              dup = (w == HW);
+            }
           }
-          for (int c2 = lane; c2 < c && !dup; c2 += 64) {
-            const u64 *sw = cw_n + (i64)c2 * HW;
-            int w = 0;
-            while (w < HW && load_sc0(sw + w) == load_sc0(cw + w)) w++;
-            dup = (w == HW);
+          if (!__any(dup)) {
+            n_uniq++;
+            if (c == lane) keep = true;
           }
-        }
-        if (!__any(dup)) {
-          n_uniq++;
-          if (c == lane) keep = true;
         }
       }
       const double nv = (lane < cnt && keep) ? cv : 0.0;
@@ -574,7 +557,7 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
         {
           double ow[SPL];
 #pragma unroll
-          for (int q = 0; q < SPL; q++) ow[q] = (lane + 64 * q < S) ? ov[q] : INFINITY;
+          for (int q = 0; q < SPL; q++) ow[q] = (lane + 64 * q < S) ? rowL[lane + 64 * q] : INFINITY;
           for (int j = 0; j < M; j++) {
             double lm = ow[0];
 #pragma unroll
@@ -596,7 +579,7 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
         }
         lds_wave_fence();
         n_sub = g;
-        // swap j: child new_i[j] -> slot old_i[j]
+        // swap j: child new_i[j] -> slot old_i[j] (K^n in memory, and the wave's own copy of the row)
         if (lane < g) {
           const int bi = guard_index(new_i[lane], n_kids, a.err), wi = guard_index(old_i[lane], S, a.err);
           const u64 d = cdig[bi];
@@ -614,26 +597,39 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
             }
           }
           f.dig[n * (i64)S + wi] = d;
+          rowD[wi] = d;
+          rowL[wi] = new_v[lane];
         }
-        for (int j = 0; j < g; j++) {  // the register copies of the row and of the digests follow the swaps
-          const int wi = old_i[j];
-          const double v = new_v[j];
-          const u64 d = cdig[new_i[j]];
+        lds_wave_fence();
+      }
+    }
+    // census of the new K^n: positions now, the three reservations (lanes 0..2) fly while phase 6 computes
+    int cpos[SPL], cres = 0;
+    if (f.cen_items) {
+      int ccnt[3] = {0, 0, 0};
 #pragma unroll
-          for (int q = 0; q < SPL; q++)
-            if (lane + 64 * q == wi) {
-              ov[q] = v;
-              dg[q] = d;
-            }
+      for (int q = 0; q < SPL; q++) {
+        const int lvq = level_of(dig_k(rowD[lane + 64 * q]));
+        cpos[q] = 0;
+#pragma unroll
+        for (int L = 1; L <= 3; L++) {
+          const u64 m = __ballot(lvq == L);
+          if (lvq == L) cpos[q] = ccnt[L - 1] + __popcll(m & lt_mask);
+          ccnt[L - 1] += __popcll(m);
         }
       }
+      const int myc = lane == 0 ? ccnt[0] : (lane == 1 ? ccnt[1] : (lane == 2 ? ccnt[2] : 0));
+      if (myc > 0) cres = atomicAdd(&f.cen_n[lane * LIST_SHARDS + (int)(n & (LIST_SHARDS - 1))], myc);
     }
     // ------------------------------------------------------------------ phase 6: the new row and its statistics
     {
+      double ov[SPL];
       double m = -INFINITY;
 #pragma unroll
-      for (int q = 0; q < SPL; q++)
+      for (int q = 0; q < SPL; q++) {
+        ov[q] = rowL[lane + 64 * q];
         if (lane + 64 * q < S) m = fmax(m, ov[q]);
+      }
       m = wave_max(m);
       const double B = 0.0 - m;
       double z = 0.0;
@@ -662,45 +658,91 @@ __global__ __launch_bounds__(512, FULL ? 2 : 4) void sssc_estep_fused_kernel(Fus
         if (fr | fc) atomicOr(&a.err[1], 1);
       }
     }
+    if (f.cen_items) {
+      const int shard = (int)(n & (LIST_SHARDS - 1));
+#pragma unroll
+      for (int q = 0; q < SPL; q++) {
+        const int lvq = level_of(dig_k(rowD[lane + 64 * q]));
+#pragma unroll
+        for (int L = 1; L <= 3; L++) {
+          const int base = __builtin_amdgcn_readlane(cres, L - 1);
+          if (lvq == L) {
+            const int pos = base + cpos[q];
+            if (pos >= 0 && pos < f.cen_cap)
+              f.cen_items[(i64)(L - 1) * f.cen_stride + (i64)shard * f.cen_cap + pos] = (int)(n * (i64)S + lane + 64 * q);
+            else
+              atomicOr(a.err, EVO_ERR_LIST_FULL);
+          }
+        }
+      }
+    }
     lds_wave_fence();
   }
+  if (dn) flush_defer();
 }
 
 // Free-energy terms and E-step counters of the fused kernels -> dpar[DP_FS] (assigned), dpar[DP_ECNT0 / 1] (accumulated),
 // in vary_kn_kernel + reduce3_partials_kernel's order of additions: blocks of four datapoints ((f0 + f1) + f2) + f3 first,
-// then thread t adds blocks t, t + 1024, ..., then the tree -- the same bits as the separate kernels leave.
-__global__ __launch_bounds__(R3_THREADS) void fused_reduce3_kernel(const double *__restrict__ rowF, const int *__restrict__ rowcnt,
-                                                                   i64 N, double *__restrict__ dpar) {
+// then "thread" t of 1024 adds blocks t, t + 1024, ..., then the tree over the 1024 sums -- the same bits as the separate
+// kernels leave.  The 1024 chains are spread over FR3_BLOCKS workgroups (one workgroup reading 1.2 MB took 45 us at the
+// north-star shape); the last one to finish runs the tree.
+#define FR3_BLOCKS 16
+__global__ __launch_bounds__(R3_THREADS / FR3_BLOCKS) void fused_reduce3_kernel(const double *__restrict__ rowF, const int *__restrict__ rowcnt,
+                                                                                i64 N, double *__restrict__ dpar, double *__restrict__ part,
+                                                                                unsigned *__restrict__ counter) {
+  constexpr int T = R3_THREADS / FR3_BLOCKS;
   __shared__ double sh[3][R3_THREADS];
+  __shared__ unsigned last;
   const i64 nb = (N + 3) / 4;
+  const int vt = blockIdx.x * T + threadIdx.x;  // the chain this thread adds up
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (i64 b = threadIdx.x; b < nb; b += R3_THREADS) {
-    double fq[4];
-    int uq = 0, sq = 0;
+  for (i64 b0 = vt; b0 < nb; b0 += (i64)4 * R3_THREADS) {  // four blocks per thread in flight
+    double fq[4][4];
+    int cq[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const i64 n = 4 * b + u;
-      fq[u] = n < N ? rowF[n] : 0.0;
-      const int c = n < N ? rowcnt[n] : 0;
-      uq += c & 0xFFFF;
-      sq += c >> 16;
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const i64 n = 4 * (b0 + (i64)r * R3_THREADS) + u;
+        fq[r][u] = n < N ? rowF[n] : 0.0;
+        cq[r][u] = n < N ? rowcnt[n] : 0;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (b0 + (i64)r * R3_THREADS < nb) {
+        s0 += ((fq[r][0] + fq[r][1]) + fq[r][2]) + fq[r][3];
+        int uq = 0, sq = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          uq += cq[r][u] & 0xFFFF;
+          sq += cq[r][u] >> 16;
+        }
+        s1 += (double)uq;
+        s2 += (double)sq;
+      }
     }
-    s0 += ((fq[0] + fq[1]) + fq[2]) + fq[3];
-    s1 += (double)uq;
-    s2 += (double)sq;
   }
-  sh[0][threadIdx.x] = s0;
-  sh[1][threadIdx.x] = s1;
-  sh[2][threadIdx.x] = s2;
+  part[vt] = s0;
+  part[R3_THREADS + vt] = s1;
+  part[2 * R3_THREADS + vt] = s2;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1u);
+  __syncthreads();
+  if (last != FR3_BLOCKS - 1) return;
+  __threadfence();
+  for (int i = threadIdx.x; i < R3_THREADS; i += T)
+    for (int k = 0; k < 3; k++) sh[k][i] = __hip_atomic_load(&part[k * R3_THREADS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   for (int o = R3_THREADS / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o)
-      for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    for (int i = threadIdx.x; i < o; i += T)
+      for (int k = 0; k < 3; k++) sh[k][i] += sh[k][i + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     dpar[DP_FS] = sh[0][0];
     dpar[DP_ECNT0] += sh[1][0];
     dpar[DP_ECNT1] += sh[2][0];
+    *counter = 0u;  // ready for the next launch (stream-ordered)
   }
 }

@@ -217,6 +217,12 @@ class Engine:
                                     1 if fit_parents else 0, int(Mprime), ctypes.byref(fused)))
         return bool(fused.value)
 
+    def estep_counters(self):
+        """{fused_calls, separate_calls, deferred_to_full, deferred_to_full64} of evoamd_estep (diagnostics)."""
+        out = (ctypes.c_int64 * 4)()
+        check(self.lib.evoamd_estep_counters(self._h, out))
+        return dict(zip(("fused_calls", "separate_calls", "deferred_to_full", "deferred_to_full64"), [int(v) for v in out]))
+
     MUTATIONS = {"randflip": 0, "sparseflip": 1, "cross": 2, "cross_randflip": 3, "cross_sparseflip": 4}
 
     def evolve_states(self, mutation, n_parents, n_children, n_generations, seed, fit_parents=True, sparseness=0.0,

@@ -347,6 +347,10 @@ int evoamd_restore_theta_backup(evoamd_ctx *ctx);
  * data, digests, S_perm = 0, <= 64 children, H <= 1024; option "fused_estep") ONE kernel does it with a wave per datapoint.
  * *fused_out (may be NULL): 1 if the fused kernel ran. */
 int evoamd_estep(evoamd_ctx *ctx, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime, int *fused_out);
+/* Diagnostics of evoamd_estep: out = { calls that ran the fused kernel, calls that ran the separate passes, datapoints the
+ * last fused call's first launch left to the second (a state above four latents, an elimination that needs row exchanges,
+ * exact mode), datapoints the second left to the third (a state above 16 latents) }.  Synchronises the stream. */
+int evoamd_estep_counters(evoamd_ctx *ctx, int64_t out[4]);
 /* Fs only (sum_n logsumexp) of an arbitrary host lpj matrix (N,C) -- exact-likelihood path. */
 int evoamd_free_energy(evoamd_ctx *ctx, const double *lpj, int64_t N, int C, double *Fs_out);
 /* Adds the E-step scalars produced outside evoamd_stats (e.g. host-side vary_Kn counts)

@@ -137,6 +137,8 @@ def test_fused_estep_dense_states(engine, H, S, p_on):
         while s < S:
             k = min(H, max(0, int(rng.poisson(p_on)))) if s % 7 else int(rng.randint(0, 3))
             k = min(k, 12)
+            if s % 11 == 5 and n % 3 == 0:
+                k = 17 + (s % 5)  # above the 16 latents of the first FULL launch: the datapoint moves on to the second
             row = np.zeros(H, dtype=bool)
             row[rng.choice(H, k, replace=False)] = True
             key = row.tobytes()
@@ -147,8 +149,9 @@ def test_fused_estep_dense_states(engine, H, S, p_on):
             s += 1
     ea = ("fit", "randflip", 8, 2)
     kn = _lockstep(engine, SSSC, D, H, S, my_data, theta0, ss0, ea, 3)
-    k = kn[0].sum(axis=-1)
-    assert (k >= 5).any() and (k >= 9).any() and ((k >= 3) & (k <= 4)).any()
+    k = ss0.sum(axis=-1)  # (what the first E-step evaluates)
+    assert (k >= 5).any() and (k >= 9).any() and ((k >= 3) & (k <= 4)).any() and (k >= 17).any()
+    assert (kn[-1].sum(axis=-1) >= 5).any()
 
 
 def test_fused_estep_exact_mode(engine):
@@ -189,9 +192,9 @@ def test_fused_estep_exact_mode(engine):
 
 
 def test_fused_estep_automatic_choice(engine):
-    """Option "fused_estep" = 1 (default): the first E-step of a geometry runs the separate passes (no census yet), the
-    following ones the fused kernel while K^n is sparse; a K^n with states above eight latents goes back to the separate
-    passes (whose levels hold 64 latents)."""
+    """Option "fused_estep" = 1 (default): the first E-step of a geometry (or after a K^n upload) runs the separate passes
+    (no census yet), the following ones the fused kernel while K^n is sparse -- states above four latents in at most a
+    quarter of the datapoints; a dense K^n goes back to the separate passes."""
     from evo_amd.models import SSSC
     from evo_amd.variational import init_states
     rng = np.random.RandomState(9)
@@ -212,6 +215,13 @@ def test_fused_estep_automatic_choice(engine):
         ss[0, s] = False
         ss[0, s, s:s + 12] = True
     engine.upload_states(ss)  # (a K^n from the host: its census is unknown -> separate passes, which then count it)
+    _, _, _, theta = model.step(theta, suff, my_data)
+    assert model.last_estep_fused is False
+    _, _, _, theta = model.step(theta, suff, my_data)  # 24 dense states in 200 datapoints: still sparse -> fused (FULL serves them)
+    assert model.last_estep_fused is True
+    ss = engine.download_states()
+    ss[:, :, :6] = True  # every state of every datapoint above four latents: the automatic choice goes back to the separate passes
+    engine.upload_states(ss)
     for _ in range(2):
         _, _, _, theta = model.step(theta, suff, my_data)
         assert model.last_estep_fused is False

@@ -1194,7 +1194,9 @@ def test_learning_level_bars_device_path(engine, algo):
       (1) mean final F within 2 standard errors of the reference's mean final F;
       (2) bars recovered (distinct learned fields with |cos| > 0.9 to a generating bar): mean count not below the
           reference's by more than 2 standard errors, and as many fully recovered runs (EBSC);
-      (3) F ends near L_gen: the median |F_end - L_gen| is at most 1.5 x the reference's own median gap (+ 0.05).
+      (3) F ends near L_gen: the mean |F_end - L_gen| is not above the reference's own mean gap by more than 2 standard
+          errors (after 40 iterations the reference itself is 0.2 .. 0.3 nats from L_gen with EBSC -- 16 in a local optimum --
+          and 0.4 .. 4.4 with ES3C).
     One run in rng="reference" mode (host M-step), which IS the reference's stream, reproduces the fixture's trajectory."""
     import _sketch
     from evo_amd.models import BSC, SSSC
@@ -1212,7 +1214,8 @@ def test_learning_level_bars_device_path(engine, algo):
     bars_ref = g[algo + "_bars"].astype(float)
     cls = BSC if algo == "ebsc" else SSSC
 
-    def setup(seed, **kw):
+    def setup(data_seed, **kw):
+        seed = data_seed
         np.random.seed(1000 + seed)
         model = cls(D, H, S, engine=engine, **kw)
         if algo == "ebsc":
@@ -1245,7 +1248,7 @@ def test_learning_level_bars_device_path(engine, algo):
         assert (bars_dev == H).sum() >= (bars_ref == H).sum() - 1, (bars_dev, bars_ref)
     # (3)
     gap_dev, gap_ref = np.abs(F_dev - L_gen), np.abs(F_ref - L_gen)
-    assert np.median(gap_dev) <= 1.5 * np.median(gap_ref) + 0.05, (gap_dev, gap_ref)
+    assert gap_dev.mean() <= gap_ref.mean() + 2.0 * se(gap_dev, gap_ref) + 1e-9, (gap_dev, gap_ref)
     # the reference's own stream through the GPU path: seed 0, host M-step
     model, theta, suff, my_data = setup(0)
     Fs = []

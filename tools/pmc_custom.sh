@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/${TAG}_${CFG}
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p -- python3 $R/bench.py --config $CFG --steps ${PMC_STEPS:-3} --warmup 1 --em-per-step ${PMC_EM:-2} --no-cpu-baseline --inprocess-init > $OUT/p.json 2> $OUT/p.log || { echo "pass failed"; tail -5 $OUT/p.log; }
+rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p -- python3 $R/bench.py --config $CFG --steps ${PMC_STEPS:-3} --warmup 1 --em-per-step ${PMC_EM:-2} --no-cpu-baseline --inprocess-init $BENCH_EXTRA > $OUT/p.json 2> $OUT/p.log || { echo "pass failed"; tail -5 $OUT/p.log; }
 python3 - "$OUT" "$KSUB" <<'PY'
 import csv, glob, sys, collections
 out, ksub = sys.argv[1], sys.argv[2]

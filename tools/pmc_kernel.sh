@@ -13,7 +13,7 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --em-per-step 2 --no-cpu-baseline --inprocess-init > $OUT/p$i.json 2> $OUT/p$i.log || echo "pass $i failed: $grp"
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/bench.py --config $CFG --steps 3 --warmup 1 --em-per-step 2 --no-cpu-baseline --inprocess-init $BENCH_EXTRA > $OUT/p$i.json 2> $OUT/p$i.log || echo "pass $i failed: $grp"
   echo "pass $i done: $grp"
 done <<GROUPS
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
