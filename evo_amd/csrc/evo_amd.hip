@@ -317,14 +317,17 @@ struct evoamd_ctx {
   int stats_flat = 0;   // option "stats_flat": census mode, states with <= 2 latents on the thread-per-state kernel instead of
                         // the wave-per-datapoint one.  Measured (c4, steady state): 504-539 vs 584 us for the kernel, but the
                         // quad levels then share 256 bin regions instead of 2048 (107 vs 69 us) and N / 8 shards lose: off
-  // fused per-datapoint E-step (kernels_fused.hpp): option "fused_estep" 0 never / 1 when K^n is sparse enough (default) /
-  // 2 whenever the shape allows it; rowF / rowcnt = per-datapoint free-energy term and counters, defer = datapoints the
+  // fused per-datapoint E-step (kernels_fused.hpp): option "fused_estep" 0 never (default: measured slower than the separate
+  // passes at every BASELINE shape) / 1 when K^n is sparse enough / 2 whenever the shape allows it; rowF / rowcnt = per-datapoint free-energy term and counters, defer = datapoints the
   // FAST instantiation left to the FULL one (N items + the counter behind them)
-  int fused_opt = 1;
+  int fused_opt = 0;
   double *rowF = nullptr;
   int *rowcnt = nullptr, *defer = nullptr;
   double *fpart = nullptr;  // 3 x 1024 chain sums of fused_reduce3_kernel
+  unsigned long long *fprof = nullptr;  // -DFUSED_PROFILE builds
   bool last_estep_fused = false;
+  bool levels_only = false;  // launch_sssc_lpj<0>: the census levels without the main kernel (the fused E-step evaluates <= 2 latents itself)
+  bool reduce_pending = false;  // fused E-step: rowF / rowcnt not yet summed into the scalar block (fused_reduce3_kernel)
   long fused_calls = 0, unfused_calls = 0;
   int debug_poison_list = 0;  // option "debug_poison_list" (tests): the next census gets an out-of-range entry
   int census_skip = 0;  // levels that passes over the CURRENT census did not launch (checked when it is rebuilt)
@@ -1823,7 +1826,7 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     const int ccap = (int)list_cap(total);
     const ListIn cA = {c->clist, c->clist_n, ccap}, cB = {c->clist + c->clist_words, c->clist_n + LIST_SHARDS, ccap},
                  cC = {c->clist + 2 * c->clist_words, c->clist_n + 2 * LIST_SHARDS, ccap};
-    {
+    if (!c->levels_only) {
       SpanGuard g(c, kid_main);
       const int rows_cap = 1024 / a.C + 2;
       const int stage_dg = a.H <= 512;
@@ -2291,12 +2294,19 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
 // per datapoint (kernels_fused.hpp); otherwise the separate passes run -- same results bit for bit.
 // ---------------------------------------------------------------------------------------
 static bool fused_shape_ok(const evoamd_ctx *c, int n_parents, int n_children) {
+  // (the LDS condition is the one under which launch_sssc_lpj<0> serves K^n from the census lists)
   return c->model == EVOAMD_MODEL_SSSC && c->S_perm == 0 && !c->mask_infr && c->use_digest && c->dig && census_mode(c) &&
-         c->H <= 1024 && c->H >= 2 && n_parents * n_children <= 64 && n_parents * n_children <= c->Cmax && c->rowF && c->defer;
+         c->H <= 1024 && c->H >= 2 && (c->H % 2) == 0 && n_parents * n_children <= 64 && n_parents * n_children <= c->Cmax &&
+         c->rowF && c->defer &&
+         ((size_t)(1024 / c->S + 2) * c->H + (c->H <= 512 ? (size_t)4 * c->H : 0)) * sizeof(double) <= MAIN_LPJ_LDS_MAX;
 }
 
+static int flush_reduce(evoamd_ctx *c);
+
 static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime) {
-  int r = ensure_B(c);
+  int r = flush_reduce(c);  // (a previous fused E-step whose counters nobody has read yet)
+  if (r) return r;
+  r = ensure_B(c);
   if (r) return r;
   Batch b = {c->states, nullptr, c->Y, c->Bm, c->yy, c->N, c->S, 0, c->lpj, c->L, 0, c->flags, KID_LPJ_RES, 0};
   FusedArgs f = {};
@@ -2317,48 +2327,64 @@ static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint
   f.flags_res = c->flags;
   f.flags_cand = c->flags + c->N;
   f.list_cap = (int)c->N;
+#ifdef FUSED_PROFILE
+  if (!c->fprof) {
+    HIP_TRY(hipMalloc((void **)&c->fprof, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->fprof, 0, 8 * sizeof(unsigned long long)));
+  }
+  f.prof = c->fprof;
+#endif
   f.cand = c->cand;
   f.Cmax = c->Cmax;
-  int *list1 = c->defer, *cnt1 = c->defer + c->N, *list2 = c->defer + c->N + 1, *cnt2 = c->defer + 2 * c->N + 1;
+  int *list1 = c->defer, *cnt1 = c->defer + c->N;
   const int SPL = c->S <= 64 ? 1 : (c->S <= 128 ? 2 : (c->S <= 256 ? 4 : (c->S <= 512 ? 8 : 16)));
   const size_t tab = (size_t)4 * c->H * sizeof(double);
+  // resident states above two latents: the list kernels over the census of THIS K^n (built by the last fused call or by
+  // census_kernel), sixteen states per wave pass; their values land in the lpj row the fused kernel reads
+  {
+    c->levels_only = true;
+    const int rl = lpj_resident_launch(c, c->lpj);
+    c->levels_only = false;
+    if (rl) return rl;
+  }
   HIP_TRY(hipMemsetAsync(cnt1, 0, sizeof(int), c->stream));
-  HIP_TRY(hipMemsetAsync(cnt2, 0, sizeof(int), c->stream));
-  // the census of the new K^n is built by the kernels themselves: a level that no pass over the OLD census launched must
-  // have had an empty list; then fresh counters (what ensure_census does in front of census_kernel)
-  check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
-  c->census_skip = 0;
-  f.cen_items = c->clist;
-  f.cen_n = c->clist_n;
-  f.cen_stride = (i64)c->clist_words;
-  f.cen_cap = (int)list_cap(c->N * (i64)c->S);
+  // the census of the NEW K^n: by the kernel itself on small shards (a launch saved), by census_kernel on large ones (its
+  // 35-47 us at the north-star shape are less than the ~70 the ballots and reservations cost inside the fused kernel)
+  const bool inkernel_census = c->N * (i64)c->S < ((i64)4 << 20);
+  if (inkernel_census) {
+    check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
+    c->census_skip = 0;
+    f.cen_items = c->clist;
+    f.cen_n = c->clist_n;
+    f.cen_stride = (i64)c->clist_words;
+    f.cen_cap = (int)list_cap(c->N * (i64)c->S);
+  }
   SpanGuard g(c, KID_ESTEP_FUSED);
-  // three launches of one body: FAST over all datapoints, FULL with LDS for 16 latents per state over what FAST left,
-  // FULL with LDS for up to SSSC_KCAP latents over what that left (the lists live on the device: an empty one costs a launch)
-  for (int stage = 0; stage < 3; stage++) {
-    const bool full = stage > 0;
-    f.in_items = stage == 0 ? nullptr : (stage == 1 ? list1 : list2);
-    f.in_count = stage == 0 ? nullptr : (stage == 1 ? cnt1 : cnt2);
-    f.out_items = stage == 0 ? list1 : (stage == 1 ? list2 : nullptr);
-    f.out_count = stage == 0 ? cnt1 : (stage == 1 ? cnt2 : nullptr);
-    int W = stage == 0 ? 4 : (stage == 1 ? 4 : 1);
-    f.kc_big = stage == 2 ? SSSC_KCAP : 16;
-    f.stage_d1 = stage < 2;
-    f.lds_wave_bytes = fused_lds_wave_bytes(SPL, full, f.kc_big);
+  // two launches of one body: every datapoint with LDS for 16 latents per pivoted child, then -- from a list on the device,
+  // empty in practice -- the datapoints that met a denser child, one wave per workgroup with LDS for SSSC_KCAP latents
+  for (int stage = 0; stage < 2; stage++) {
+    f.in_items = stage == 0 ? nullptr : list1;
+    f.in_count = stage == 0 ? nullptr : cnt1;
+    f.out_items = stage == 0 ? list1 : nullptr;
+    f.out_count = stage == 0 ? cnt1 : nullptr;
+    int W = stage == 0 ? 4 : 1;
+    f.kc_big = stage == 0 ? 16 : SSSC_KCAP;
+    f.stage_d1 = stage == 0;
+    f.lds_wave_bytes = fused_lds_wave_bytes(SPL, f.kc_big);
     auto lds_of = [&](int w) { return (f.stage_d1 ? tab : 0) + (size_t)w * f.lds_wave_bytes; };
-    while (stage == 2 && lds_of(1) > 150 * 1024 && f.kc_big > 16) {  // (S = 1024: the rows leave room for fewer latents)
+    while (stage == 1 && lds_of(1) > 150 * 1024 && f.kc_big > 16) {  // (S = 1024: the rows leave room for fewer latents)
       f.kc_big -= 4;
-      f.lds_wave_bytes = fused_lds_wave_bytes(SPL, full, f.kc_big);
+      f.lds_wave_bytes = fused_lds_wave_bytes(SPL, f.kc_big);
     }
     while (W > 1 && lds_of(W) > 150 * 1024) W >>= 1;
     const size_t lds = lds_of(W);
-    REQUIRE(lds <= 150 * 1024, "fused E-step: H too large for the LDS rows");
+    REQUIRE(lds <= 150 * 1024, "fused E-step: S too large for the LDS rows");
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    per_cu = std::max(1, std::min(per_cu, 8 / W));  // two waves per SIMD (256 registers: the scratch traffic of a tighter budget cost 10x)
+    per_cu = std::max(1, std::min(per_cu, 8 / W));  // two waves per SIMD (256 registers; four waves with scratch traffic ran the same)
     const unsigned grid = (unsigned)std::min<i64>(cdiv(c->N, W), (i64)c->n_cu * per_cu);
 #define FUSED_LAUNCH(SPLV)                                                               \
   do {                                                                                   \
-    if (full)                                                                            \
+    if (stage)                                                                           \
       sssc_estep_fused_kernel<SPLV, true><<<grid, 64 * W, lds, c->stream>>>(f);          \
     else                                                                                 \
       sssc_estep_fused_kernel<SPLV, false><<<grid, 64 * W, lds, c->stream>>>(f);         \
@@ -2372,8 +2398,28 @@ static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint
     }
 #undef FUSED_LAUNCH
     HIP_TRY(hipGetLastError());
-    DBG_SYNC(c, stage == 0 ? "fused E-step (FAST)" : (stage == 1 ? "fused E-step (FULL, 16 latents)" : "fused E-step (FULL, KCAP latents)"));
+    DBG_SYNC(c, stage == 0 ? "fused E-step" : "fused E-step (listed datapoints, KCAP latents)");
   }
+  c->reduce_pending = true;  // summed in front of the first reader (statistics pass: beside the forked contraction)
+#ifdef FUSED_PROFILE
+  {
+    unsigned long long h[8];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(h, c->fprof, sizeof(h), hipMemcpyDeviceToHost));
+    if ((c->fused_calls % 50) == 49) {
+      fprintf(stderr, "[fused profile] wave cycles per datapoint:");
+      for (int i = 0; i < 8; i++) fprintf(stderr, " p%d %.0f", i, (double)h[i] / (double)c->N / (double)(c->fused_calls + 1));
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
+  return 0;
+}
+
+// rowF / rowcnt of the fused E-step -> dpar[DP_FS], dpar[DP_ECNT0 / 1]
+static int flush_reduce(evoamd_ctx *c) {
+  if (!c->reduce_pending) return 0;
+  c->reduce_pending = false;
   fused_reduce3_kernel<<<FR3_BLOCKS, R3_THREADS / FR3_BLOCKS, 0, c->stream>>>(c->rowF, c->rowcnt, c->N, c->dpar, c->fpart,
                                                                               (unsigned *)(c->defer + 2 * (c->N + 1)));
   HIP_TRY(hipGetLastError());
@@ -2409,7 +2455,7 @@ extern "C" int evoamd_estep(evoamd_ctx *c, int n_parents, int n_children, uint64
   if (r) return r;
   c->gen++;
   c->kn_gen++;
-  c->census_gen = c->kn_gen;  // the fused kernels listed the new K^n on the way
+  if (c->N * (i64)c->S < ((i64)4 << 20)) c->census_gen = c->kn_gen;  // the fused kernel listed the new K^n on the way
   c->rows_fresh = true;
   c->have_cand = false;  // the children never left the kernel
   c->cand_from_device = true;
@@ -2427,9 +2473,7 @@ extern "C" int evoamd_estep_counters(evoamd_ctx *c, int64_t out[4]) {
     int h[2] = {0, 0};
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(&h[0], c->defer + c->N, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&h[1], c->defer + 2 * c->N + 1, sizeof(int), hipMemcpyDeviceToHost));
     out[2] = h[0];
-    out[3] = h[1];
   }
   return 0;
 }
@@ -2536,6 +2580,7 @@ static int row_lse(evoamd_ctx *c, const double *lpj, i64 N, int L, double *rowma
 // Everything of evoamd_stats up to (and including) the all-reduce; the packed accumulator stays on
 // the device.  tail[7] receives ljc of the Theta the E-step ran with.
 static int compute_reconstruction(evoamd_ctx *c);
+static int flush_reduce(evoamd_ctx *c);
 
 // the forked statistics contraction must have finished before anything reads its part of acc
 static int join_fork(evoamd_ctx *c) {
@@ -3035,6 +3080,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       c->gemm_forked = true;  // the caller joins (after the H x H inverses)
     else
       HIP_TRY(hipStreamWaitEvent(main_stream, c->ev_join, 0));
+  }
+  {
+    int rfr = flush_reduce(c);  // fused E-step: free-energy term and counters into the scalar block (beside the forked contraction)
+    if (rfr) return rfr;
   }
   {
     SpanGuard g(c, KID_MISC);

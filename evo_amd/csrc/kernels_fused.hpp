@@ -13,15 +13,17 @@
 // generator draws the same counter-based random numbers, the selection applies the same tie rules: for a given seed the
 // fused path leaves the same K^n and the same lpj bits as the separate kernels (tests/test_gpu_fused.py).
 //
-// Two instantiations share the body:
-//   FAST  every state the datapoint meets -- resident and child -- has at most four active latents, so every digest IS its
-//         state: no bit word is read, child digests come from the parent's digest, accepted children are written back
-//         from their digests.  A datapoint that meets anything else (a state above four latents, a state whose elimination
-//         needs row exchanges, exact mode with a state above two latents) is left UNTOUCHED and its index appended to a list.
-//   FULL  serves that list with everything the separate kernels have: bit words, the 5..8 quad form, the pivoting
-//         wavefront form -- with LDS for 16 latents per state first (four waves per workgroup); a datapoint that meets a
-//         denser state moves on to a second list, served by a launch with LDS for SSSC_KCAP latents (one wave per
-//         workgroup).  Low occupancy, few datapoints.
+// Who evaluates what:
+//   * resident states with at most two active latents: here, from the state-term tables (sssc_k2_value);
+//   * resident states above two latents: the LIST kernels over the census of this K^n, launched in front of this kernel
+//     (sixteen states per wave pass instead of the handful one datapoint holds: in-wave they cost a third of this
+//     kernel's vector instructions for a few per cent of the states) -- this kernel finds their values in the lpj row;
+//   * children: here, all of them -- tables, four lanes per state for 3..4 and for 5..8 latents, the pivoting wavefront
+//     form for the rest, the states that need row exchanges and exact mode, with LDS for 16 latents per state; a datapoint
+//     that meets a denser child is left UNTOUCHED and moves on to a list served by a second launch with LDS for SSSC_KCAP
+//     latents (one wave per workgroup; empty in practice).
+// A child's digest comes from its parent's digest (no bit word is read while states hold at most DIG_SLOTS latents), an
+// accepted child is written back from its digest.
 // Complete data, digests, S_perm = 0, randflip x 1 generation, at most 64 children per datapoint (the examples' 10).
 #pragma once
 #include "kernels_evolve.hpp"
@@ -37,9 +39,8 @@ struct FusedArgs {
   double *rowmax, *rowsum, *rowF;   // (N) each: max_s lpj, sum_s exp(lpj - max), logsumexp of the new row
   int *rowcnt;                      // (N): #new unique children | #swapped << 16  (variational/utils.py:336-337)
   unsigned *flags_res, *flags_cand; // (N) clamp flags of the two lpj "calls" of a datapoint (_models.py:581-594)
-  // datapoints an instantiation cannot serve are left UNTOUCHED and appended to out_*; in_* (FULL) is the list the launch
-  // before appended.  FAST: natural order -> list 1; FULL with 16 latents of LDS per state: list 1 -> list 2; FULL with 64
-  // (one wave per workgroup): list 2 -> nothing (a state above that raises the same error as the separate kernels)
+  // a datapoint the first launch cannot serve (a child above kc_big = 16 latents) is left UNTOUCHED and appended to out_*;
+  // the second launch (LISTED, one wave per workgroup, LDS for SSSC_KCAP latents) reads that list through in_*
   const int *in_items, *in_count;
   int *out_items, *out_count;
   int list_cap;
@@ -50,11 +51,22 @@ struct FusedArgs {
   int *cen_items, *cen_n;
   i64 cen_stride;
   int cen_cap;
-  u64 *cand;                        // FULL: (N, Cmax, HW) children's bit words (scratch)
+  u64 *cand;                        // (N, Cmax, HW) scratch rows: bit words of the children above DIG_SLOTS latents
   int Cmax;
-  int kc_big;                       // FULL: latents the pivoting form holds (LDS: big_lds(kc_big) per wave)
+  int kc_big;                       // latents the pivoting form holds (LDS: big_lds(kc_big) per wave)
   int lds_wave_bytes;               // bytes of dynamic LDS per wave (host: fused_lds_wave_bytes)
+  unsigned long long *prof;         // -DFUSED_PROFILE builds only: per-phase wave cycles (s_memtime), 8 slots
 };
+#ifdef FUSED_PROFILE
+#define FPROF(slot)                                                                    \
+  do {                                                                                 \
+    const unsigned long long _t = __builtin_readcyclecounter();                        \
+    if (lane == 0 && f.prof) atomicAdd(&f.prof[slot], _t - _tp);                       \
+    _tp = _t;                                                                          \
+  } while (0)
+#else
+#define FPROF(slot) do {} while (0)
+#endif
 
 // Digest of the state that differs from the state with COMPLETE digest `pd` (at most DIG_SLOTS latents) in latent h.
 __device__ __forceinline__ u64 digest_toggle(const u64 pd, const int h) {
@@ -108,31 +120,31 @@ __device__ __forceinline__ u64 load_sc0(const u64 *p) {
 }
 
 // dynamic LDS: [H double4 singleton table] + waves x fused_lds_wave_bytes.  Per wave: the datapoint's lpj row and digests
-// (SPL x 64 each), the children's digests and lpj (64 each), the accepted swaps, the level lists; FULL adds the latents of
-// a 5..8 pass and the k x k system of the pivoting form.  (The B row is NOT staged: the ~2 S gathers per 4 KB row hit the
-// caches, and without it sixteen waves per CU fit -- this kernel lives on latency hiding, not on LDS bandwidth.)
-__host__ __device__ inline int fused_lds_wave_bytes(int SPL, bool full, int kc_big) {
+// (SPL x 64 each), the children's digests and lpj (64 each), the accepted swaps, the level lists, the latents of a 5..8
+// pass and the k x k system of the pivoting form (kc_big latents).  (The B row is NOT staged: the ~2 S gathers per 4 KB
+// row hit the caches.)
+__host__ __device__ inline int fused_lds_wave_bytes(int SPL, int kc_big) {
   int b = SPL * 64 * 8 * 2;            // rowL, rowD
   b += 64 * 8 * 3;                     // cdig, cval, new_v
-  b += ((SPL + 1) * 64 * 2 + 7) / 8 * 8 * 2;  // lst, hlst (u16)
+  b += 64 * 2 * 2;                     // lst, hlst (u16): children only
   b += 64 * 4 * 3;                     // sel, new_i, old_i
   b += 32 * 4;                         // dbuf: deferred datapoints waiting for ONE reservation per 32
-  if (full) {
-    b += (16 * 8 + 16) * 4;                                            // idxb, kcnt: latents of 16 states with 5..8
-    b += (4 * kc_big * kc_big + 5 * kc_big) * 8 + ((kc_big * 4 + 7) / 8) * 8;  // BigLds
-  }
+  b += (16 * 8 + 16) * 4;              // idxb, kcnt: latents of 16 states with 5..8
+  b += (4 * kc_big * kc_big + 5 * kc_big) * 8 + ((kc_big * 4 + 7) / 8) * 8;  // BigLds
   return (b + 15) / 16 * 16;
 }
 
-template <int SPL, bool FULL>
+// LISTED: the datapoints come from in_items (second launch, more LDS per state); else natural order.
+template <int SPL, bool LISTED>
 __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
   SsscArgs &a = f.a;
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double fsm[];
   constexpr int SP = SPL * 64;
-  constexpr int LSTB = ((SPL + 1) * 64 * 2 + 7) / 8 * 8;
   const int H = a.H, HW = a.HW, S = f.S;
   const int lane = lane_id(), wave = wave_id_uniform(), W = (int)(blockDim.x >> 6);
+  const i64 count = LISTED ? (i64)min(*f.in_count, f.list_cap) : a.N;
+  if (LISTED && count == 0) return;  // (uniform: the usual case)
   double4 *d1s = (double4 *)fsm;
   char *wb = (char *)(fsm + (f.stage_d1 ? (size_t)4 * H : 0)) + (size_t)wave * f.lds_wave_bytes;
   double *rowL = (double *)wb;            // lpj of the resident states (clamped), slot s
@@ -141,16 +153,14 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
   double *cval = (double *)(cdig + 64);   // ... and lpj (clamped)
   double *new_v = cval + 64;
   unsigned short *lst = (unsigned short *)(new_v + 64);
-  unsigned short *hlst = (unsigned short *)((char *)lst + LSTB);
-  int *sel = (int *)((char *)hlst + LSTB);
+  unsigned short *hlst = lst + 64;
+  int *sel = (int *)(hlst + 64);
   int *new_i = sel + 64, *old_i = new_i + 64;
   int *dbuf = old_i + 64;
-  int *idxb = dbuf + 32;  // FULL only: latents (8 each) and counts of the 16 states of a 5..8 pass
+  int *idxb = dbuf + 32;  // latents (8 each) and counts of the 16 states of a 5..8 pass
   int *kcnt = idxb + 16 * 8;
   BigLds BL;
-  if (FULL) BL.carve((double *)(kcnt + 16), f.kc_big);
-  const i64 count = FULL ? (i64)min(*f.in_count, f.list_cap) : a.N;
-  if (FULL && count == 0) return;  // (uniform: the usual case for the second FULL launch)
+  BL.carve((double *)(kcnt + 16), f.kc_big);
   if (f.stage_d1) {
     for (int i = threadIdx.x; i < H; i += blockDim.x) d1s[i] = a.D1[i];
     __syncthreads();
@@ -162,8 +172,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
   const u64 lt_mask = (1ull << lane) - 1ull;
   const int t4 = lane & 3, qd = lane >> 2;
   auto level_of = [](const int k) { return k > 8 ? 3 : (k > 4 ? 2 : (k > 2 ? 1 : 0)); };
-  // Deferred datapoints leave in batches: a returning atomic on ONE counter sustains ~90 per us (MI355X guide, "dequeue"),
-  // and an early K^n defers a third of the datapoints -- one atomic per datapoint was 0.5 ms of this kernel.
+  // Deferred datapoints leave in batches (a returning atomic on ONE counter sustains ~90 per us)
   int dn = 0;  // wave-uniform: entries waiting in dbuf
   auto flush_defer = [&]() {
     int base = 0;
@@ -179,24 +188,32 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
     lds_wave_fence();
   };
   for (i64 it = (i64)blockIdx.x * W + wave; it < count; it += (i64)gridDim.x * W) {
-    const i64 n = FULL ? (i64)guard_index(f.in_items[it], a.N, a.err) : it;
+    const i64 n = LISTED ? (i64)guard_index(f.in_items[it], a.N, a.err) : it;
+#ifdef FUSED_PROFILE
+    unsigned long long _tp = __builtin_readcyclecounter();
+#endif
     const u64 *dgn = f.dig + n * (i64)S;
     const u64 *st_n = f.states + n * (i64)S * HW;
-    const u64 *cw_n = FULL ? f.cand + n * (i64)f.Cmax * HW : nullptr;
+    u64 *cw_n = f.cand + n * (i64)f.Cmax * HW;
+    double *lpj_n = f.lpj + n * (i64)S;
     const double *Bn = a.Bm + n * (i64)H;
     const double yyn = a.yy[n];
     unsigned fl_res = 0, fl_cand = 0;  // clamp flags raised by this lane (OR-ed over the wave at the end)
     bool defer = false;                // wave-uniform
-    int hcnt = 0;                      // wave-uniform: states the quad levels handed on (hlst)
+    int hcnt = 0;                      // wave-uniform: children the quad levels handed on (hlst)
     // ------------------------------------------------------------------ phase 1: lpj of the resident states
-    bool above2 = false, above4 = false;
+    // at most two active latents: from the state-term tables, here; more: evaluated by the list kernels over the census
+    // of this K^n before this kernel ran (sssc_quad_kernel<1 | 2, 0, 0>, sssc_big_kernel<0, 0>: sixteen states per wave
+    // pass instead of the handful one datapoint holds) -- their values, clamped and flagged, wait in the lpj row
     {
       u64 dg[SPL];
+      double pre[SPL];
       PairEntry pe[SPL];
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
         const int s = lane + 64 * q;
         dg[q] = dgn[s < S ? s : 0];
+        pre[q] = lpj_n[s < S ? s : 0];
       }
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
@@ -205,166 +222,22 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
         const int k = dig_k(dg[q]);
         pe[q] = a.PT[k == 2 ? (i64)dig_idx(dg[q], 0) * H + dig_idx(dg[q], 1) : 0];
         rowD[lane + 64 * q] = dg[q];
-        above2 = above2 || k > 2;
-        above4 = above4 || k > 4;
       }
 #pragma unroll
       for (int q = 0; q < SPL; q++) {
         const bool live = lane + 64 * q < S;
         const int k = dig_k(dg[q]);
-        double v = 0.0;
+        double v = live ? pre[q] : 0.0;
         if (live && k <= 2)
           v = clamp_lpj(sssc_k2_value(k, dig_idx(dg[q], 0), dig_idx(dg[q], 1), D1t, Bn, pe[q], yyn, s2, a.err), fl_res);
         rowL[lane + 64 * q] = v;
       }
     }
     lds_wave_fence();
-    // One level of listed states: lst[0 .. cnt) holds their slots (resident: s; children: the child's lane).
-    // LVL 1: four lanes per state (3..4 latents, from the digest); LVL 2: four lanes per state, two columns each (5..8
-    // latents, from the bit words).  Values go straight to the row (rowL / cval); a state the elimination cannot do
-    // without row exchanges is handed on through hlst (FULL: the pivoting form below; FAST: the datapoint is deferred).
-    auto eval_quads = [&](auto lvl_tag, const int cnt, const bool cand) {
-      constexpr int LVL = decltype(lvl_tag)::value;
-      constexpr int C = LVL == 2 ? 2 : 1, K = 4 * C;
-      for (int pb = 0; pb < cnt; pb += 16) {  // uniform
-        const int ei = pb + qd;
-        const bool live = ei < cnt;
-        const int slot = live ? (int)lst[ei] : 0;
-        int idx[K], cidx[C], ks = 0;
-        if (LVL == 1) {
-          const u64 d = !live ? 0ull : (cand ? cdig[slot] : rowD[slot]);
-          ks = dig_k(d);
-#pragma unroll
-          for (int i = 0; i < K; i++) idx[i] = i < ks ? dig_idx(d, i) : 0;
-        } else {
-          // the latents of the pass's 16 states from their bit words, one state after the other (the whole wave scans)
-          for (int e = 0; e < 16 && pb + e < cnt; e++) {
-            const int sl = (int)lst[pb + e];
-            const u64 *sp = cand ? cw_n + (i64)sl * HW : st_n + (i64)sl * HW;
-            int kk = 0;  // (children's words were written by this wave: coherent loads)
-            const u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
-            for (int w = 0; w < HW; w++) {
-              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
-              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
-              const u64 bits = ((u64)hi << 32) | lo;
-              const bool on = (bits >> (63 - lane)) & 1ull;
-              const u64 m = __ballot(on);
-              const int pos = kk + __popcll(m & lt_mask);
-              if (on && pos < 8) idxb[e * 8 + pos] = w * 64 + lane;
-              kk += __popcll(m);
-            }
-            if (lane == 0) {
-              if (kk > 8 || kk < 5) atomicOr(a.err, EVO_ERR_BAD_ENTRY);  // the digest's count said 5..8
-              kcnt[e] = kk < 8 ? kk : 8;
-            }
-          }
-          lds_wave_fence();
-          ks = live ? kcnt[qd] : 0;
-#pragma unroll
-          for (int i = 0; i < K; i++) idx[i] = i < ks ? guard_index(idxb[qd * 8 + i], H, a.err) : 0;
-          lds_wave_fence();
-        }
-#pragma unroll
-        for (int j = 0; j < C; j++) {
-          const int cc = t4 * C + j;
-          int v = 0;
-#pragma unroll
-          for (int i = 0; i < K; i++) v = (i == cc) ? idx[i] : v;
-          cidx[j] = v;
-        }
-        double val = 0.0, kap_all[K], Lam[K][C];
-        bool hard = false;
-        quad_solve<C, 0>(a, t4, ks, idx, cidx, Bn, yyn, val, hard, kap_all, Lam);
-        hard = hard && ks > 0 && live;
-        if (live && t4 == 0 && !hard) {
-          if (cand)
-            cval[slot] = clamp_lpj(val, fl_cand);
-          else
-            rowL[slot] = clamp_lpj(val, fl_res);
-        }
-        const u64 hm = __ballot(hard && t4 == 0);
-        if (hm != 0ull) {  // uniform
-          if (!FULL) defer = true;
-          if (hard && t4 == 0) hlst[hcnt + __popcll(hm & lt_mask)] = (unsigned short)slot;
-          hcnt += __popcll(hm);
-        }
-      }
-      lds_wave_fence();
-    };
-    // resident slots whose level (from the digest's count) is L -> lst; returns the count (uniform)
-    auto compact_res = [&](const int L, const bool all_above2) {
-      int cnt = 0;
-#pragma unroll
-      for (int q = 0; q < SPL; q++) {
-        const int lvq = level_of(dig_k(rowD[lane + 64 * q]));
-        const bool on = all_above2 ? lvq >= 1 : lvq == L;
-        const u64 m = __ballot(on);
-        if (on) lst[cnt + __popcll(m & lt_mask)] = (unsigned short)(lane + 64 * q);
-        cnt += __popcll(m);
-      }
-      lds_wave_fence();
-      return cnt;
-    };
-    // the pivoting wavefront form, one listed state after the other (FULL only): lst[0 .. cnt) then hlst[0 .. hcnt)
-    auto eval_big = [&](const int cnt, const bool cand) {
-      for (int e = 0; e < cnt + hcnt && !defer; e++) {
-        const int slot = e < cnt ? (int)lst[e] : (int)hlst[e - cnt];
-        const u64 *sp = cand ? cw_n + (i64)slot * HW : st_n + (i64)slot * HW;
-        lds_wave_fence();
-        int k = 0;
-        {
-          const u64 myword = (lane < HW) ? (cand ? load_sc0(sp + lane) : sp[lane]) : 0ull;
-          for (int w = 0; w < HW; w++) {
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
-            const u64 bits = ((u64)hi << 32) | lo;
-            const bool on = (bits >> (63 - lane)) & 1ull;
-            const u64 m = __ballot(on);
-            const int pos = k + __popcll(m & lt_mask);
-            if (on && pos < f.kc_big) BL.idx[pos] = w * 64 + lane;
-            k += __popcll(m);
-          }
-        }
-        double val = EVO_F64_MIN;
-        bool flagged = true;
-        if (k > f.kc_big) {  // uniform
-          if (f.out_items)
-            defer = true;  // on to the launch with more LDS per state
-          else if (lane == 0)
-            atomicOr(a.err, 1);
-          flagged = false;  // (above SSSC_KCAP the separate kernels store finfo.min unflagged and raise the error)
-        } else {
-          const int rc = big_solve<0, false>(a, n, k, BL, lane, exact, Bn, yyn, val);
-          if (rc == 2) val = __builtin_inf();
-        }
-        if (lane == 0) {
-          if (cand)
-            cval[slot] = flagged ? clamp_lpj(val, fl_cand) : val;
-          else
-            rowL[slot] = flagged ? clamp_lpj(val, fl_res) : val;
-        }
-      }
-      hcnt = 0;
-      lds_wave_fence();
-    };
-    if (!FULL && (__any(above4) || (exact && __any(above2)))) defer = true;
-    if (!defer && __any(above2)) {
-      if (!exact) {
-        const int c1 = compact_res(1, false);
-        if (c1) eval_quads(std::integral_constant<int, 1>{}, c1, false);
-        if (FULL) {
-          const int c2 = compact_res(2, false);
-          if (c2) eval_quads(std::integral_constant<int, 2>{}, c2, false);
-        }
-      }
-      if (FULL) {  // above eight latents + what the quad levels handed on; exact mode: every state above two latents
-        const int c3 = compact_res(3, exact);
-        if (c3 + hcnt) eval_big(c3, false);
-      }
-    }
+    FPROF(0);
     // ------------------------------------------------------------------ phase 2: parents (eas.py:138-150)
     // (evolve_randflip_kernel's arithmetic on the clamped lpj values the separate kernels read back from memory)
-    if (!defer) {
+    {
       double ov[SPL];
       double lmin = INFINITY;
 #pragma unroll
@@ -412,81 +285,189 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
       }
       lds_wave_fence();
     }
+    FPROF(1);
     // ------------------------------------------------------------------ phase 3: children (randflip, eas.py:10-43)
+    // A child's digest comes from its parent's digest when that is complete (at most DIG_SLOTS latents: no bit word is
+    // read); the child's WORDS are written to the scratch rows only where something will read them -- a child above
+    // DIG_SLOTS latents (its latents for the elimination, the word compare of the de-duplication, the swap).
     u64 cd = 0ull;  // digest of this lane's child
     int clv = 0;
-    if (!defer) {
-      const bool kid = lane < n_kids;
-      if (kid) {
-        const int p = lane / f.n_children, i = lane - p * f.n_children;
-        int picks[EV_MAX_CHILDREN];
-        int mine = 0;
-        for (int t = 0; t <= i; t++) {
-          int r = (int)(rng_u01(f.seed, (u64)n, 2 + (u64)p, (u64)t) * (double)(H - t));
-          if (r >= H - t) r = H - t - 1;
-          int pos = 0;
-          for (int t2 = 0; t2 < t; t2++)
-            if (picks[t2] <= r) {
-              r++;
-              pos = t2 + 1;
-            }
-          for (int t2 = t; t2 > pos; t2--) picks[t2] = picks[t2 - 1];
-          picks[pos] = r;
-          mine = r;
-        }
-        const int par = guard_index(sel[p], S, a.err);
-        if (!FULL) {
-          cd = digest_toggle(rowD[par], mine);  // (FAST: every resident digest is complete)
-        } else {
-          const u64 *parw = st_n + (i64)par * HW;
-          u64 *dst = f.cand + (n * (i64)f.Cmax + lane) * HW;
-          u64 d = 0;
-          int dk = 0;
-          for (int w0 = 0; w0 < HW; w0 += 8) {
-            u64 pv[8];
+    const bool kid = lane < n_kids;
+    if (kid) {
+      const int p = lane / f.n_children, i = lane - p * f.n_children;
+      int picks[EV_MAX_CHILDREN];
+      int mine = 0;
+      for (int t = 0; t <= i; t++) {
+        int r = (int)(rng_u01(f.seed, (u64)n, 2 + (u64)p, (u64)t) * (double)(H - t));
+        if (r >= H - t) r = H - t - 1;
+        int pos = 0;
+        for (int t2 = 0; t2 < t; t2++)
+          if (picks[t2] <= r) {
+            r++;
+            pos = t2 + 1;
+          }
+        for (int t2 = t; t2 > pos; t2--) picks[t2] = picks[t2 - 1];
+        picks[pos] = r;
+        mine = r;
+      }
+      const int par = guard_index(sel[p], S, a.err);
+      const u64 pd = rowD[par];
+      u64 *dst = cw_n + (i64)lane * HW;
+      const u64 flip = 0x8000000000000000ull >> (mine & 63);
+      if (dig_k(pd) <= DIG_SLOTS) {
+        cd = digest_toggle(pd, mine);
+        if (dig_k(cd) > DIG_SLOTS)  // five latents: the words of a four-latent parent with one bit more
+          for (int w = 0; w < HW; w++) dst[w] = digest_word(pd, w) ^ (w == (mine >> 6) ? flip : 0ull);
+      } else {
+        const u64 *parw = st_n + (i64)par * HW;
+        u64 d = 0;
+        int dk = 0;
+        for (int w0 = 0; w0 < HW; w0 += 8) {
+          u64 pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) pv[u] = (w0 + u < HW) ? parw[w0 + u] : 0ull;
+          for (int u = 0; u < 8; u++) pv[u] = (w0 + u < HW) ? parw[w0 + u] : 0ull;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-              const int w = w0 + u;
-              if (w < HW) {
-                u64 v = pv[u];
-                if (w == (mine >> 6)) v ^= (0x8000000000000000ull >> (mine & 63));
-                dst[w] = v;
-                while (v) digest_add(d, dk, w * 64 + pop_msb(v));
-              }
+          for (int u = 0; u < 8; u++) {
+            const int w = w0 + u;
+            if (w < HW) {
+              u64 v = pv[u];
+              if (w == (mine >> 6)) v ^= flip;
+              dst[w] = v;
+              while (v) digest_add(d, dk, w * 64 + pop_msb(v));
             }
           }
-          cd = digest_close(d, dk);
         }
-        cdig[lane] = cd;
+        cd = digest_close(d, dk);
       }
-      if (FULL) vm_wave_fence();
-      // ---------------------------------------------------------------- phase 4: lpj of the children
-      const int ck = kid ? dig_k(cd) : 0;
-      clv = !kid ? 0 : level_of(ck);
-      if (exact && clv) clv = 3;
-      if (!FULL && __any(clv >= 2)) defer = true;
-      if (!defer) {
-        const PairEntry pe = a.PT[(kid && ck == 2) ? (i64)dig_idx(cd, 0) * H + dig_idx(cd, 1) : 0];
-        if (kid && ck <= 2) cval[lane] = clamp_lpj(sssc_k2_value(ck, dig_idx(cd, 0), dig_idx(cd, 1), D1t, Bn, pe, yyn, s2, a.err), fl_cand);
+      cdig[lane] = cd;
+    }
+    FPROF(2);
+    // ------------------------------------------------------------------ phase 4: lpj of the children
+    const int ck = kid ? dig_k(cd) : 0;
+    clv = !kid ? 0 : level_of(ck);
+    if (exact && clv) clv = 3;
+    const bool wordy = __any(kid && ck > DIG_SLOTS);  // some child's words were written above: make them readable
+    if (wordy) vm_wave_fence();
+    {
+      const PairEntry pe = a.PT[(kid && ck == 2) ? (i64)dig_idx(cd, 0) * H + dig_idx(cd, 1) : 0];
+      if (kid && ck <= 2) cval[lane] = clamp_lpj(sssc_k2_value(ck, dig_idx(cd, 0), dig_idx(cd, 1), D1t, Bn, pe, yyn, s2, a.err), fl_cand);
+    }
+    lds_wave_fence();
+    // One level of listed children: lst[0 .. cnt) holds their lanes.  LVL 1: four lanes per state (3..4 latents, from the
+    // digest); LVL 2: four lanes per state, two columns each (5..8 latents, from the bit words).  A state the elimination
+    // cannot do without row exchanges is handed on through hlst to the pivoting form below.
+    auto eval_quads = [&](auto lvl_tag, const int cnt) {
+      constexpr int LVL = decltype(lvl_tag)::value;
+      constexpr int C = LVL == 2 ? 2 : 1, K = 4 * C;
+      for (int pb = 0; pb < cnt; pb += 16) {  // uniform
+        const int ei = pb + qd;
+        const bool live = ei < cnt;
+        const int slot = live ? (int)lst[ei] : 0;
+        int idx[K], cidx[C], ks = 0;
+        if (LVL == 1) {
+          const u64 d = live ? cdig[slot] : 0ull;
+          ks = dig_k(d);
+#pragma unroll
+          for (int i = 0; i < K; i++) idx[i] = i < ks ? dig_idx(d, i) : 0;
+        } else {
+          // the latents of the pass's 16 states from their bit words, one state after the other (the whole wave scans)
+          for (int e = 0; e < 16 && pb + e < cnt; e++) {
+            const u64 *sp = cw_n + (i64)lst[pb + e] * HW;
+            int kk = 0;  // (the words were written by this wave: coherent loads)
+            const u64 myword = (lane < HW) ? load_sc0(sp + lane) : 0ull;
+            for (int w = 0; w < HW; w++) {
+              const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
+              const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
+              const u64 bits = ((u64)hi << 32) | lo;
+              const bool on = (bits >> (63 - lane)) & 1ull;
+              const u64 m = __ballot(on);
+              const int pos = kk + __popcll(m & lt_mask);
+              if (on && pos < 8) idxb[e * 8 + pos] = w * 64 + lane;
+              kk += __popcll(m);
+            }
+            if (lane == 0) {
+              if (kk > 8 || kk < 5) atomicOr(a.err, EVO_ERR_BAD_ENTRY);  // the digest's count said 5..8
+              kcnt[e] = kk < 8 ? kk : 8;
+            }
+          }
+          lds_wave_fence();
+          ks = live ? kcnt[qd] : 0;
+#pragma unroll
+          for (int i = 0; i < K; i++) idx[i] = i < ks ? guard_index(idxb[qd * 8 + i], H, a.err) : 0;
+          lds_wave_fence();
+        }
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+          const int cc = t4 * C + j;
+          int v = 0;
+#pragma unroll
+          for (int i = 0; i < K; i++) v = (i == cc) ? idx[i] : v;
+          cidx[j] = v;
+        }
+        double val = 0.0, kap_all[K], Lam[K][C];
+        bool hard = false;
+        quad_solve<C, 0>(a, t4, ks, idx, cidx, Bn, yyn, val, hard, kap_all, Lam);
+        hard = hard && ks > 0 && live;
+        if (live && t4 == 0 && !hard) cval[slot] = clamp_lpj(val, fl_cand);
+        const u64 hm = __ballot(hard && t4 == 0);
+        if (hm != 0ull) {  // uniform
+          if (hard && t4 == 0) hlst[hcnt + __popcll(hm & lt_mask)] = (unsigned short)slot;
+          hcnt += __popcll(hm);
+        }
       }
       lds_wave_fence();
-    }
-    if (!defer) {
-      auto compact_cand = [&](const int L) {
-        const bool on = clv == L;
-        const u64 m = __ballot(on);
-        if (on) lst[__popcll(m & lt_mask)] = (unsigned short)lane;
+    };
+    auto compact_cand = [&](const int L) {
+      const bool on = clv == L;
+      const u64 m = __ballot(on);
+      if (on) lst[__popcll(m & lt_mask)] = (unsigned short)lane;
+      lds_wave_fence();
+      return (int)__popcll(m);
+    };
+    FPROF(3);
+    if (__any(clv == 1)) eval_quads(std::integral_constant<int, 1>{}, compact_cand(1));
+    FPROF(4);
+    if (__any(clv == 2)) eval_quads(std::integral_constant<int, 2>{}, compact_cand(2));
+    {
+      // the pivoting wavefront form, one child after the other: above eight latents, what the quad levels handed on, and
+      // in exact mode every child above two latents.  A child above DIG_SLOTS latents has its words in the scratch rows; the
+      // others (handed on with 3..4 latents) are rebuilt from their digests.
+      const int c3 = __any(clv == 3) ? compact_cand(3) : 0;
+      for (int e = 0; e < c3 + hcnt && !defer; e++) {
+        const int slot = e < c3 ? (int)lst[e] : (int)hlst[e - c3];
+        const u64 d = cdig[slot];
         lds_wave_fence();
-        return (int)__popcll(m);
-      };
-      if (__any(clv == 1)) eval_quads(std::integral_constant<int, 1>{}, compact_cand(1), true);
-      if (FULL) {
-        if (__any(clv == 2)) eval_quads(std::integral_constant<int, 2>{}, compact_cand(2), true);
-        const int c3 = __any(clv == 3) ? compact_cand(3) : 0;
-        if (c3 + hcnt) eval_big(c3, true);
+        int k = 0;
+        {
+          u64 myword = 0ull;
+          if (lane < HW) myword = dig_k(d) > DIG_SLOTS ? load_sc0(cw_n + (i64)slot * HW + lane) : digest_word(d, lane);
+          for (int w = 0; w < HW; w++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword & 0xffffffffull), w);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myword >> 32), w);
+            const u64 bits = ((u64)hi << 32) | lo;
+            const bool on = (bits >> (63 - lane)) & 1ull;
+            const u64 m = __ballot(on);
+            const int pos = k + __popcll(m & lt_mask);
+            if (on && pos < f.kc_big) BL.idx[pos] = w * 64 + lane;
+            k += __popcll(m);
+          }
+        }
+        double val = EVO_F64_MIN;
+        bool flagged = true;
+        if (k > f.kc_big) {  // uniform
+          if (f.out_items)
+            defer = true;  // on to the launch with more LDS per state
+          else if (lane == 0)
+            atomicOr(a.err, 1);
+          flagged = false;  // (above SSSC_KCAP the separate kernels store finfo.min unflagged and raise the error)
+        } else {
+          const int rc = big_solve<0, false>(a, n, k, BL, lane, exact, Bn, yyn, val);
+          if (rc == 2) val = __builtin_inf();
+        }
+        if (lane == 0) cval[slot] = flagged ? clamp_lpj(val, fl_cand) : val;
       }
+      hcnt = 0;
+      lds_wave_fence();
     }
     if (defer) {  // nothing of this datapoint has been written: the next launch does it from scratch
       if (lane == 0) dbuf[dn] = (int)n;
@@ -495,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
       if (dn == 32) flush_defer();
       continue;
     }
+    FPROF(5);
     // ------------------------------------------------------------------ phase 5: vary_Kn (variational/utils.py:231-337)
     // (vary_kn_kernel<SPL, 1> with digests: same de-duplication, same ranks, same tie rule)
     int n_uniq = 0, n_sub = 0;
@@ -517,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
           bool dup = false;
           if (dig_k(hc) <= DIG_SLOTS) {
             dup = maybe;  // exact: the digest is the state
-          } else if (FULL && __any(maybe)) {  // rare: confirm with the words (children's words: this wave's own stores)
+          } else if (__any(maybe)) {  // rare: confirm with the words (children above DIG_SLOTS latents have theirs in the scratch rows)
             const u64 *cw = cw_n + (i64)c * HW;
             for (int s = lane; s < S && !dup; s += 64) {
               const u64 *sw = st_n + (i64)s * HW;
@@ -526,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
               dup = (w == HW);
             }
             for (int c2 = lane; c2 < c && !dup; c2 += 64) {
+              if (dig_k(cdig[c2]) <= DIG_SLOTS) continue;  // (a complete digest that differs: another state)
               const u64 *sw = cw_n + (i64)c2 * HW;
               int w = 0;
               while (w < HW && load_sc0(sw + w) == load_sc0(cw + w)) w++;
@@ -584,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
           const int bi = guard_index(new_i[lane], n_kids, a.err), wi = guard_index(old_i[lane], S, a.err);
           const u64 d = cdig[bi];
           u64 *dstw = f.states + (n * (i64)S + wi) * HW;
-          if (!FULL) {
+          if (dig_k(d) <= DIG_SLOTS) {
             for (int w = 0; w < HW; w++) dstw[w] = digest_word(d, w);
           } else {
             for (int w0 = 0; w0 < HW; w0 += 8) {
@@ -603,6 +586,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
         lds_wave_fence();
       }
     }
+    FPROF(6);
     // census of the new K^n: positions now, the three reservations (lanes 0..2) fly while phase 6 computes
     int cpos[SPL], cres = 0;
     if (f.cen_items) {
@@ -638,7 +622,6 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
         if (lane + 64 * q < S) z += exp(ov[q] + B);
       z = wave_sum(z);
       const double fterm = log(z) - B;
-      double *lpj_n = f.lpj + n * (i64)S;
 #pragma unroll
       for (int q = 0; q < SPL; q++)
         if (lane + 64 * q < S) lpj_n[lane + 64 * q] = ov[q];
@@ -677,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
       }
     }
     lds_wave_fence();
+    FPROF(7);
   }
   if (dn) flush_defer();
 }

@@ -218,10 +218,10 @@ class Engine:
         return bool(fused.value)
 
     def estep_counters(self):
-        """{fused_calls, separate_calls, deferred_to_full, deferred_to_full64} of evoamd_estep (diagnostics)."""
+        """{fused_calls, separate_calls, deferred (datapoints the fused kernel left to its second launch), -} of evoamd_estep."""
         out = (ctypes.c_int64 * 4)()
         check(self.lib.evoamd_estep_counters(self._h, out))
-        return dict(zip(("fused_calls", "separate_calls", "deferred_to_full", "deferred_to_full64"), [int(v) for v in out]))
+        return dict(zip(("fused_calls", "separate_calls", "deferred", "unused"), [int(v) for v in out]))
 
     MUTATIONS = {"randflip": 0, "sparseflip": 1, "cross": 2, "cross_randflip": 3, "cross_sparseflip": 4}
 

@@ -148,9 +148,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "sk_spare" (-1 = automatic (default), 0 .. 32): workgroups per XCD that the long-K contraction does not launch while it
  * runs on the second stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free
  * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8).
- * "fused_estep" (0 / 1 / 2, default 1): evoamd_estep runs the fused per-datapoint kernel never / when the census of the last
- * statistics pass says K^n is sparse (no state above eight latents, states above four in at most a quarter of the datapoints)
- * / whenever the shape allows it.
+ * "fused_estep" (0 / 1 / 2, default 0): evoamd_estep runs the fused wave-per-datapoint kernel never / when the census of the
+ * last statistics pass says K^n is sparse (states above four latents in at most a quarter of the datapoints) / whenever the
+ * shape allows it.  Same results bit for bit; default off because the separate passes are faster on MI355X at every BASELINE
+ * shape (the chain is bound by vector-instruction issue and per-wave latency, not by the HBM bytes fusion saves: DESIGN 3).
  * "debug_poison_list" (one-shot, tests): the next census of the resident K^n gets an out-of-range entry.  Every list entry
  * and every latent index that crosses LDS is range-checked before it becomes an address, so the pass that reads the entry
  * ends in EVOAMD_E_INVALID ("... out of range") instead of a memory fault; the census is rebuilt afterwards. */
@@ -344,12 +345,12 @@ int evoamd_restore_theta_backup(evoamd_ctx *ctx);
  * lpj of the children, vary_Kn (evo/variational/utils.py:231-337); K^n, lpj rows and the row statistics of the M-step are
  * updated in place, the free-energy term and the counters go to the scalar block.  Equivalent to evoamd_lpj_resident +
  * evoamd_evolve_randflip + evoamd_vary_kn with the same arguments, bit for bit; where the shape allows it (ES3C, complete
- * data, digests, S_perm = 0, <= 64 children, H <= 1024; option "fused_estep") ONE kernel does it with a wave per datapoint.
+ * data, digests, S_perm = 0, <= 64 children, H <= 1024) and option "fused_estep" asks for it, ONE kernel does it with a wave
+ * per datapoint (the resident states above two latents by the list kernels in front of it).
  * *fused_out (may be NULL): 1 if the fused kernel ran. */
 int evoamd_estep(evoamd_ctx *ctx, int n_parents, int n_children, uint64_t seed, int fit_parents, int Mprime, int *fused_out);
 /* Diagnostics of evoamd_estep: out = { calls that ran the fused kernel, calls that ran the separate passes, datapoints the
- * last fused call's first launch left to the second (a state above four latents, an elimination that needs row exchanges,
- * exact mode), datapoints the second left to the third (a state above 16 latents) }.  Synchronises the stream. */
+ * last fused call's first launch left to the second (a child above 16 active latents), 0 }.  Synchronises the stream. */
 int evoamd_estep_counters(evoamd_ctx *ctx, int64_t out[4]);
 /* Fs only (sum_n logsumexp) of an arbitrary host lpj matrix (N,C) -- exact-likelihood path. */
 int evoamd_free_energy(evoamd_ctx *ctx, const double *lpj, int64_t N, int C, double *Fs_out);

@@ -58,7 +58,7 @@ def _lockstep(engine, cls, D, H, S, my_data, theta0, ss0, ea, n_steps, to_learn=
             assert np.abs(acc_a - acc_b).max() <= 1e-11 * scale, t
             out.append(suff["ss"].copy())
     finally:
-        engine.set_option("fused_estep", 1)
+        engine.set_option("fused_estep", 0)
     return out
 
 
@@ -109,7 +109,7 @@ def test_fused_estep_device_mstep_trajectory(engine):
             assert used == [opt == 2] * 5
             res.append((Fs, {k: np.array(v) for k, v in theta.items()}))
     finally:
-        engine.set_option("fused_estep", 1)
+        engine.set_option("fused_estep", 0)
     assert res[0][0][0] == res[1][0][0]
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-10)
     for k in ("W", "pies", "mus", "Psi", "sigma2"):
@@ -192,7 +192,7 @@ def test_fused_estep_exact_mode(engine):
 
 
 def test_fused_estep_automatic_choice(engine):
-    """Option "fused_estep" = 1 (default): the first E-step of a geometry (or after a K^n upload) runs the separate passes
+    """Option "fused_estep" = 1 (automatic): the first E-step of a geometry (or after a K^n upload) runs the separate passes
     (no census yet), the following ones the fused kernel while K^n is sparse -- states above four latents in at most a
     quarter of the datapoints; a dense K^n goes back to the separate passes."""
     from evo_amd.models import SSSC
@@ -202,6 +202,16 @@ def test_fused_estep_automatic_choice(engine):
     Y = rng.normal(size=(N, D))
     my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
     np.random.seed(4)
+    engine.set_option("fused_estep", 1)
+    try:
+        _automatic_choice_body(engine, D, H, S, N, my_data)
+    finally:
+        engine.set_option("fused_estep", 0)
+
+
+def _automatic_choice_body(engine, D, H, S, N, my_data):
+    from evo_amd.models import SSSC
+    from evo_amd.variational import init_states
     model = SSSC(D, H, S, rng="device", sync_host=False, engine=engine, seed=3, device_mstep=True)
     theta = model.check_params(model.standard_init(my_data))
     suff = init_states(N, S, H, "fit", "randflip", 6, 1, 1)
@@ -217,7 +227,7 @@ def test_fused_estep_automatic_choice(engine):
     engine.upload_states(ss)  # (a K^n from the host: its census is unknown -> separate passes, which then count it)
     _, _, _, theta = model.step(theta, suff, my_data)
     assert model.last_estep_fused is False
-    _, _, _, theta = model.step(theta, suff, my_data)  # 24 dense states in 200 datapoints: still sparse -> fused (FULL serves them)
+    _, _, _, theta = model.step(theta, suff, my_data)  # 24 dense states in 200 datapoints: still sparse -> fused
     assert model.last_estep_fused is True
     ss = engine.download_states()
     ss[:, :, :6] = True  # every state of every datapoint above four latents: the automatic choice goes back to the separate passes
