@@ -61,7 +61,7 @@ struct FusedArgs {
 #define FPROF(slot)                                                                    \
   do {                                                                                 \
     const unsigned long long _t = __builtin_readcyclecounter();                        \
-    if (lane == 0 && f.prof) atomicAdd(&f.prof[slot], _t - _tp);                       \
+    _pacc[slot] += _t - _tp;  /* per wave; one atomic per wave and phase at the end */  \
     _tp = _t;                                                                          \
   } while (0)
 #else
@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
     dn = 0;
     lds_wave_fence();
   };
+#ifdef FUSED_PROFILE
+  unsigned long long _pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (i64 it = (i64)blockIdx.x * W + wave; it < count; it += (i64)gridDim.x * W) {
     const i64 n = LISTED ? (i64)guard_index(f.in_items[it], a.N, a.err) : it;
 #ifdef FUSED_PROFILE
@@ -663,6 +666,10 @@ __global__ __launch_bounds__(256, 2) void sssc_estep_fused_kernel(FusedArgs f) {
     FPROF(7);
   }
   if (dn) flush_defer();
+#ifdef FUSED_PROFILE
+  if (lane == 0 && f.prof)
+    for (int i = 0; i < 8; i++) atomicAdd(&f.prof[i], _pacc[i]);
+#endif
 }
 
 // Free-energy terms and E-step counters of the fused kernels -> dpar[DP_FS] (assigned), dpar[DP_ECNT0 / 1] (accumulated),
