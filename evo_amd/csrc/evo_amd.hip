@@ -154,6 +154,8 @@ struct evoamd_ctx {
   // into pinned memory itself: 67 us in front of everything queued behind it).  Option "theta_copy_engine" = 0: old form.
   hipStream_t stream_copy = nullptr;
   hipEvent_t ev_theta = nullptr, ev_theta_done = nullptr;
+  hipEvent_t ev_mbox = nullptr, ev_bak = nullptr;  // mailbox kernel / Theta backup on the side stream (off the critical path)
+  int mbox_side = 1;  // option "mailbox_side_stream"
   int theta_copy_engine = 0;  // measured (c4 / c4shard, interleaved A/B): no gain -- the host then waits for the copy
                               // instead, and at N / 8 it returns too late to keep the queue filled (1.30 vs 1.25 ms)
   double rel_frac = -1.0;  // EBSC incomplete data: sum(x_infr) / N over all ranks (evoamd_set_reliable_fraction)
@@ -485,6 +487,8 @@ extern "C" int evoamd_ctx_create(int device, evoamd_ctx **out) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_theta, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_theta_done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_mbox, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_bak, hipEventDisableTiming));
   for (int i = 0; i < 16; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
 
   HIP_TRY(hipFuncSetAttribute((const void *)sssc_stats_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -564,6 +568,8 @@ extern "C" void evoamd_ctx_destroy(evoamd_ctx *c) {
   if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
   if (c->ev_theta) (void)hipEventDestroy(c->ev_theta);
   if (c->ev_theta_done) (void)hipEventDestroy(c->ev_theta_done);
+  if (c->ev_mbox) (void)hipEventDestroy(c->ev_mbox);
+  if (c->ev_bak) (void)hipEventDestroy(c->ev_bak);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < 16; i++)
@@ -693,6 +699,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   if (strcmp(name, "stats_chunks") == 0) {
     if (value < 1 || value > 16) return fail(EVOAMD_E_INVALID, "stats_chunks: 1 .. 16");
     c->stats_chunks = value;
+    return 0;
+  }
+  if (strcmp(name, "mailbox_side_stream") == 0) {
+    c->mbox_side = value != 0;
     return 0;
   }
   if (strcmp(name, "fused_estep") == 0) {
@@ -3415,8 +3425,22 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   const unsigned long long seq = ++c->mbox_seq;
   const long long total = MAILBOX_HDR + (with_theta ? (long long)(DH + HH + 2 * H) : 0);
   const int grid = (int)std::min<long long>(64, cdiv(total, 256 * 8));
-  mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, c->stream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
-                                                              c->mbox_counter, seq);
+  // The mailbox kernel writes to pinned host memory and ends in a system-scope fence: 26 us of which nothing behind it
+  // in the stream depends.  On the side stream it runs beside the refresh / the prefetched pass; what it reads (tail,
+  // scalar block, error words, Theta) is next written by the NEXT iteration's kernels, which the host enqueues only after
+  // it has seen this mailbox.
+  hipStream_t mstream = c->stream;
+  // (measured, ms per iteration lazy / eager Theta: c4 3.94 -> 3.88 / 4.43 -> 4.05, N / 8 shard 1.13 -> 1.08 / 1.37 -> 1.60,
+  // c2 0.386 -> 0.404: the event pair costs ~10 us, and a 3 MB Theta copy beside the refresh only delays the host -- so
+  // only the header-only mailbox of a long iteration goes there)
+  const double it_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H : 2.0 * (double)c->N * c->D * c->H;
+  if (c->mbox_side && !dma && !with_theta && it_flops >= 8e9) {
+    HIP_TRY(hipEventRecord(c->ev_mbox, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream_copy, c->ev_mbox, 0));
+    mstream = c->stream_copy;
+  }
+  mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, mstream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
+                                                           c->mbox_counter, seq);
   HIP_TRY(hipGetLastError());
   if (refresh) {
     int rr = refresh_after_update(c);
@@ -3439,7 +3463,7 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
     __builtin_ia32_pause();
     if ((++spins & 0xFFFu) == 0 &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
+      HIP_TRY(hipStreamSynchronize(mstream));
       if (*flag != seq) return fail(EVOAMD_E_HIP, "mailbox kernel finished without publishing its sequence number");
     }
   }
@@ -3489,8 +3513,11 @@ static int backup_theta(evoamd_ctx *c) {
     ALLOC(c->theta_bak, n);
     c->theta_bak_n = n;
   }
-  theta_backup_kernel<<<(unsigned)std::min<size_t>(256, cdiv((i64)n, 256 * 8)), 256, 0, c->stream>>>(c->theta_bak, s, 0);
+  // on the side stream, beside the statistics pass (nothing writes Theta between the E-step and the update, which waits
+  // for ev_bak): 9 us at the north-star shape that were in front of the update
+  theta_backup_kernel<<<(unsigned)std::min<size_t>(256, cdiv((i64)n, 256 * 8)), 256, 0, c->stream_copy>>>(c->theta_bak, s, 0);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_bak, c->stream_copy));
   c->theta_bak_valid = true;
   return 0;
 }
@@ -3501,6 +3528,7 @@ extern "C" int evoamd_restore_theta_backup(evoamd_ctx *c) {
   HIP_TRY(hipSetDevice(c->device));
   int r = join_fork(c);
   if (r) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream_copy));
   theta_backup_kernel<<<256, 256, 0, c->stream>>>(c->theta_bak, theta_segs(c), 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -3516,21 +3544,24 @@ extern "C" int evoamd_restore_theta_backup(evoamd_ctx *c) {
 extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_out, double *dpar_out) {
   REQUIRE(tail_out && dpar_out, "NULL output");
   REQUIRE(!(c && c->mask_infr && c->rel_frac < 0.0), "incomplete data: evoamd_set_reliable_fraction first (bsc.py:113-118)");
+  const bool theta_home = (learn_mask & 64) != 0;  // the caller fetches Theta^new on demand (evoamd_get_params_*)
+  c->theta_bak_valid = false;
+  bool bak_pending = false;
+  if ((learn_mask & 31) && theta_home) {  // before the statistics pass is enqueued: the copy runs beside it
+    int rb = backup_theta(c);
+    if (rb) return rb;
+    bak_pending = true;
+  }
   int r = stats_compute(c, /*fork_gemm=*/true);
   if (r) return r;
   c->h_theta_fresh = false;
   const bool want_rec = (learn_mask & 32) != 0;
-  const bool theta_home = (learn_mask & 64) != 0;  // the caller fetches Theta^new on demand (evoamd_get_params_*)
   learn_mask &= 31;
   if (want_rec && !c->yhat_valid) {  // under the Theta the E-step used, i.e. before the update
     r = compute_reconstruction(c);   // (incomplete data: the statistics pass formed it already)
     if (r) return r;
   }
-  c->theta_bak_valid = false;
-  if (learn_mask && theta_home) {
-    r = backup_theta(c);
-    if (r) return r;
-  }
+  if (bak_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bak, 0));
   if (learn_mask) {
     r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true);
     if (r) return r;

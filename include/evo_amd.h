@@ -148,6 +148,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * "sk_spare" (-1 = automatic (default), 0 .. 32): workgroups per XCD that the long-K contraction does not launch while it
  * runs on the second stream beside the H x H elimination chain of the Theta update, so that the chain's kernels find free
  * CU slots (automatic: 4 where the product takes at least three times as long as the chain, else 8).
+ * "mailbox_side_stream" (0/1, default 1): the kernel that hands an iteration's scalars (and Theta^new) to the host runs on a
+ * side stream beside the refresh of the tables and the prefetched pass instead of in front of them.
  * "fused_estep" (0 / 1 / 2, default 0): evoamd_estep runs the fused wave-per-datapoint kernel never / when the census of the
  * last statistics pass says K^n is sparse (states above four latents in at most a quarter of the datapoints) / whenever the
  * shape allows it.  Same results bit for bit; default off because the separate passes are faster on MI355X at every BASELINE
