@@ -3432,9 +3432,9 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   hipStream_t mstream = c->stream;
   // (measured, ms per iteration lazy / eager Theta: c4 3.94 -> 3.88 / 4.43 -> 4.05, N / 8 shard 1.13 -> 1.08 / 1.37 -> 1.60,
   // c2 0.386 -> 0.404: the event pair costs ~10 us, and a 3 MB Theta copy beside the refresh only delays the host -- so
-  // only the header-only mailbox of a long iteration goes there)
+  // only the mailbox of a long iteration goes there, with Theta on board only at the north-star size)
   const double it_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H : 2.0 * (double)c->N * c->D * c->H;
-  if (c->mbox_side && !dma && !with_theta && it_flops >= 8e9) {
+  if (c->mbox_side && !dma && it_flops >= (with_theta ? 8e10 : 8e9)) {
     HIP_TRY(hipEventRecord(c->ev_mbox, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream_copy, c->ev_mbox, 0));
     mstream = c->stream_copy;
