@@ -151,6 +151,7 @@ def pmc_traffic(config, kernels):
         try:
             with open(path) as f:
                 d = json.load(f)
+            pmc_traffic.source = os.path.relpath(path, ROOT)
             break
         except Exception:
             continue
@@ -623,7 +624,8 @@ def main():
                     "traffic": pmc_traffic(traffic_key(args), kernels),
                     "traffic_note": "HBM bytes per pass, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, read "
                                     "side corrected for gfx950 (2 x FETCH_SIZE: an upper bound for kernels whose loads are 8 bytes per lane), "
-                                    "summed over the kernels of the span; profiles/r03_* (r02_* where a config was not re-profiled)",
+                                    "summed over the kernels of the span; counters of this workload from "
+                                    + str(getattr(pmc_traffic, "source", None)),
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "algorithmic_bytes_note": "SURVEY 8d: N_rank x (D*8 + S*(ceil(H/8) + 8)), states priced bit-packed",
                     "avg_launch_ms": ms, "launches_timed": launches}

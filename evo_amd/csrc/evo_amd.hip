@@ -3287,7 +3287,8 @@ static int refresh_after_update(evoamd_ctx *c) {
   return 0;
 }
 
-static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = false, bool defer_refresh = false) {
+static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = false, bool defer_refresh = false,
+                                double *bak = nullptr) {
   const AccLayout a = acc_layout(c);
   const int H = c->H, D = c->D;
   const i64 HH = (i64)H * H;
@@ -3302,7 +3303,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     // tmpA <- xpt_szsz (for W, sssc.py:693), tmpB <- xpt_ss + eps I (for Psi, sssc.py:738)
     sssc_mstep_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, c->acc + a.xss,
                                                                     c->acc + a.xszsz, Nptr, H, learn,
-                                                                    c->pies, c->mus, c->tmpA, c->tmpC, c->tmpB);
+                                                                    c->pies, c->mus, c->tmpA, c->tmpC, c->tmpB, bak, c->W,
+                                                                    c->Psi, c->dpar, D);
     if ((learn & L_W) && (learn & L_PSI))
       r = launch_inverse(c, c->tmpA, c->tmpB, H, force_pivot);
     else if (learn & L_W)
@@ -3505,7 +3507,13 @@ static CopySegs theta_segs(evoamd_ctx *c) {
 
 // lazy Theta: the host has no copy of the parameters the E-step ran with, and the update overwrites them in place.
 // One launch (3 MB at the north-star shape, ~3 us) keeps them until the update is known to be well posed.
-static int backup_theta(evoamd_ctx *c) {
+// ES3C with D <= 8 H: the first kernel of the update (sssc_mstep_prepare_kernel, an H x H grid) writes the copy on its way,
+// no launch and no event of its own.
+static bool backup_rides_in_update(const evoamd_ctx *c) {
+  return c->model == EVOAMD_MODEL_SSSC && c->D <= 8 * c->H;
+}
+
+static int backup_theta(evoamd_ctx *c, bool reserve_only) {
   const CopySegs s = theta_segs(c);
   size_t n = 0;
   for (int k = 0; k < 5; k++) n += (size_t)s.n[k];
@@ -3513,6 +3521,7 @@ static int backup_theta(evoamd_ctx *c) {
     ALLOC(c->theta_bak, n);
     c->theta_bak_n = n;
   }
+  if (reserve_only) return 0;
   // on the side stream, beside the statistics pass (nothing writes Theta between the E-step and the update, which waits
   // for ev_bak): 9 us at the north-star shape that were in front of the update
   theta_backup_kernel<<<(unsigned)std::min<size_t>(256, cdiv((i64)n, 256 * 8)), 256, 0, c->stream_copy>>>(c->theta_bak, s, 0);
@@ -3547,10 +3556,15 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   const bool theta_home = (learn_mask & 64) != 0;  // the caller fetches Theta^new on demand (evoamd_get_params_*)
   c->theta_bak_valid = false;
   bool bak_pending = false;
+  double *bak_inline = nullptr;
   if ((learn_mask & 31) && theta_home) {  // before the statistics pass is enqueued: the copy runs beside it
-    int rb = backup_theta(c);
+    const bool rides = backup_rides_in_update(c);
+    int rb = backup_theta(c, rides);
     if (rb) return rb;
-    bak_pending = true;
+    if (rides)
+      bak_inline = c->theta_bak;
+    else
+      bak_pending = true;
   }
   int r = stats_compute(c, /*fork_gemm=*/true);
   if (r) return r;
@@ -3563,8 +3577,9 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   }
   if (bak_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bak, 0));
   if (learn_mask) {
-    r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true);
+    r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true, bak_inline);
     if (r) return r;
+    if (bak_inline) c->theta_bak_valid = true;
     c->stats_rows_valid = false;  // the rows belong to the previous Theta now
   }
   r = join_fork(c);

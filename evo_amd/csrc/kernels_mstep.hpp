@@ -1306,10 +1306,24 @@ __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
     const double *__restrict__ xs, const double *__restrict__ xsz, const double *__restrict__ xss,
     const double *__restrict__ xszsz, const double *__restrict__ Nptr, int H, int learn,
     double *__restrict__ pies, double *__restrict__ mus, double *__restrict__ xszsz_copy,
-    double *__restrict__ psi_raw, double *__restrict__ T2) {
+    double *__restrict__ psi_raw, double *__restrict__ T2, double *__restrict__ bak = nullptr,
+    const double *__restrict__ Wsrc = nullptr, const double *__restrict__ Psisrc = nullptr,
+    const double *__restrict__ dpar = nullptr, int D = 0) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
+  if (bak) {
+    // lazy Theta: the parameters the E-step ran with, saved on the way (W | Psi | mus | pies | scalar block -- the layout of
+    // theta_backup_kernel) before this launch and the ones behind it overwrite them; no launch of its own
+    const i64 DH = (i64)D * H, HH = (i64)H * H;
+    for (i64 e = t; e < DH; e += HH) bak[e] = Wsrc[e];
+    bak[DH + t] = Psisrc[t];
+    if (j == 0) {  // the thread that will overwrite mus[i] / pies[i] below saves them first
+      bak[DH + HH + i] = mus[i];
+      bak[DH + HH + H + i] = pies[i];
+    }
+    if (t < DP_COUNT) bak[DH + HH + 2 * H + t] = dpar[t];
+  }
   const bool lm = (learn & L_MUS) != 0;
   const double mi = lm ? xsz[i] * 1.0 / (xs[i] + 2.220446049250313e-16) : mus[i];  // eps_mus
   const double mj = lm ? xsz[j] * 1.0 / (xs[j] + 2.220446049250313e-16) : mus[j];
