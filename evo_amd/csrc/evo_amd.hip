@@ -195,6 +195,10 @@ struct evoamd_ctx {
   // option "lpj_singular_screen": exactly singular Psi_A above two latents the reference's way (kernels_sssc.hpp,
   // sssc_exact_mode) -- 0 never, 1 when the tables kernel has stamped this Theta (default), 2 always
   int sing_screen = 1;
+  // states above SSSC_KCAP active latents (H > SSSC_KCAP only): slots of global memory for the wavefront kernel's matrices
+  double *huge = nullptr;
+  int *huge_ctl = nullptr;
+  int huge_slots = 0, huge_kc = 0;
   int *sing_gen = nullptr;  // = err + 4: generation of the last Theta whose Psi held an exactly singular 1x1 / 2x2 block
   int theta_gen = 0;        // stamp of the current Theta (one per sssc_tables_kernel launch)
   int gemm_grouped = 1;  // option "gemm_grouped": grouped split-K instead of stream-K where whole chunks fill the grid
@@ -541,7 +545,7 @@ static void free_all(evoamd_ctx *c) {
                   c->acc_base, c->Es,     c->list1,   c->list2,    c->list3,    c->list_n,    c->err,
                   c->tmp_y,  c->tmp_lpj, c->tmp_states, c->dig, c->cand_dig, c->lpj_alt, c->cand_raw, c->dupold, c->gen_start,
                   c->pbins.ent, c->pbins.part, c->pbins.gcnt, c->gemm_ws, c->Yt, c->Yf, c->Ytf, c->Wf, c->Bf, c->Esf,
-                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak, c->rowF, c->rowcnt, c->defer, c->fpart};
+                  c->clist, c->clist_n, c->ovf_rec, c->theta_bak, c->rowF, c->rowcnt, c->defer, c->fpart, c->huge, c->huge_ctl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_acc) (void)hipHostFree(c->h_acc);
@@ -908,6 +912,21 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 8);
   c->sing_gen = c->err + 4;
+  c->huge_slots = c->huge_kc = 0;
+  if (c->huge) (void)hipFree(c->huge);
+  if (c->huge_ctl) (void)hipFree(c->huge_ctl);
+  c->huge = nullptr;
+  c->huge_ctl = nullptr;
+  if (model == EVOAMD_MODEL_SSSC && H > SSSC_KCAP) {
+    // the reference evaluates a state with any number of active latents (sssc.py:261-324); above SSSC_KCAP the k x k
+    // system does not fit a CU's LDS and the wavefront kernel works in one of these slots (at most 16, at most 256 MB)
+    const size_t slot = big_slot_doubles(H);
+    c->huge_kc = H;
+    c->huge_slots = (int)std::max<size_t>(1, std::min<size_t>(16, ((size_t)256 << 20) / (slot * sizeof(double))));
+    ALLOC(c->huge, slot * (size_t)c->huge_slots);
+    ALLOC(c->huge_ctl, (size_t)c->huge_slots);
+    HIP_TRY(hipMemsetAsync(c->huge_ctl, 0, (size_t)c->huge_slots * sizeof(int), c->stream));
+  }
   for (float **fp : {&c->Yf, &c->Ytf, &c->Wf, &c->Bf, &c->Esf}) {
     if (*fp) (void)hipFree(*fp);
     *fp = nullptr;
@@ -1694,6 +1713,10 @@ static SsscArgs sssc_args(evoamd_ctx *c, const Batch &b) {
   a.sing_gen = c->sing_gen;
   a.gen = c->theta_gen;
   a.screen = c->sing_screen;
+  a.huge = c->huge;
+  a.huge_ctl = c->huge_ctl;
+  a.huge_slots = c->huge_slots;
+  a.huge_kc = c->huge_kc;
   a.mask = b.mask;
   a.Wt = c->Wt;
   a.D = c->D;

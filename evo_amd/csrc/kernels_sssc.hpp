@@ -88,6 +88,10 @@ struct SsscArgs {
   // when Psi holds an exactly singular 1 x 1 / 2 x 2 principal block, the stamp of the current Theta, option value
   const int *sing_gen;
   int gen, screen;
+  // more than SSSC_KCAP active latents: slots of global memory for the wavefront kernel's matrices (sssc_big_kernel)
+  double *huge;
+  int *huge_ctl;
+  int huge_slots, huge_kc;
   // incomplete data (sssc.py:276 W[this_x_infr, :]): reliable-entry mask rows of this batch, W^T, D
   const uint8_t *mask;    // (N, D) or nullptr
   const double *Wt;       // (H, D)
@@ -148,6 +152,42 @@ __device__ __forceinline__ void pair_lam_singular_psi(double s, double G00, doub
     l10 = -M10 * rm;
     l11 = M00 * rm;
   }
+}
+
+// inv of a REGULAR 2 x 2 matrix the way np.linalg.inv computes it (dgesv on the identity: LU with partial pivoting --
+// lu2_exactly_singular's elimination -- then the two triangular solves per column)
+__device__ __forceinline__ void inv2_gesv(double a00, double a01, double a10, double a11, double &x00, double &x01,
+                                          double &x10, double &x11) {
+  const bool swap = fabs(a10) > fabs(a00);
+  const double p0 = swap ? a10 : a00, p1 = swap ? a11 : a01, q0 = swap ? a00 : a10, q1 = swap ? a01 : a11;
+  const double l = __dmul_rn(q0, __ddiv_rn(1.0, p0));
+  const double u11 = __dsub_rn(q1, __dmul_rn(l, p1));
+  auto solve = [&](double r0, double r1, double &x0, double &x1) {  // column (r0, r1) of P I
+    const double y1 = __dsub_rn(r1, __dmul_rn(l, r0));
+    x1 = __ddiv_rn(y1, u11);
+    x0 = __ddiv_rn(__dsub_rn(r0, __dmul_rn(p1, x1)), p0);
+  };
+  solve(swap ? 0.0 : 1.0, swap ? 1.0 : 0.0, x00, x10);
+  solve(swap ? 1.0 : 0.0, swap ? 0.0 : 1.0, x01, x11);
+}
+// Can M_A = G_A / sigma2 + inv(Psi_A) be singular at all?  Not while the symmetric part of Psi_A is positive definite
+// (G_A is a Gram matrix): the screen below then costs two compares.
+__device__ __forceinline__ bool pair_psi_positive(double P00, double P01, double P10, double P11) {
+  const double o = 0.5 * (P01 + P10);
+  return P00 > 0.0 && P11 > 0.0 && P00 * P11 > o * o;
+}
+// |A| = 2, Psi_A regular: is M_A = G_A / sigma2 + inv(Psi_A) exactly singular for LAPACK (sssc.py:295-300: inv raises,
+// the reference goes on with pinv(M_A) and slogdet(M_A) = -inf, i.e. lpj = +inf -> B_max)?  Then Lam = pinv(M_A).
+// Structural cases only (an M_A whose elimination leaves rounding noise is regular for LAPACK and for this).
+__device__ __forceinline__ bool pair_m_singular(double s, double G00, double G01, double G10, double G11, double P00,
+                                                double P01, double P10, double P11, double &l00, double &l01,
+                                                double &l10, double &l11) {
+  double q00, q01, q10, q11;
+  inv2_gesv(P00, P01, P10, P11, q00, q01, q10, q11);
+  const double M00 = s * G00 + q00, M01 = s * G01 + q01, M10 = s * G10 + q10, M11 = s * G11 + q11;
+  if (!lu2_exactly_singular(M00, M01, M10, M11)) return false;
+  pinv2_deficient(M00, M01, M10, M11, l00, l01, l10, l11);
+  return true;
 }
 
 template <int K>
@@ -401,6 +441,31 @@ __device__ __forceinline__ void sssc_eval_regs(const SsscArgs &a, i64 n, const u
     // |A| <= 2 without the tables (candidate batches whose rows do not fit the main kernel's LDS, shared sets): the same
     // exactly-singular-Psi_A semantics as sssc_tables_kernel -- lpj = +inf (-> B_max), Lam / kappa from pinv(Psi_A)
     const bool sing = k == 1 ? P[0][0] == 0.0 : lu2_exactly_singular(P[0][0], P[0][K - 1], P[K - 1][0], P[K - 1][K - 1]);
+    if (!sing) {
+      // Psi_A regular, M_A = G_A / sigma2 + inv(Psi_A) exactly singular (sssc.py:295-300): lpj = +inf, Lam = pinv(M_A)
+      double m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;
+      bool ms = false;
+      if (k == 1)
+        ms = !(P[0][0] > 0.0) && a.s2inv * G[0][0] + 1.0 / P[0][0] == 0.0;  // pinv(0) = 0
+      else if (!pair_psi_positive(P[0][0], P[0][K - 1], P[K - 1][0], P[K - 1][K - 1]))
+        ms = pair_m_singular(a.s2inv, G[0][0], G[0][K - 1], G[K - 1][0], G[K - 1][K - 1], P[0][0], P[0][K - 1], P[K - 1][0],
+                             P[K - 1][K - 1], m00, m01, m10, m11);
+      if (ms) {
+        if (MODE == 0) {
+          val = __builtin_inf();
+        } else {
+          kap[0] = a.s2inv * (m00 * v[0] + m01 * v[K - 1]) + mu[0];
+          kap[K - 1] = k == 1 ? mu[K - 1] : a.s2inv * (m10 * v[0] + m11 * v[K - 1]) + mu[K - 1];
+          P[0][0] = m00;
+          if (k == 2) {
+            P[0][K - 1] = m01;
+            P[K - 1][0] = m10;
+            P[K - 1][K - 1] = m11;
+          }
+        }
+        return;
+      }
+    }
     if (sing) {
       if (MODE == 0) {
         val = __builtin_inf();
@@ -1221,100 +1286,202 @@ __global__ __launch_bounds__(256) void finish_sym_kernel(double *__restrict__ xs
 }
 
 // ---- exact mode of the wavefront kernel (sssc_exact_mode): one wave, k x k matrices in LDS (row-major, stride k) ----
-// WG64: the wave is a whole 64-thread workgroup (sssc_big_kernel) and orders its LDS traffic with lds_barrier(); false: one
+// BAR 1: the wave is a whole 64-thread workgroup (sssc_big_kernel) and orders its LDS traffic with lds_barrier(); 0: one
 // wave of a larger workgroup (the fused per-datapoint E-step, kernels_fused.hpp) -- a wave's LDS operations execute in
-// order, so a compiler-visible wait for the LDS queue is the whole barrier.
-template <bool WG64>
+// order, so a compiler-visible wait for the LDS queue is the whole barrier; 2: a 64-thread workgroup whose matrices live
+// in GLOBAL memory (more than SSSC_KCAP active latents: they do not fit a CU's LDS) -- __syncthreads() waits for the
+// stores as well, and a lane then owns the rows lane, lane + 64, ...
+template <int BAR>
 __device__ __forceinline__ void big_bar() {
-  if (WG64)
+  if (BAR == 2)
+    __syncthreads();
+  else if (BAR == 1)
     lds_barrier();
   else
     lds_wave_fence();
+}
+// f(r) for every row r < k this lane owns: its own lane index (k <= 64: BAR 0 / 1), or lane, lane + 64, ... (BAR 2)
+template <int BAR, class F>
+__device__ __forceinline__ void rows_of(const int lane, const int k, F f) {
+  if (BAR == 2) {
+    for (int r = lane; r < k; r += 64) f(r);
+  } else {
+    if (lane < k) f(lane);
+  }
+}
+// idamax over the rows p..k-1 of column p of M: the FIRST entry of largest magnitude.  m: that magnitude (-1 if none).
+template <int BAR>
+__device__ __forceinline__ int wave_idamax(const double *M, const int k, const int p, const int lane, double &m) {
+  double v = -1.0;
+  int vr = 0x7fffffff;
+  rows_of<BAR>(lane, k, [&](int r) {
+    if (r >= p) {
+      const double x = fabs(M[r * k + p]);
+      if (x > v || vr == 0x7fffffff) {  // (the first row of a lane also when its entry is NaN / the comparison fails)
+        v = x;
+        vr = r;
+      }
+    }
+  });
+  m = wave_max(v);
+  if (BAR == 2) return (int)wave_min_u32(v == m ? (unsigned)vr : 0x7fffffffu);
+  return __ffsll((long long)__ballot(v == m)) - 1;
 }
 // LU with partial pivoting of M: true when an exactly zero pivot turns up, which is what makes np.linalg.inv raise
 // LinAlgError (dgetrf's info > 0; sssc.py:280).  dgetf2's arithmetic: the first entry of largest magnitude is the pivot
 // (idamax), the column below it is scaled by the RECIPROCAL of the pivot.  Exact for the structural cases -- zero rows,
 // equal rows, exactly dependent small-integer blocks; a matrix whose elimination leaves rounding noise is regular for
 // LAPACK and for this.  M is destroyed; fv: k doubles of scratch.
-template <bool WG64 = true>
+template <int BAR = 1>
 __device__ __forceinline__ bool wave_lu_exactly_singular(double *M, double *fv, int k, int lane) {
   for (int p = 0; p < k; p++) {
-    const double v = (lane >= p && lane < k) ? fabs(M[lane * k + p]) : -1.0;
-    const double m = wave_max(v);
+    double m;
+    const int piv = wave_idamax<BAR>(M, k, p, lane, m);
     if (m == 0.0) return true;     // uniform
     if (!(m > 0.0)) return false;  // NaN: inv does not raise, the values stay NaN
-    const int piv = __ffsll((long long)__ballot(v == m)) - 1;
-    if (piv != p && lane < k) {
-      const double t1 = M[p * k + lane];
-      M[p * k + lane] = M[piv * k + lane];
-      M[piv * k + lane] = t1;
-    }
-    big_bar<WG64>();
+    if (piv != p)
+      rows_of<BAR>(lane, k, [&](int c) {  // (columns of the two rows)
+        const double t1 = M[p * k + c];
+        M[p * k + c] = M[piv * k + c];
+        M[piv * k + c] = t1;
+      });
+    big_bar<BAR>();
     const double r = __ddiv_rn(1.0, M[p * k + p]);
-    if (lane > p && lane < k) fv[lane] = M[lane * k + p] * r;
-    big_bar<WG64>();
+    rows_of<BAR>(lane, k, [&](int i) {
+      if (i > p) fv[i] = M[i * k + p] * r;
+    });
+    big_bar<BAR>();
     const int mm = k - p - 1;
     for (int q = lane; q < mm * mm; q += 64) {
       const int i = p + 1 + q / mm, j = p + 1 + q % mm;
       M[i * k + j] = fma(-fv[i], M[p * k + j], M[i * k + j]);
     }
-    big_bar<WG64>();
+    big_bar<BAR>();
   }
   return false;
 }
 
+// X = inv(A) for a REGULAR A the way np.linalg.inv computes it (dgesv on the identity: dgetrf's LU with partial pivoting,
+// then the unit-lower and the upper triangular solves of dgetrs).  A is destroyed; fv: k doubles of scratch; X may not
+// alias A.  (Exact mode only, sssc.py:279 -- what M_s = W_s^T W_s / sigma2 + inv(Psi_s) is made of.)
+template <int BAR>
+__device__ __forceinline__ void wave_inverse(double *A, double *X, double *fv, int k, int lane) {
+  for (int q = lane; q < k * k; q += 64) X[q] = (q / k == q % k) ? 1.0 : 0.0;
+  big_bar<BAR>();
+  for (int p = 0; p < k; p++) {
+    double m;
+    const int piv = wave_idamax<BAR>(A, k, p, lane, m);
+    if (piv != p && piv >= 0 && piv < k)
+      rows_of<BAR>(lane, k, [&](int c) {
+        const double t1 = A[p * k + c];
+        A[p * k + c] = A[piv * k + c];
+        A[piv * k + c] = t1;
+        const double t2 = X[p * k + c];
+        X[p * k + c] = X[piv * k + c];
+        X[piv * k + c] = t2;
+      });
+    big_bar<BAR>();
+    const double r = __ddiv_rn(1.0, A[p * k + p]);
+    rows_of<BAR>(lane, k, [&](int i) {
+      if (i > p) fv[i] = A[i * k + p] * r;
+    });
+    big_bar<BAR>();
+    const int mm = k - p - 1;
+    for (int q = lane; q < mm * mm; q += 64) {
+      const int i = p + 1 + q / mm, j = p + 1 + q % mm;
+      A[i * k + j] = fma(-fv[i], A[p * k + j], A[i * k + j]);
+    }
+    for (int q = lane; q < mm * k; q += 64) {
+      const int i = p + 1 + q / k, j = q % k;
+      X[i * k + j] = fma(-fv[i], X[p * k + j], X[i * k + j]);
+    }
+    big_bar<BAR>();
+  }
+  for (int p = k - 1; p >= 0; p--) {
+    const double d = A[p * k + p];
+    rows_of<BAR>(lane, k, [&](int c) { X[p * k + c] = __ddiv_rn(X[p * k + c], d); });
+    big_bar<BAR>();
+    for (int q = lane; q < p * k; q += 64) {
+      const int i = q / k, j = q % k;
+      X[i * k + j] = fma(-A[i * k + p], X[p * k + j], X[i * k + j]);
+    }
+    big_bar<BAR>();
+  }
+}
+
 // out = pinv(A) the way np.linalg.pinv defines it (SVD, singular values up to rcond = 1e-15 of the largest dropped;
 // sssc.py:281/300), by one-sided Jacobi: the columns of A are rotated until they are mutually orthogonal, V collects the
-// rotations, so A_in = A_out V^T with A_out's columns = sigma_j u_j and pinv = sum_j v_j a_j^T / sigma_j^2.  Lane i owns
-// row i of A and of V (no barrier inside the sweeps).  A and V are destroyed; out may not alias them.
-template <bool WG64 = true>
+// rotations, so A_in = A_out V^T with A_out's columns = sigma_j u_j and pinv = sum_j v_j a_j^T / sigma_j^2.  A lane owns
+// whole rows of A and of V (no barrier inside the sweeps).  A and V are destroyed; out may not alias them.
+template <int BAR = 1>
 __device__ __forceinline__ void wave_pinv(double *A, double *V, double *out, int k, int lane) {
-  const bool mine = lane < k;
-  if (mine)
-    for (int j = 0; j < k; j++) V[lane * k + j] = (j == lane) ? 1.0 : 0.0;
+  rows_of<BAR>(lane, k, [&](int r) {
+    for (int j = 0; j < k; j++) V[r * k + j] = (j == r) ? 1.0 : 0.0;
+  });
+  if (BAR == 2) big_bar<BAR>();
   for (int sweep = 0; sweep < 40; sweep++) {
     bool rotated = false;
     for (int p = 0; p + 1 < k; p++)
       for (int q = p + 1; q < k; q++) {
-        const double ap = mine ? A[lane * k + p] : 0.0, aq = mine ? A[lane * k + q] : 0.0;
-        const double alpha = wave_sum(ap * ap), beta = wave_sum(aq * aq), gamma = wave_sum(ap * aq);
+        double al = 0.0, be = 0.0, ga = 0.0;
+        rows_of<BAR>(lane, k, [&](int r) {
+          const double ap = A[r * k + p], aq = A[r * k + q];
+          al += ap * ap;
+          be += aq * aq;
+          ga += ap * aq;
+        });
+        const double alpha = wave_sum(al), beta = wave_sum(be), gamma = wave_sum(ga);
         if (!(fabs(gamma) > 1e-16 * sqrt(alpha * beta))) continue;  // uniform
         rotated = true;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-        if (mine) {
-          A[lane * k + p] = cs * ap - sn * aq;
-          A[lane * k + q] = sn * ap + cs * aq;
-          const double vp = V[lane * k + p], vq = V[lane * k + q];
-          V[lane * k + p] = cs * vp - sn * vq;
-          V[lane * k + q] = sn * vp + cs * vq;
-        }
+        rows_of<BAR>(lane, k, [&](int r) {
+          const double ap = A[r * k + p], aq = A[r * k + q];
+          A[r * k + p] = cs * ap - sn * aq;
+          A[r * k + q] = sn * ap + cs * aq;
+          const double vp = V[r * k + p], vq = V[r * k + q];
+          V[r * k + p] = cs * vp - sn * vq;
+          V[r * k + q] = sn * vp + cs * vq;
+        });
+        if (BAR == 2) big_bar<BAR>();  // (global memory: a lane's own stores before its next loads of the same rows)
       }
     if (!rotated) break;
   }
   double smax2 = 0.0;
   for (int j = 0; j < k; j++) {
-    const double a = mine ? A[lane * k + j] : 0.0;
-    smax2 = fmax(smax2, wave_sum(a * a));
+    double a2 = 0.0;
+    rows_of<BAR>(lane, k, [&](int r) {
+      const double x = A[r * k + j];
+      a2 += x * x;
+    });
+    smax2 = fmax(smax2, wave_sum(a2));
   }
   for (int j = 0; j < k; j++) {  // a_j / sigma_j^2, or nothing for a dropped singular value
-    const double a = mine ? A[lane * k + j] : 0.0;
-    const double s2 = wave_sum(a * a);
+    double a2 = 0.0;
+    rows_of<BAR>(lane, k, [&](int r) {
+      const double x = A[r * k + j];
+      a2 += x * x;
+    });
+    const double s2 = wave_sum(a2);
     const bool keep = sqrt(s2) > 1e-15 * sqrt(smax2);
-    if (mine) A[lane * k + j] = keep ? a / s2 : 0.0;
+    rows_of<BAR>(lane, k, [&](int r) {
+      const double x = A[r * k + j];
+      A[r * k + j] = keep ? x / s2 : 0.0;
+    });
   }
-  big_bar<WG64>();
-  if (mine)
+  big_bar<BAR>();
+  rows_of<BAR>(lane, k, [&](int r) {
     for (int l = 0; l < k; l++) {
       double acc = 0.0;
-      for (int j = 0; j < k; j++) acc = fma(V[lane * k + j], A[l * k + j], acc);
-      out[lane * k + l] = acc;
+      for (int j = 0; j < k; j++) acc = fma(V[r * k + j], A[l * k + j], acc);
+      out[r * k + l] = acc;
     }
-  big_bar<WG64>();
+  });
+  big_bar<BAR>();
 }
 
-// The wavefront-per-state evaluation: LDS of one state, sized for kc latents (4 kc^2 + 5 kc doubles + kc ints, big_lds()).
+// The wavefront-per-state evaluation: storage of one state, sized for kc latents (4 kc^2 + 5 kc doubles + kc ints, big_lds()).
 struct BigLds {
   double *Tm, *Pm, *Gm, *bv, *muv, *vv, *wv, *fv, *Vm;
   int *idx;
@@ -1327,10 +1494,12 @@ struct BigLds {
     vv = muv + kc;
     wv = vv + kc;
     fv = wv + kc;
-    Vm = fv + kc;  // exact mode only: the rotations of wave_pinv
+    Vm = fv + kc;  // exact mode only: the rotations of wave_pinv / inv(Psi_A)
     idx = (int *)(Vm + kc * kc);
   }
 };
+// doubles one slot of the global-memory form takes for kc latents (the int index array rounded up)
+__host__ __device__ inline size_t big_slot_doubles(int kc) { return (size_t)4 * kc * kc + 5 * (size_t)kc + ((size_t)kc + 1) / 2; }
 
 // Active latents of the state at `sp` into L.idx (the first kc of them, ascending); returns their number.
 // lane w loads word w (one round trip for the whole state), the loop broadcasts them.
@@ -1357,24 +1526,24 @@ __device__ __forceinline__ int big_scan(const u64 *sp, int HW, int kc, int *idx,
 }
 
 // Everything between the latents (L.idx[0..k), k <= kc) and the tails of the two modes: gathers, v, rr, the exact-mode
-// screen of Psi_A, T = I + Psi_A G_A / sigma2, LU with partial pivoting, back substitution.  Returns
+// screens of Psi_A and M_A, T = I + Psi_A G_A / sigma2, LU with partial pivoting, back substitution.  Returns
 //   0  solved: MODE 0 -> `val` = lpj (not clamped); MODE 1 -> L.wv = Lam v (kappa = wv / sigma2 + mu), L.Pm = Lam, L.muv
-//   2  MODE 0, exact mode, Psi_A exactly singular: lpj = +inf (the caller clamps it to B_max and counts it)
+//   2  MODE 0, exact mode, Psi_A or M_A exactly singular: lpj = +inf (the caller clamps it to B_max and counts it)
 // Bn: the datapoint's row of B = Y W (global or LDS); n: the datapoint (mask rows of incomplete data).
-template <int MODE, bool WG64>
+template <int MODE, int BAR>
 __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const int k, const BigLds &L, const int lane,
                                          const bool exact, const double *Bn, const double yyn, double &val) {
 #pragma clang fp contract(off)  // (explicit fma only: the same bits in every kernel this is inlined into)
   double *Tm = L.Tm, *Pm = L.Pm, *Gm = L.Gm, *bv = L.bv, *muv = L.muv, *vv = L.vv, *wv = L.wv, *fv = L.fv, *Vm = L.Vm;
   const int *idx = L.idx;
-  big_bar<WG64>();
+  big_bar<BAR>();
   double pb = 0.0;
-  if (lane < k) {
-    const int h = idx[lane];
-    bv[lane] = Bn[h];
-    muv[lane] = a.mus[h];
-    pb = a.pil_bar[h];
-  }
+  rows_of<BAR>(lane, k, [&](int r) {
+    const int h = idx[r];
+    bv[r] = Bn[h];
+    muv[r] = a.mus[h];
+    pb += a.pil_bar[h];
+  });
   pb = wave_sum(pb);
   for (int q = lane; q < k * k; q += 64) {
     const int i = q / k, j = q - i * k;
@@ -1385,7 +1554,7 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
   if (a.mask) {
     // incomplete data: G_A of THIS datapoint, W_obs^T W_obs restricted to A -- k (k + 1) / 2 masked dot
     // products over D, lanes over the observables (rows of W^T are contiguous)
-    big_bar<WG64>();
+    big_bar<BAR>();
     const uint8_t *mrow = a.mask + n * a.D;
     for (int i = 0; i < k; i++) {
       const double *wi = a.Wt + (i64)idx[i] * a.D;
@@ -1402,22 +1571,22 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
       }
     }
   }
-  big_bar<WG64>();
+  big_bar<BAR>();
   double rr_part = 0.0;
-  if (lane < k) {
-    double s = bv[lane];
-    for (int j = 0; j < k; j++) s = fma(-Gm[lane * k + j], muv[j], s);
-    vv[lane] = s;
-    rr_part = muv[lane] * (bv[lane] + s);
-  }
+  rows_of<BAR>(lane, k, [&](int r) {
+    double s = bv[r];
+    for (int j = 0; j < k; j++) s = fma(-Gm[r * k + j], muv[j], s);
+    vv[r] = s;
+    rr_part += muv[r] * (bv[r] + s);
+  });
   const double rr = yyn - wave_sum(rr_part);
-  big_bar<WG64>();
-  bool psing = false;
+  big_bar<BAR>();
+  bool psing = false, msing = false;
   if (exact && k > 0) {  // is Psi_A exactly singular (np.linalg.inv raises, sssc.py:280)?
     for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
-    big_bar<WG64>();
-    psing = wave_lu_exactly_singular<WG64>(Tm, fv, k, lane);
-    big_bar<WG64>();
+    big_bar<BAR>();
+    psing = wave_lu_exactly_singular<BAR>(Tm, fv, k, lane);
+    big_bar<BAR>();
   }
   bool solved = false;
   if (psing) {
@@ -1426,79 +1595,115 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
     // pinv(Psi_A) -- pinv(M_A) when that is exactly singular too (sssc.py:296-300) -- and kappa = mu + Lam v / sigma2
     if (MODE == 0) return 2;  // uniform
     for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
-    big_bar<WG64>();
-    wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
+    big_bar<BAR>();
+    wave_pinv<BAR>(Tm, Vm, Pm, k, lane);  // Pm = pinv(Psi_A)
     for (int q = lane; q < k * k; q += 64) {
       const double mq = fma(a.s2inv, Gm[q], Pm[q]);
       Gm[q] = mq;  // M_A (G_A is not read again)
       Tm[q] = mq;
     }
-    big_bar<WG64>();
-    const bool msing = wave_lu_exactly_singular<WG64>(Tm, fv, k, lane);
-    big_bar<WG64>();
+    big_bar<BAR>();
+    msing = wave_lu_exactly_singular<BAR>(Tm, fv, k, lane);
+    big_bar<BAR>();
     for (int q = lane; q < k * k; q += 64) Tm[q] = Gm[q];
-    big_bar<WG64>();
+    big_bar<BAR>();
     if (msing) {
-      wave_pinv<WG64>(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
-      if (lane < k) {
+      wave_pinv<BAR>(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
+      rows_of<BAR>(lane, k, [&](int r) {
         double s = 0.0;
-        for (int j = 0; j < k; j++) s = fma(Pm[lane * k + j], vv[j], s);
-        wv[lane] = s;
-      }
+        for (int j = 0; j < k; j++) s = fma(Pm[r * k + j], vv[j], s);
+        wv[r] = s;
+      });
       solved = true;
     } else {  // the elimination below with M_A in the place of T and the identity in the place of Psi_A: Pm = inv(M_A)
       for (int q = lane; q < k * k; q += 64) Pm[q] = (q / k == q % k) ? 1.0 : 0.0;
-      if (lane < k) wv[lane] = vv[lane];
+      rows_of<BAR>(lane, k, [&](int r) { wv[r] = vv[r]; });
     }
   } else {
-    if (lane < k) {
-      double s = 0.0;
-      for (int j = 0; j < k; j++) s = fma(Pm[lane * k + j], vv[j], s);
-      wv[lane] = s;
+    if (exact && k > 0) {
+      // Psi_A regular: is M_A = G_A / sigma2 + inv(Psi_A) exactly singular (sssc.py:295-300; a Psi that is not positive
+      // definite)?  Then slogdet(M_A) = -inf, lpj = +inf -> B_max, and the statistics read Lam = pinv(M_A).
+      for (int q = lane; q < k * k; q += 64) Tm[q] = Pm[q];
+      big_bar<BAR>();
+      wave_inverse<BAR>(Tm, Vm, fv, k, lane);  // Vm = inv(Psi_A)
+      for (int q = lane; q < k * k; q += 64) Tm[q] = fma(a.s2inv, Gm[q], Vm[q]);
+      big_bar<BAR>();
+      msing = wave_lu_exactly_singular<BAR>(Tm, fv, k, lane);
+      big_bar<BAR>();
+      if (msing) {
+        if (MODE == 0) return 2;  // uniform
+        for (int q = lane; q < k * k; q += 64) Tm[q] = fma(a.s2inv, Gm[q], Vm[q]);
+        big_bar<BAR>();
+        wave_pinv<BAR>(Tm, Vm, Pm, k, lane);  // Lam = pinv(M_A)
+        rows_of<BAR>(lane, k, [&](int r) {
+          double s = 0.0;
+          for (int j = 0; j < k; j++) s = fma(Pm[r * k + j], vv[j], s);
+          wv[r] = s;
+        });
+        solved = true;
+      }
     }
-    for (int q = lane; q < k * k; q += 64) {
-      const int i = q / k, j = q - i * k;
-      double tt = 0.0;
-      for (int l = 0; l < k; l++) tt = fma(Pm[i * k + l], Gm[l * k + j], tt);
-      Tm[q] = fma(a.s2inv, tt, (i == j) ? 1.0 : 0.0);
+    if (!solved) {
+      rows_of<BAR>(lane, k, [&](int r) {
+        double s = 0.0;
+        for (int j = 0; j < k; j++) s = fma(Pm[r * k + j], vv[j], s);
+        wv[r] = s;
+      });
+      for (int q = lane; q < k * k; q += 64) {
+        const int i = q / k, j = q - i * k;
+        double tt = 0.0;
+        for (int l = 0; l < k; l++) tt = fma(Pm[i * k + l], Gm[l * k + j], tt);
+        Tm[q] = fma(a.s2inv, tt, (i == j) ? 1.0 : 0.0);
+      }
     }
   }
-  big_bar<WG64>();
+  big_bar<BAR>();
   // ---- LU with partial pivoting; RHS = w (and Pm in statistics mode)
   bool singular = false;
   for (int p = 0; p < (solved ? 0 : k); p++) {
-    // pivot: |column p| with 63 - row in the low 6 mantissa bits, one DPP max-reduce
+    // pivot: |column p| with 63 - lane in the low 6 mantissa bits, one DPP max-reduce (BAR 2: a lane's best row first)
     double key = -1.0;
-    if (lane >= p && lane < k) {
-      const unsigned long long bits =
-          ((unsigned long long)__double_as_longlong(fabs(Tm[lane * k + p])) & ~0x3FULL) | (unsigned long long)(63 - lane);
-      key = __longlong_as_double((long long)bits);
-    }
-    key = wave_max(key);
-    const int piv = 63 - (int)((unsigned long long)__double_as_longlong(key) & 0x3FULL);
-    if (piv != p) {
-      if (lane < k) {
-        const double t1 = Tm[p * k + lane];
-        Tm[p * k + lane] = Tm[piv * k + lane];
-        Tm[piv * k + lane] = t1;
-        if (MODE == 1) {
-          const double t2 = Pm[p * k + lane];
-          Pm[p * k + lane] = Pm[piv * k + lane];
-          Pm[piv * k + lane] = t2;
+    int krow = p;
+    rows_of<BAR>(lane, k, [&](int r) {
+      if (r >= p) {
+        const unsigned long long bits =
+            ((unsigned long long)__double_as_longlong(fabs(Tm[r * k + p])) & ~0x3FULL) | (unsigned long long)(63 - lane);
+        const double kr = __longlong_as_double((long long)bits);
+        if (kr > key) {
+          key = kr;
+          krow = r;
         }
       }
+    });
+    key = wave_max(key);
+    int piv = 63 - (int)((unsigned long long)__double_as_longlong(key) & 0x3FULL);
+    if (BAR == 2) piv = __shfl(krow, piv, 64);
+    if (piv < p || piv >= k) piv = p;  // (a column of NaN: no exchange)
+    if (piv != p) {
+      rows_of<BAR>(lane, k, [&](int c) {
+        const double t1 = Tm[p * k + c];
+        Tm[p * k + c] = Tm[piv * k + c];
+        Tm[piv * k + c] = t1;
+        if (MODE == 1) {
+          const double t2 = Pm[p * k + c];
+          Pm[p * k + c] = Pm[piv * k + c];
+          Pm[piv * k + c] = t2;
+        }
+      });
       if (lane == 0) {
         const double t3 = wv[p];
         wv[p] = wv[piv];
         wv[piv] = t3;
       }
     }
-    big_bar<WG64>();
+    big_bar<BAR>();
     const double d = Tm[p * k + p];
     if (d == 0.0) singular = true;
     const double r = fast_rcp(d);
-    if (lane > p && lane < k) fv[lane] = Tm[lane * k + p] * r;
-    big_bar<WG64>();
+    rows_of<BAR>(lane, k, [&](int i) {
+      if (i > p) fv[i] = Tm[i * k + p] * r;
+    });
+    big_bar<BAR>();
     const int m = k - p - 1;
     for (int q = lane; q < m * m; q += 64) {
       const int i = p + 1 + q / m, j = p + 1 + q % m;
@@ -1510,39 +1715,78 @@ __device__ __forceinline__ int big_solve(const SsscArgs &a, const i64 n, const i
         Pm[i * k + j] = fma(-fv[i], Pm[p * k + j], Pm[i * k + j]);
       }
     }
-    if (lane > p && lane < k) wv[lane] = fma(-fv[lane], wv[p], wv[lane]);
-    big_bar<WG64>();
+    rows_of<BAR>(lane, k, [&](int i) {
+      if (i > p) wv[i] = fma(-fv[i], wv[p], wv[i]);
+    });
+    big_bar<BAR>();
   }
-  double ld = (lane < k) ? log(fabs(Tm[lane * k + lane])) : 0.0;
+  double ld = 0.0;
+  rows_of<BAR>(lane, k, [&](int r) { ld += log(fabs(Tm[r * k + r])); });
   const double logdet = wave_sum(ld);
   // ---- back substitution, column oriented
   for (int p = (solved ? 0 : k) - 1; p >= 0; p--) {
     const double r = fast_rcp(Tm[p * k + p]);
     if (lane == 0) wv[p] *= r;
-    if (MODE == 1 && lane < k) Pm[p * k + lane] *= r;
-    big_bar<WG64>();
-    if (lane < p) wv[lane] = fma(-Tm[lane * k + p], wv[p], wv[lane]);
+    if (MODE == 1) rows_of<BAR>(lane, k, [&](int c) { Pm[p * k + c] *= r; });
+    big_bar<BAR>();
+    rows_of<BAR>(lane, k, [&](int i) {
+      if (i < p) wv[i] = fma(-Tm[i * k + p], wv[p], wv[i]);
+    });
     if (MODE == 1) {
       for (int q = lane; q < p * k; q += 64) {
         const int i = q / k, j = q % k;
         Pm[i * k + j] = fma(-Tm[i * k + p], Pm[p * k + j], Pm[i * k + j]);
       }
     }
-    big_bar<WG64>();
+    big_bar<BAR>();
   }
   if (singular && lane == 0) atomicOr(a.err, 2);
   if (MODE == 0) {
-    const double quad = wave_sum((lane < k) ? vv[lane] * wv[lane] : 0.0);
+    double qp = 0.0;
+    rows_of<BAR>(lane, k, [&](int r) { qp += vv[r] * wv[r]; });
+    const double quad = wave_sum(qp);
     val = -0.5 * (logdet + (rr * a.s2inv - quad * a.s2inv * a.s2inv)) + pb;
   }
   return 0;
 }
 
+// MODE 1 tail of the wavefront kernel: the moments of one solved state (L.wv, L.Pm, L.muv) into the accumulators
+template <int BAR>
+__device__ __forceinline__ void big_emit(const SsscArgs &a, const i64 n, const int k, const BigLds &L, const int lane,
+                                         const double qn) {
+  double *Pm = L.Pm, *fv = L.fv;
+  const int *idx = L.idx;
+  rows_of<BAR>(lane, k, [&](int r) {
+    const double kap = L.wv[r] * a.s2inv + L.muv[r];
+    fv[r] = kap;
+    unsafeAtomicAdd(&a.Es[n * a.ldE + idx[r]], qn);
+    unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[r]], qn * kap);
+    if (a.cs) {  // (few states reach this kernel: straight to a slice)
+      double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * a.H;
+      unsafeAtomicAdd(&sl[idx[r]], qn);
+      unsafeAtomicAdd(&sl[a.H + idx[r]], qn * kap);
+      unsafeAtomicAdd(&sl[2 * a.H + idx[r]], qn * (Pm[r * k + r] + kap * kap));
+    } else {
+      unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[r]], qn * (Pm[r * k + r] + kap * kap));
+    }
+  });
+  big_bar<BAR>();
+  for (int q = lane; q < k * k; q += 64) {
+    const int i = q / k, j = q - i * k;
+    const i64 o = (i64)idx[i] * a.H + idx[j];
+    if (j > i) unsafeAtomicAdd(&a.xss_o[o], qn);
+    if (j != i) unsafeAtomicAdd(&a.xszsz_o[o], qn * (Pm[q] + fv[i] * fv[j]));
+  }
+}
+
 // One wavefront (64-thread workgroup) per listed pair, the k x k system in LDS, lanes over matrix
-// elements.  `kc` is the largest k this launch holds (LDS = 3 kc^2 + 5 kc doubles: 1.9 KiB at
-// kc = 8, 98 KiB at kc = 64); pairs above kc go to `lo` (or raise EVOAMD_E_KLIMIT when there is no
-// further level).  G_A and Psi_A are gathered into LDS once (k^2 parallel 16-byte gathers), so the
-// T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
+// elements.  `kc` is the largest k this launch holds in LDS (3 kc^2 + 5 kc doubles: 1.9 KiB at
+// kc = 8, 98 KiB at kc = 64); pairs above kc go to `lo`.  At the last level (no `lo`) a state with more than kc latents
+// -- the reference's loop has no limit (sssc.py:261-324) -- is solved by the same code with its matrices in GLOBAL
+// memory: a.huge holds a.huge_slots slots for a.huge_kc latents each, a workgroup takes one for the duration of the
+// state (a.huge_ctl: 0 free / 1 taken).  Slow (every barrier waits for memory) and never met in practice; without the
+// slots, or above huge_kc, EVOAMD_E_KLIMIT as before.  G_A and Psi_A are gathered once (k^2 parallel 16-byte gathers), so
+// the T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
 // TAG as in sssc_small_kernel: profilers then list the levels of the pass over K^n (0), of the candidate batch (1)
 // and everything else (2) under different names.
 // li2 (optional): a second list served behind the first (census mode: the resident states above eight latents, then
@@ -1570,7 +1814,8 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
     const u64 *sp = a.states + ((a.shared ? 0 : n * (i64)a.C) + c) * a.HW;
     lds_barrier();
     const int k = big_scan(sp, a.HW, kc, L.idx, lane);
-    if (k > kc) {  // uniform
+    const bool huge = k > kc && !lo.items && a.huge != nullptr && k <= a.huge_kc;  // uniform
+    if (k > kc && !huge) {  // uniform
       if (lane == 0) {
         if (lo.items) {
           const int shard = (int)(t & (LIST_SHARDS - 1));
@@ -1594,7 +1839,42 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
       qn = q / (a.rowsum[n] + EVO_F64_TINY);
     }
     double val = 0.0;
-    const int rc = big_solve<MODE, true>(a, n, k, L, lane, exact, a.Bm + n * a.H, a.yy[n], val);
+    int rc;
+    if (huge) {
+      int slot = -1;
+      if (lane == 0) {  // take a slot (holders always finish: no circular wait; the bound is for a corrupted control word)
+        int s0 = (int)(blockIdx.x % (unsigned)a.huge_slots);
+        for (int tries = 0; tries < (1 << 22); tries++) {
+          if (atomicCAS(&a.huge_ctl[s0], 0, 1) == 0) {
+            slot = s0;
+            break;
+          }
+          s0 = s0 + 1 < a.huge_slots ? s0 + 1 : 0;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      slot = __shfl(slot, 0, 64);
+      if (slot < 0) {  // uniform
+        if (lane == 0) {
+          atomicOr(a.err, 1);
+          if (MODE == 0) a.lpj_out[n * a.ldo + a.col0 + c] = EVO_F64_MIN;
+        }
+        continue;
+      }
+      __threadfence();  // (acquire: nothing of the previous holder's in this CU's cache)
+      BigLds Gl;
+      Gl.carve(a.huge + (size_t)slot * big_slot_doubles(a.huge_kc), k);
+      big_scan(sp, a.HW, k, Gl.idx, lane);
+      __syncthreads();
+      rc = big_solve<MODE, 2>(a, n, k, Gl, lane, exact, a.Bm + n * a.H, a.yy[n], val);
+      if (MODE == 1) big_emit<2>(a, n, k, Gl, lane, qn);
+      __syncthreads();
+      __threadfence();
+      if (lane == 0) atomicExch(&a.huge_ctl[slot], 0);
+    } else {
+      rc = big_solve<MODE, 1>(a, n, k, L, lane, exact, a.Bm + n * a.H, a.yy[n], val);
+      if (MODE == 1) big_emit<1>(a, n, k, L, lane, qn);
+    }
     if (MODE == 0) {
       if (lane == 0) {
         unsigned fl = 0;
@@ -1603,30 +1883,6 @@ __global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, Lis
           atomicOr(&a.flags[n], fl);
           atomicOr(&a.err[1], 1);
         }
-      }
-    } else {
-      double *Pm = L.Pm, *fv = L.fv;
-      const int *idx = L.idx;
-      if (lane < k) {
-        const double kap = L.wv[lane] * a.s2inv + L.muv[lane];
-        fv[lane] = kap;
-        unsafeAtomicAdd(&a.Es[n * a.ldE + idx[lane]], qn);
-        unsafeAtomicAdd(&a.Ez[n * a.ldE + idx[lane]], qn * kap);
-        if (a.cs) {  // (few states reach this kernel: straight to a slice)
-          double *sl = a.cs + (size_t)(blockIdx.x % CS_SLICES) * 3 * a.H;
-          unsafeAtomicAdd(&sl[idx[lane]], qn);
-          unsafeAtomicAdd(&sl[a.H + idx[lane]], qn * kap);
-          unsafeAtomicAdd(&sl[2 * a.H + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
-        } else {
-          unsafeAtomicAdd(&a.Ed[n * a.ldE + idx[lane]], qn * (Pm[lane * k + lane] + kap * kap));
-        }
-      }
-      lds_barrier();
-      for (int q = lane; q < k * k; q += 64) {
-        const int i = q / k, j = q - i * k;
-        const i64 o = (i64)idx[i] * a.H + idx[j];
-        if (j > i) unsafeAtomicAdd(&a.xss_o[o], qn);
-        if (j != i) unsafeAtomicAdd(&a.xszsz_o[o], qn * (Pm[q] + fv[i] * fv[j]));
       }
     }
   }
@@ -1715,6 +1971,12 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
       d.y = __builtin_inf();
       d.w = (s * g != 0.0) ? 1.0 / (s * g) : 0.0;
       atomicMax(sing_gen, gen);
+    } else if (!(p > 0.0) && s * g + 1.0 / p == 0.0) {
+      // Psi_hh regular (negative), M = G_hh / sigma2 + 1 / Psi_hh exactly zero: inv(M_s) raises, the reference takes
+      // pinv(M_s) = 0 and slogdet(M_s) = -inf, so lpj = +inf -> B_max and Lam = 0 (sssc.py:295-300)
+      d.y = __builtin_inf();
+      d.w = 0.0;
+      atomicMax(sing_gen, gen);
     }
     D1[h0] = d;
     return;
@@ -1741,6 +2003,12 @@ __global__ __launch_bounds__(256) void sssc_tables_kernel(const double *__restri
     // lpj = +inf -> B_max, and its statistics use Lam = inv(G_A / sigma2 + pinv(Psi_A)) (pinv of that if it is singular
     // too) -- NOT the continuous limit T^-1 Psi_A of the lines above (sssc.py:278-301).  L = +inf with a FINITE Lam.
     pair_lam_singular_psi(s, G00, G01, G10, G11, P00, P01, P10, P11, e.l00, e.l01, e.l10, e.l11);
+    e.L = __builtin_inf();
+    atomicMax(sing_gen, gen);
+  } else if (!pair_psi_positive(P00, P01, P10, P11) &&
+             pair_m_singular(s, G00, G01, G10, G11, P00, P01, P10, P11, e.l00, e.l01, e.l10, e.l11)) {
+    // Psi_A regular, M_A = G_A / sigma2 + inv(Psi_A) exactly singular: L = +inf with the FINITE Lam = pinv(M_A), and the
+    // levels above two latents screen every state of this Theta (a larger A holding this pair may be singular as well)
     e.L = __builtin_inf();
     atomicMax(sing_gen, gen);
   }

@@ -357,6 +357,103 @@ def make_lpj_singular_k3():
                         ljc=np.float64(theta["ljc"]), **theta_arrays("", theta, SSSC_KEYS))
 
 
+def _operator_fixture(path, model, theta, sets, H, Y, extra=None):
+    """log_pseudo_joint on hand-made states, with lambda_s / kappa_s of every state as the statistics loop reads them."""
+    states = np.zeros((len(sets), H), dtype=bool)
+    for c, on in enumerate(sets):
+        states[c, list(on)] = True
+    KM = max(len(on) for on in sets)
+    N = Y.shape[0]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    suff = {}
+    model.E_step_precompute(theta, suff, my_data)
+    lpj = np.zeros((N, len(sets)))
+    lam = np.zeros((len(sets), KM, KM))
+    kappa = np.zeros((N, len(sets), KM))
+    cnt = np.zeros((N, 3), dtype=np.int64)
+    for n in range(N):
+        my_data["this_y"] = Y[n]
+        my_data["this_x_infr"] = my_data["x_infr"][n]
+        suff["this_states"] = states
+        for key in ("reset_lpj_isnan", "reset_lpj_smaller_eps_lpj", "reset_lpj_isinf"):
+            suff[key] = 0
+        with np.errstate(all="ignore"):
+            lpj[n] = model.log_pseudo_joint(theta, suff, my_data)
+        cnt[n] = [suff["reset_lpj_isnan"], suff["reset_lpj_smaller_eps_lpj"], suff["reset_lpj_isinf"]]
+        for c, on in enumerate(sets):            # what the statistics loop reads from `storage` (sssc.py:566-575)
+            if not on:
+                continue
+            ent = suff["storage"][str((model.s_ids * states[c]).sum())]
+            k = len(on)
+            lam[c, :k, :k] = ent["lambda_s"]
+            kappa[n, c, :k] = np.dot(ent["lambda_s_W_s_sigma2_inv"], Y[n] - ent["W_s_mus_s"]) + theta["mus"][states[c]]
+    np.savez_compressed(path, H=np.int64(H), states=pack(states), Y=Y, lpj=lpj, lam=lam, kappa=kappa, reset_counts=cnt,
+                        psi_s_pinv=np.int64(suff["Psi_s_pinv"]), ljc=np.float64(theta["ljc"]),
+                        **theta_arrays("", theta, SSSC_KEYS), **(extra or {}))
+    return lpj, suff
+
+
+def make_lpj_indefinite():
+    """Round 4: the remaining branch of sssc.py:295-300 -- a REGULAR Psi_s whose M_s = W_s^T W_s / sigma2 + inv(Psi_s) is
+    exactly singular (inv raises, the reference goes on with pinv(M_s) and slogdet(M_s) = -inf, lpj = +inf -> B_max) --
+    inside an INDEFINITE Psi (mixed-sign spectrum, T = I + Psi_A G_A / sigma2 regular but not positive).  sigma2 = 1/2 and
+    planted latents whose arithmetic is exact in binary:
+      3        W = e_0, Psi_33 = -1/2, uncorrelated:  M = 2 - 2 = 0 for every set that holds it (a decoupled zero row);
+      (6, 11)  W = (e_1, e_1 + e_2), Psi block [[-1, 1/2], [1/2, -1/2]] -> inv = -[[2, 2], [2, 4]] = -G / sigma2: M = 0;
+      (8, 15)  W = (e_3, e_3 + e_4), Psi block [[-1/4, 1/2], [1/2, -1/2]] -> inv = [[4, 4], [4, 2]]: M = [[6, 6], [6, 6]],
+               rank one, first pivot non-zero.
+    Each of 6, 11, 8, 15 alone has a regular M.  The other latents share the rows 5.. of W and a dense indefinite Psi."""
+    rng = np.random.RandomState(404)
+    D, H = 18, 20
+    model = SSSC(D, H, 40, use_storage=True)
+    theta = learned_like_sssc_theta(D, H, rng)
+    theta["sigma2"] = np.float64(0.5)
+    W, Psi = theta["W"], theta["Psi"]
+    Q = np.linalg.qr(rng.normal(size=(H, H)))[0]
+    lamb = np.concatenate([rng.uniform(0.4, 1.6, H - 7), -rng.uniform(0.3, 1.2, 7)])
+    Psi[:] = (Q * lamb) @ Q.T + rng.normal(size=(H, H)) * 0.02   # indefinite, slightly non-symmetric (SURVEY Q2)
+    planted = (3, 6, 11, 8, 15)
+    W[:5, :] = 0.0
+    for h in planted:
+        W[:, h] = 0.0
+        Psi[h, :] = 0.0
+        Psi[:, h] = 0.0
+    W[0, 3] = 1.0
+    Psi[3, 3] = -0.5
+    W[1, 6] = 1.0
+    W[1, 11] = W[2, 11] = 1.0
+    Psi[6, 6], Psi[6, 11], Psi[11, 6], Psi[11, 11] = -1.0, 0.5, 0.5, -0.5
+    W[3, 8] = 1.0
+    W[3, 15] = W[4, 15] = 1.0
+    Psi[8, 8], Psi[8, 15], Psi[15, 8], Psi[15, 15] = -0.25, 0.5, 0.5, -0.5
+    sets = [(), (3,), (6,), (11,), (8,), (15,), (6, 11), (8, 15), (3, 6), (0, 1), (2, 4), (5, 19), (0,), (7,),
+            (0, 3), (3, 8, 15), (6, 11, 0), (8, 15, 1, 2), (0, 1, 2), (1, 2, 4, 5), (6, 8, 0), (11, 15, 7, 9),
+            (0, 1, 2, 4, 5), (3, 0, 1, 2, 4, 5), (6, 11, 0, 1, 2, 4, 5, 7), (0, 1, 2, 4, 5, 7, 9, 10),
+            (8, 15, 0, 1, 2, 4, 5, 7, 9), (0, 1, 2, 4, 5, 7, 9, 10, 12, 13), (3, 6, 11, 8, 15),
+            (0, 1, 2, 4, 5, 7, 9, 10, 12, 13, 14, 16), (3, 0, 1, 2, 4, 5, 7, 9, 10, 12, 13, 14, 16, 17),
+            (6, 8, 11, 0, 1, 2, 4, 5, 7, 9, 10, 12), tuple(range(H)), (6, 15), (8, 11)]
+    Y = rng.normal(size=(3, D))
+    lpj, suff = _operator_fixture(os.path.join(HERE, "lpj_sssc_indefinite.npz"), model, theta, sets, H, Y)
+    print("indefinite Psi fixture: %d of %d states at B_max, Psi_s_pinv = %d, eig(Psi_sym) in [%.2f, %.2f]"
+          % ((lpj[0] == 0.0).sum(), len(sets), suff["Psi_s_pinv"], lamb.min(), lamb.max()))
+
+
+def make_lpj_dense():
+    """Round 4: states with MORE than 64 active latents (H = 150, k up to 150) beside sparse ones -- the reference's loop
+    has no limit on |s| (sssc.py:261-324)."""
+    rng = np.random.RandomState(405)
+    D, H = 40, 150
+    model = SSSC(D, H, 24, use_storage=True)
+    theta = learned_like_sssc_theta(D, H, rng)
+    sets = []
+    for k in (0, 1, 2, 3, 7, 12, 40, 63, 64, 65, 66, 80, 97, 128, 129, 149, 150):
+        sets.append(tuple(sorted(rng.choice(H, size=k, replace=False).tolist())))
+    sets += [tuple(range(0, 130)), tuple(range(20, 150)), tuple(range(0, 150, 2))]
+    Y = rng.normal(size=(2, D))
+    lpj, suff = _operator_fixture(os.path.join(HERE, "lpj_sssc_dense.npz"), model, theta, sets, H, Y)
+    print("dense-state fixture: k = %s, lpj in [%.1f, %.1f]" % ([len(x) for x in sets], lpj.min(), lpj.max()))
+
+
 def make_vary_kn():
     out = {}
     cases = []
@@ -692,6 +789,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lpj_k3":  # exactly singular Psi_A with three or more active latents (round 3)
         make_lpj_singular_k3()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lpj_r4":  # round 4: singular M_s inside an indefinite Psi; more than 64 active latents
+        make_lpj_indefinite()
+        make_lpj_dense()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prec32":  # SSSC(precision=np.float32) (sssc.py:49), added in round 3
         make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
         sys.exit(0)
@@ -720,6 +821,8 @@ if __name__ == "__main__":
     make_step_fixture("es3c_perm", "es3c", 20, 24, 12, 30, seed=72, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=PERM_ZERO)
     make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
     make_lpj_singular_k3()
+    make_lpj_indefinite()
+    make_lpj_dense()
     make_learn_bars()
     for nm in sorted(SHAPES):
         a, D, H, S, N, seed, ea = SHAPES[nm][:7]

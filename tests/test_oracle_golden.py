@@ -214,11 +214,14 @@ def test_lpj_sssc():
     np.testing.assert_allclose(theta["ljc"], float(g["ljc"]), rtol=1e-15)
 
 
-@pytest.mark.parametrize("fixture,n_sing", [("lpj_sssc_singular.npz", 7), ("lpj_sssc_singular_k3.npz", 11)])
+@pytest.mark.parametrize("fixture,n_sing", [("lpj_sssc_singular.npz", 7), ("lpj_sssc_singular_k3.npz", 11),
+                                            ("lpj_sssc_indefinite.npz", 15), ("lpj_sssc_dense.npz", 0)])
 def test_lpj_sssc_singular_psi(fixture, n_sing):
     """Exactly singular Psi_s (sssc.py:278-301): pinv branches, lpj = +inf -> B_max with the isinf counter, and the
     lambda_s / kappa_s the reference's statistics loop reads from its storage -- all from the reference itself
-    (states with at most two active latents; `_k3`: three to ten, and one M_s that is exactly singular as well)."""
+    (states with at most two active latents; `_k3`: three to ten, and one M_s that is exactly singular as well).
+    `_indefinite` (round 4): a REGULAR Psi_s whose M_s is exactly singular (sssc.py:295-300), inside an indefinite Psi;
+    `_dense`: up to 150 active latents, nothing singular."""
     g = load_golden(fixture)
     H = int(g["H"])
     theta = {k: g[k] for k in SSSC_KEYS}
