@@ -42,13 +42,14 @@ enum {
   EVOAMD_E_HIP = -2,     /* a HIP runtime call failed (message has the HIP error)    */
   EVOAMD_E_NODEVICE = -3,/* no gfx950 device visible                                 */
   EVOAMD_E_RCCL = -4,    /* RCCL missing or a collective failed                      */
-  EVOAMD_E_KLIMIT = -5,  /* ES3C: a state has more active latents than EVOAMD_KCAP   */
+  EVOAMD_E_KLIMIT = -5,  /* ES3C, fused E-step kernel only: more than EVOAMD_KCAP active latents (the separate passes solve such a state in global memory) */
   EVOAMD_E_SINGULAR = -6 /* ES3C: exactly singular k x k system (reference: pinv path)*/
 };
 
 enum { EVOAMD_MODEL_BSC = 0, EVOAMD_MODEL_SSSC = 1 };
 
-/* ES3C: largest |s| the k x k solver handles (LDS-resident, one wavefront per state). */
+/* ES3C: largest |s| whose k x k system the wavefront kernel holds in LDS (one wavefront per state); a state with more
+ * active latents is solved by the same kernel in global memory (slots allocated by evoamd_configure when H > 64). */
 #define EVOAMD_KCAP 64
 
 typedef struct evoamd_ctx evoamd_ctx;

@@ -584,6 +584,50 @@ def test_es3c_step_with_duplicated_latent_against_oracle(engine, device_mstep):
     assert np.isfinite(F2) and all(np.isfinite(np.asarray(th_a[k])).all() for k in ("W", "pies", "mus", "Psi", "sigma2"))
 
 
+@pytest.mark.parametrize("device_mstep", [False, True])
+def test_es3c_step_with_more_than_64_active_latents_against_oracle(engine, device_mstep):
+    """Round 4: the reference's per-state loop has no limit on |s| (sssc.py:261-324); here states above SSSC_KCAP = 64
+    active latents used to end in EVOAMD_E_KLIMIT.  A K^n initialised with ~72 of H = 96 latents active per state: the
+    resident pass, the candidates (children of such parents), the selection, the statistics and the Theta update of two
+    full EM steps against oracle.evo_oracle.sssc_step (dense states pinned by tests/golden/lpj_sssc_dense.npz)."""
+    from oracle import evo_oracle as orc
+    from evo_amd.models import SSSC
+    from evo_amd.variational import init_states
+    D, H, S, N = 40, 96, 10, 384  # N = 4 H: the Theta update is well posed
+    rng = np.random.RandomState(21)
+    gen = {"W": rng.normal(size=(D, H)), "pies": np.full(H, 0.75), "mus": rng.normal(size=H) * 0.3,
+           "Psi": np.eye(H) * 0.5, "sigma2": np.float64(0.5)}
+    np.random.seed(8)
+    Y = orc.sssc_generate(gen, N)[0]
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    np.random.seed(9)
+    theta0 = orc.sssc_standard_init(Y, H)
+    np.random.seed(10)
+    suff_a = init_states(N, S, H, "fit", "randflip", 4, 2, 1, p_init_Kn=0.75)
+    np.random.seed(10)
+    suff_o = orc.init_states(N, S, H, "fit", "randflip", 4, 2, 1, p_init_Kn=0.75)
+    assert np.array_equal(suff_a["ss"], suff_o["ss"])
+    assert (suff_o["ss"].sum(axis=2) > 64).mean() > 0.8
+    model = SSSC(D, H, S, engine=engine, device_mstep=device_mstep)
+    th_a = {k: np.array(v) for k, v in theta0.items()}
+    th_o = {k: np.array(v) for k, v in theta0.items()}
+    th_a["sigma2"], th_o["sigma2"] = np.float64(th_a["sigma2"]), np.float64(th_o["sigma2"])
+    for t in range(2):
+        np.random.seed(200 + t)
+        Fa, nua, nsa, th_a = model.step(th_a, suff_a, my_data)
+        np.random.seed(200 + t)
+        Fo, nuo, nso, th_o, _ = orc.sssc_step(th_o, suff_o, Y)
+        np.testing.assert_allclose(Fa, Fo, rtol=1e-9, err_msg="F step %d" % t)
+        assert (nua, nsa) == (nuo, nso)
+        assert np.array_equal(suff_a["ss"], suff_o["ss"]), "K^n step %d" % t
+        np.testing.assert_allclose(suff_a["lpj"], suff_o["lpj"], rtol=1e-9, atol=1e-9)
+        for k in ("W", "pies", "mus", "Psi", "sigma2"):
+            ref = np.asarray(th_o[k])
+            np.testing.assert_allclose(th_a[k], ref, rtol=1e-6, atol=1e-7 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg="%s step %d" % (k, t))
+    assert (suff_a["ss"].sum(axis=2) > 64).mean() > 0.5
+
+
 @pytest.mark.parametrize("algo", ["ebsc", "es3c"])
 @pytest.mark.parametrize("device_mstep", [False, True])
 def test_reconstruction_against_reference(engine, algo, device_mstep):
