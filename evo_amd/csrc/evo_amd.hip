@@ -320,6 +320,9 @@ struct evoamd_ctx {
   size_t ovf_rec_n = 0;
   unsigned long long kn_gen = 1, census_gen = 0;
   int census_opt = 1;   // option "census_lists": 0 = round-2 level chains everywhere
+  // option "merge_small_levels": with few states above four active latents (census of the last statistics pass) the
+  // pivoting wavefront kernel serves the 5..8 list too, instead of a quad launch of its own (3 passes x ~10-20 us)
+  int merge_small = 1;
   int stats_flat = 0;   // option "stats_flat": census mode, states with <= 2 latents on the thread-per-state kernel instead of
                         // the wave-per-datapoint one.  Measured (c4, steady state): 504-539 vs 584 us for the kernel, but the
                         // quad levels then share 256 bin regions instead of 2048 (107 vs 69 us) and N / 8 shards lose: off
@@ -681,6 +684,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "merge_small_levels") == 0) {
+    c->merge_small = value != 0;
     return 0;
   }
   if (strcmp(name, "stats_flat") == 0) {
@@ -1772,6 +1779,17 @@ static bool few_dense_states(const evoamd_ctx *c, int tag) {
   return expect <= 1024.0;
 }
 
+// Few enough states above FOUR active latents that the 5..8 level is not worth a launch of its own (a dependent launch
+// costs 10-20 us however little it does -- the c2 shape: 19 such states, three passes per iteration): the pivoting
+// wavefront kernel, which runs behind the quad levels anyway, then serves that list as well, at full LDS capacity.
+// K^n is close to stationary from one iteration to the next, so the candidates and the final K^n are expected to hold
+// about as many such states as the census of the last statistics pass found (x 4 for slack); a wrong guess is only slower.
+static bool few_above4(const evoamd_ctx *c, int tag) {
+  if (!c->merge_small || !c->need_known || tag == 2) return false;
+  const double expect = c->grid_scale * c->res_cnt[1] * (1.0 + 4.0 * (double)c->Cmax / (double)std::max(1, c->S));
+  return expect <= 256.0;
+}
+
 static int zero_lists(evoamd_ctx *c) {
   if (!c->lists_clean) {
     if (c->pending_skip)  // no clearing kernel ran since the last chain: check its skipped levels here
@@ -1886,11 +1904,23 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
         sssc_quad_kernel<1, 0, TAG><<<quad_grid(c, 0, TAG, total, 2048), 256, 0, c->stream>>>(a, cA, none_o, o3, PairBins{}, nullptr);
       }
       DBG_SYNC(c, "sssc lpj quad level 3..4");
-      if (need[1]) {
+      const bool few = few_above4(c, TAG);
+      const ListIn empty = {c->clist, c->clist_n + 3 * LIST_SHARDS, 0};
+      if (need[1] && !few) {
         SpanGuard gl(c, KID_LPJ_K58);
         sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, cB, none_o, o3, PairBins{}, nullptr);
       }
       DBG_SYNC(c, "sssc lpj quad level 5..8");
+      if (few) {
+        // ONE wavefront launch at full capacity: the 5..8 list, the states above eight, what the 3..4 level passed on
+        SpanGuard gl(c, KID_LPJ_K9P);
+        sssc_big_kernel<0, TAG><<<std::max(64u, level_grid(c, 1, TAG, total * 256, 1024, 1)), 64, big_lds(SSSC_KCAP), c->stream>>>(
+            a, need[1] ? cB : empty, none_o, SSSC_KCAP, need[2] ? cC : empty, i3);
+        c->pending_skip |= 2;  // nobody appends to list 2
+        HIP_TRY(hipGetLastError());
+        DBG_SYNC(c, "sssc lpj census levels (merged)");
+        return 0;
+      }
       // the pivoting wavefront kernel: resident states above eight latents, then what the quads passed on -- sized for
       // 16 latents (6.8 KB of LDS per state: ~20 workgroups per CU; at the full 64 it is 98 KB, ONE per CU, and a dense
       // K^n(0) with 40 % of its states above eight latents took 0.5 s in it), the few states beyond go on to list 2
@@ -1956,6 +1986,15 @@ static int launch_sssc_lpj(evoamd_ctx *c, const SsscArgs &a, int kid_main, const
     if (need[0])
       sssc_quad_kernel<1, 0, TAG><<<quad_grid(c, 0, TAG, total, 2048), 256, 0, c->stream>>>(a, i1, o2, o3, PairBins{}, nullptr);
     DBG_SYNC(c, "sssc lpj chain 3..4");
+    if (few_above4(c, TAG)) {
+      // (few states above four latents: the wavefront launch serves list 2 as well -- one launch less)
+      sssc_big_kernel<0, TAG><<<std::max(64u, level_grid(c, 1, TAG, total * 256, 1024, 1)), 64, big_lds(SSSC_KCAP), c->stream>>>(
+          a, i2, none_o, SSSC_KCAP, i3);
+      c->pending_skip &= ~(2 | 4);  // lists 2 and 3 have been served
+      HIP_TRY(hipGetLastError());
+      DBG_SYNC(c, "sssc lpj chain wavefront level (merged)");
+      return 0;
+    }
     if (need[1]) sssc_quad_kernel<2, 0, TAG><<<quad_grid(c, 1, TAG, total, 2048), 256, 0, c->stream>>>(a, i2, o3, o3, PairBins{}, nullptr);
     DBG_SYNC(c, "sssc lpj chain 5..8");
     sssc_big_kernel<0, TAG><<<level_grid(c, 2, TAG, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
@@ -2901,6 +2940,8 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         if (flatG > 4 * FLAT_T / H) flatG = 4 * FLAT_T / H;  // the round's B rows: at most two 16-byte pieces per thread
         if (flatG >= 1) flat_lds = ((size_t)H * (4 * flatG + 7) + 4 * flatG) * sizeof(double);
       }
+      // few states above four latents: no quad launch for them, the wavefront kernel behind the main kernel adds them
+      const bool few4 = census && flatG < 1 && few_above4(c, c->cand_from_device ? 1 : 2);
       if (flatG >= 1 && pb.ent) {
         // one resident workgroup per CU produces: the bins' entry space re-cut into n_cu regions per bin
         const i64 per_bin = (i64)pb.nwg * pb.cap;
@@ -2922,7 +2963,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
             SpanGuard gl(c, KID_STATS_K34);
             sssc_quad_kernel<1, 1, 2><<<quad_grid(c, 0, tg, total, gcap), 256, dl, c->stream>>>(sc, cA, none_out, o3, pb, c->ovf_rec);
           }
-          if (need[1]) {
+          if (need[1] && !few4) {
             SpanGuard gl(c, KID_STATS_K58);
             sssc_quad_kernel<2, 1, 2><<<quad_grid(c, 1, tg, total, gcap), 256, dl, c->stream>>>(sc, cB, none_out, o3, pb, c->ovf_rec);
           }
@@ -2962,7 +3003,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
 #define STATS_WAVE(HWT)                                                                                  \
   do {                                                                                                   \
     if (census)                                                                                          \
-      sssc_stats_wave_kernel<HWT, 4, true><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage, c->ovf_rec); \
+      sssc_stats_wave_kernel<HWT, 4, true><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage, c->ovf_rec, few4 ? 4 : 8); \
     else                                                                                                 \
       sssc_stats_wave_kernel<HWT, 4><<<sgrid, 256, lds, c->stream>>>(sc, o1, pb, stage);                  \
   } while (0)
@@ -2994,13 +3035,20 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
           SpanGuard g(c, KID_STATS_OVF);
           const int tg = c->cand_from_device ? 1 : 2;
           SpanGuard gl(c, KID_STATS_K9P);
+          const ListIn empty = {c->clist, c->clist_n + 3 * LIST_SHARDS, 0};
+          if (few4) {
+            sssc_big_kernel<1><<<std::max(64u, level_grid(c, 1, tg, total * 256, 1024, 1)), 64, big_lds(SSSC_KCAP), c->stream>>>(
+                sc, need[1] ? cB : empty, none_out, SSSC_KCAP, need[2] ? cC : empty, i3);
+            c->pending_skip |= 2;
+          } else {
           sssc_big_kernel<1><<<std::max(256u, level_grid(c, 2, tg, total * 256, 8192, 1)), 64, big_lds(16), c->stream>>>(
-              sc, need[2] ? cC : ListIn{c->clist, c->clist_n + 3 * LIST_SHARDS, 0}, o2, 16, i3);
+              sc, need[2] ? cC : empty, o2, 16, i3);
           if (need[2])
             sssc_big_kernel<1><<<level_grid(c, 2, tg, total * 256, 1024, 1), 64, big_lds(SSSC_KCAP), c->stream>>>(
                 sc, i2, none_out, SSSC_KCAP);
           else
             c->pending_skip |= 2;
+          }
           HIP_TRY(hipGetLastError());
           DBG_SYNC(c, "sssc stats wavefront level (census)");
         }

@@ -937,9 +937,12 @@ __global__ __launch_bounds__(BS) void sssc_main_lpj_kernel(SsscArgs a, ListOut l
 // CEN (census mode, kernels_sssc_quad.hpp): no overflow list is built; the quad kernels ran BEFORE this kernel and left
 // one record per state with 3..8 active latents (rec[n S + c]) and their entries in the pair bins (gcnt): a lane that
 // owns such a state adds the record to its wave's LDS rows, so no kernel adds to the [Es | Ez] rows with global atomics.
+// rec_kmax = 4: the few states with 5..8 latents have no record -- the wavefront kernel adds them afterwards (atomics),
+// like the states above eight.
 template <int HWT, int W, bool CEN = false>
 __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel(SsscArgs a, ListOut lo, PairBins pb, int stage,
-                                                                                const OvfRec *__restrict__ rec = nullptr) {
+                                                                                const OvfRec *__restrict__ rec = nullptr,
+                                                                                const int rec_kmax = 8) {
   a.s2inv = a.dpar[DP_S2INV];
   extern __shared__ double wrows[];
   __shared__ int bcnt[PB_MAX_BINS];
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
       if (CEN) {
 #pragma unroll
         for (int u = RG - 1; u >= 0; u--)
-          if (over[u] && k[u] <= 8) {
+          if (over[u] && k[u] <= rec_kmax) {
             omore = ofirst >= 0;
             ofirst = u;
           }
@@ -1206,7 +1209,7 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void sssc_stats_wave_kernel
         if (__ballot(omore) != 0ull) {  // uniform, rare: a lane with a second listed state in this group
 #pragma unroll
           for (int u = 1; u < RG; u++)
-            if (over[u] && k[u] <= 8 && u != ofirst) {
+            if (over[u] && k[u] <= rec_kmax && u != ofirst) {
               const OvfRec r2 = rec[(size_t)(n * a.C) + c0 + 64 * u + lane];
               add_rec(r2, k[u]);
             }
@@ -1789,25 +1792,30 @@ __device__ __forceinline__ void big_emit(const SsscArgs &a, const i64 n, const i
 // the T = I + Psi_A G_A / sigma2 product and v = b - G_A mu run out of LDS.
 // TAG as in sssc_small_kernel: profilers then list the levels of the pass over K^n (0), of the candidate batch (1)
 // and everything else (2) under different names.
-// li2 (optional): a second list served behind the first (census mode: the resident states above eight latents, then
-// the states the quad kernels could not eliminate without row exchanges).
+// li2, li3 (optional): further lists served behind the first (census mode: the resident states above eight latents, then
+// the states the quad kernels could not eliminate without row exchanges; with few states above four latents the 5..8
+// list as well, instead of a launch of its own).
 template <int MODE, int TAG = 2>
-__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc, ListIn li2 = ListIn{nullptr, nullptr, 0}) {
+__global__ __launch_bounds__(64) void sssc_big_kernel(SsscArgs a, ListIn li, ListOut lo, int kc, ListIn li2 = ListIn{nullptr, nullptr, 0},
+                                                      ListIn li3 = ListIn{nullptr, nullptr, 0}) {
   a.s2inv = a.dpar[DP_S2INV];
   // every barrier below orders LDS traffic only (the k x k system lives in LDS): lds_barrier() does not
   // wait for the previous state's global atomics / stores the way __syncthreads() would
   __shared__ int prefix[LIST_SHARDS + 1];
   __shared__ int prefix2[LIST_SHARDS + 1];
+  __shared__ int prefix3[LIST_SHARDS + 1];
   extern __shared__ double lds[];
   BigLds L;
   L.carve(lds, kc);
   const int lane = threadIdx.x;
   const bool exact = sssc_exact_mode(a);
   const i64 total1 = li.items ? (i64)list_prefix(li, prefix) : a.N * (i64)a.C;
-  const i64 total = total1 + (li2.items ? (i64)list_prefix(li2, prefix2) : 0);
+  const i64 total2 = total1 + (li2.items ? (i64)list_prefix(li2, prefix2) : 0);
+  const i64 total = total2 + (li3.items ? (i64)list_prefix(li3, prefix3) : 0);
   for (i64 t = blockIdx.x; t < total; t += gridDim.x) {
-    const i64 e = t >= total1 ? (i64)guard_index(list_fetch(li2, prefix2, t - total1), a.N * (i64)a.C, a.err)
-                              : (li.items ? (i64)guard_index(list_fetch(li, prefix, t), a.N * (i64)a.C, a.err) : t);
+    const i64 e = t >= total2   ? (i64)guard_index(list_fetch(li3, prefix3, t - total2), a.N * (i64)a.C, a.err)
+                  : t >= total1 ? (i64)guard_index(list_fetch(li2, prefix2, t - total1), a.N * (i64)a.C, a.err)
+                                : (li.items ? (i64)guard_index(list_fetch(li, prefix, t), a.N * (i64)a.C, a.err) : t);
     const i64 n = e / a.C;
     const int c = (int)(e - n * a.C);
     if (a.counts && c >= a.counts[n]) continue;  // uniform

@@ -136,6 +136,11 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "merge_small_levels" (0/1, default 1): ES3C with census lists / quad kernels -- while the census of the last statistics
+ * pass found few states above four active latents (expected <= 256 in the pass at hand), the pivoting wavefront kernel,
+ * which runs behind the 3..4 level anyway, serves the 5..8 list as well instead of a launch of its own (a dependent launch
+ * costs 10-20 us however little it does: c2 0.385 -> 0.34 ms per iteration).  Same values to ~1e-13; 0: always the
+ * four-lanes-per-state kernel for 5..8 latents (what the fused E-step kernel does: bit-for-bit comparisons use 0).
  * "stats_flat" (0/1, default 0: measured a few per cent at N = 100k, a loss at N / 8): with census lists, the ES3C statistics of the states with at most two active latents run
  * on the thread-per-state kernel (1024-thread workgroups owning floor(1024 / S) datapoints per round, 16 waves per CU);
  * 0: the wave-per-datapoint kernel.
