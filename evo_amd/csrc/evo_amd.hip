@@ -161,6 +161,12 @@ struct evoamd_ctx {
   double rel_frac = -1.0;  // EBSC incomplete data: sum(x_infr) / N over all ranks (evoamd_set_reliable_fraction)
   bool ar_gemm_pending = false;  // with a communicator: the contraction's block of acc is all-reduced at the join
   int overlap_gemm = 1;  // option "overlap_gemm": 0 never, 1 where it was measured to pay, 2 always
+  // option "early_fork": the forked contraction needs the [Es | Ez] rows only, so its stream may branch off BEFORE the
+  // pair-bin reduce and the finish kernel (which complete the H x H sums for the Theta chain) instead of behind them
+  // (-1 = automatic: products below 2e10 flops -- c2 0.377 -> 0.368 ms per iteration together with the fork itself, which
+  // alone costs 11 us there; N / 8 of c4 1.122 -> 1.114; N / 4 and larger lose 2-5 %: the persistent product then takes the
+  // slots the reduce needs)
+  int early_fork = -1;
   int stats_chunks = 1;  // option "stats_chunks": the statistics pass runs in this many blocks of datapoints, the MFMA
                          // contraction of block i on the second stream beside the scatter kernels of block i + 1.
                          // Measured at the north-star shape (N = 100k, H = 512): 1 block 5.47 ms per iteration, 2 blocks
@@ -684,6 +690,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "early_fork") == 0) {
+    c->early_fork = value;
     return 0;
   }
   if (strcmp(name, "merge_small_levels") == 0) {
@@ -2688,6 +2698,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // (EBSC: from ~5e10 flops on and without a communicator -- c5 on one GPU 6.47 -> 6.24 ms per iteration with eight
   // slots per XCD left to its 32 block steps of 256 workgroups; its accumulator is all-reduced in one piece)
   bool pays = (c->model == EVOAMD_MODEL_SSSC && gemm_flops >= 8e9) || (c->model == EVOAMD_MODEL_BSC && !c->comm && gemm_flops >= 5e10);
+  // branching off early (option "early_fork") makes the fork pay for small ES3C products too: the product then runs
+  // beside the pair-bin reduce, the finish kernel and the register-resident inverse instead of in front of them
+  const bool early = c->early_fork == 1 || (c->early_fork < 0 && gemm_flops < 2e10);
+  if (c->model == EVOAMD_MODEL_SSSC && !c->comm && early && gemm_flops >= 5e8 && !c->mask_infr) pays = true;
   if (c->comm && c->model == EVOAMD_MODEL_SSSC) {
     // np.array_split shards differ by one row, so a shard size next to the threshold would make some ranks
     // issue three all-reduces and others one: agree once per geometry (max over ranks), same call on every rank
@@ -2744,6 +2758,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
   nchunks = (int)cdiv(N, rows_per_chunk);
   const bool second_stream = fork_gemm || nchunks > 1;
+  bool early_recorded = false;
   hipStream_t main_stream = c->stream;
   // Forked beside the elimination chain: a resident-sized grid holds every workgroup slot until it has drained, and the
   // grouped split-K drains all at once -- the chain (H / 32 block steps of 128 workgroups each) then runs entirely BEHIND
@@ -3081,6 +3096,11 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "sssc stats overflow levels");
       }
+      if (second_stream && nchunks == 1 && early && !masked) {
+        // every kernel that writes the [Es | Ez] rows has been enqueued: the contraction's stream branches off here
+        HIP_TRY(hipEventRecord(c->ev_chunk[0], main_stream));
+        early_recorded = true;
+      }
       if (pb.ent) {  // the entries of the main kernel and of the register-kernel levels: one tile pass per block
         SpanGuard g(c, KID_STATS);
         pair_bins_reduce_kernel<<<pb.nb * pb.nsh, PB_RTHREADS, (size_t)3 * 2 * pb.rf * H * sizeof(double), c->stream>>>(pb, H, ci > 0);
@@ -3120,7 +3140,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
     // ---- this block's part of the K = N contraction
     if (c->model == EVOAMD_MODEL_SSSC && masked) continue;  // two products from the reconstructed rows, below
     if (second_stream) {
-      HIP_TRY(hipEventRecord(c->ev_chunk[ci], main_stream));
+      if (!early_recorded) HIP_TRY(hipEventRecord(c->ev_chunk[ci], main_stream));
       HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_chunk[ci], 0));
       c->stream = c->stream2;
     }

@@ -136,6 +136,9 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "early_fork" (-1 = automatic, 0, 1): the stream of the forked K = N contraction branches off as soon as the [Es | Ez] rows are
+ * written, i.e. in front of the pair-bin reduce and the finish kernel instead of behind them; automatic = for products below
+ * 2e10 flops, where it also makes the fork itself pay from 5e8 flops on (c2: 0.377 -> 0.368 ms per iteration).
  * "merge_small_levels" (0/1, default 1): ES3C with census lists / quad kernels -- while the census of the last statistics
  * pass found few states above four active latents (expected <= 256 in the pass at hand), the pivoting wavefront kernel,
  * which runs behind the 3..4 level anyway, serves the 5..8 list as well instead of a launch of its own (a dependent launch
