@@ -167,6 +167,14 @@ struct evoamd_ctx {
   // alone costs 11 us there; N / 8 of c4 1.122 -> 1.114; N / 4 and larger lose 2-5 %: the persistent product then takes the
   // slots the reduce needs)
   int early_fork = -1;
+  // the mailbox header written by the last kernel of the ES3C update (lazy Theta, mailbox on the main stream): request
+  // (evoamd_mstep_device) and the sequence number that kernel was given (0 = the mailbox kernel has to run)
+  // option "fold_clear": evoamd_vary_kn's kernel zeroes the accumulators of the next statistics pass and checks + clears
+  // the census counters on its way (was a memset and a one-workgroup kernel in front of the census)
+  int fold_clear = 1;
+  bool acc_clean = false, clist_clean = false;
+  bool mbox_fold_req = false;
+  unsigned long long mbox_folded_seq = 0;
   int stats_chunks = 1;  // option "stats_chunks": the statistics pass runs in this many blocks of datapoints, the MFMA
                          // contraction of block i on the second stream beside the scatter kernels of block i + 1.
                          // Measured at the north-star shape (N = 100k, H = 512): 1 block 5.47 ms per iteration, 2 blocks
@@ -692,6 +700,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
     c->gemm_per_xcd = value;
     return 0;
   }
+  if (strcmp(name, "fold_clear") == 0) {
+    c->fold_clear = value != 0;
+    return 0;
+  }
   if (strcmp(name, "early_fork") == 0) {
     c->early_fork = value;
     return 0;
@@ -929,6 +941,7 @@ extern "C" int evoamd_configure(evoamd_ctx *c, int model, int64_t N, int D, int 
   c->dpar = c->acc + c->acc_n;
   ALLOC(c->err, 8);
   c->sing_gen = c->err + 4;
+  c->acc_clean = c->clist_clean = false;
   c->huge_slots = c->huge_kc = 0;
   if (c->huge) (void)hipFree(c->huge);
   if (c->huge_ctl) (void)hipFree(c->huge_ctl);
@@ -1824,7 +1837,9 @@ static int ensure_census(evoamd_ctx *c) {
   if (c->census_gen == c->kn_gen) return 0;
   const i64 total = c->N * (i64)c->S;
   // a level that no pass over the OLD census launched must have had an empty list; then fresh counters
-  check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
+  // (evoamd_vary_kn's kernel has done both on its way when it is what changed K^n)
+  if (!c->clist_clean) check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
+  c->clist_clean = false;
   c->census_skip = 0;
   unsigned grid = cdiv(total, CENSUS_T * CENSUS_PPT);
   if (grid > (unsigned)(8 * c->n_cu)) grid = (unsigned)(8 * c->n_cu);
@@ -2306,8 +2321,12 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
                                                                  c->Cmax, Mprime, c->rowmax,                      \
                                                                  c->rowsum, c->partial, c->list_n, 4 * LIST_SHARDS, \
                                                                  c->dig, c->cand_dig, (c->use_digest && c->dig) ? 1 : 0, \
-                                                                 c->pending_skip, c->err)
+                                                                 c->pending_skip, c->err, cl_n, 4 * LIST_SHARDS,      \
+                                                                 c->census_skip, c->acc_base, zero_n)
     const bool c1 = c->Cmax <= 64;
+    int *cl_n = census_mode(c) ? c->clist_n : nullptr;  // the old census dies with the old K^n: checked + cleared on the way
+    const i64 zero_n = c->fold_clear ? (i64)(c->ovf_n + c->acc_n) : 0;  // ... and the next statistics pass finds its accumulators zeroed
+    if (!c->fold_clear) cl_n = nullptr;
     if (c->S <= 64) { if (c1) VK_LAUNCH(1, 1); else VK_LAUNCH(1, 4); }
     else if (c->S <= 128) { if (c1) VK_LAUNCH(2, 1); else VK_LAUNCH(2, 4); }
     else if (c->S <= 256) { if (c1) VK_LAUNCH(4, 1); else VK_LAUNCH(4, 4); }
@@ -2318,6 +2337,11 @@ extern "C" int evoamd_vary_kn(evoamd_ctx *c, int Mprime, double *sums_out) {
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "vary_kn");
     c->rows_fresh = true;
+    if (cl_n) {
+      c->clist_clean = true;
+      c->census_skip = 0;
+    }
+    c->acc_clean = zero_n > 0;
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;  // vary_kn zeroed the overflow counters
     if (c->lists_clean) c->pending_skip = 0;          // ... and checked the skipped levels of the chain before it
   }
@@ -2436,6 +2460,7 @@ static int launch_estep_fused(evoamd_ctx *c, int n_parents, int n_children, uint
   if (inkernel_census) {
     check_lists_kernel<<<1, 256, 0, c->stream>>>(c->clist_n, 4 * LIST_SHARDS, c->census_skip, c->err);
     c->census_skip = 0;
+    c->clist_clean = false;  // the fused kernel appends to them
     f.cen_items = c->clist;
     f.cen_n = c->clist_n;
     f.cen_stride = (i64)c->clist_words;
@@ -2685,6 +2710,25 @@ static int join_fork(evoamd_ctx *c) {
 // all-reduced in two pieces: everything the inverses read here, the contraction's block at the join --
 // all RCCL calls stay on the main stream, in the same order on every rank.  Not while kernels are being
 // timed on the main stream.
+static TailArgs make_tail_args(evoamd_ctx *c, const AccLayout &a, i64 N, bool census, int skipped) {
+  TailArgs ta = {};
+  ta.tail = c->acc + a.tail;
+  ta.N = (double)N;
+  ta.dpar = c->dpar;
+  ta.flags = c->flags;
+  ta.nflags3 = 3 * N;
+  ta.nper = N;
+  ta.err = c->err;
+  ta.list_n = c->model == EVOAMD_MODEL_SSSC ? (census ? c->clist_n : c->list_n) : nullptr;
+  ta.nshards = LIST_SHARDS;
+  ta.skipped_mask = skipped;
+  ta.census = c->census;
+  ta.census_lists = census ? 1 : 0;
+  ta.fly_n = (census && c->model == EVOAMD_MODEL_SSSC) ? c->list_n : nullptr;
+  ta.fly_skip = c->pending_skip;
+  return ta;
+}
+
 static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   REQUIRE(c && c->configured && c->have_data && c->have_params, "configure, upload_data and set_params first");
   // (the contraction's own class alone does not count: its span is recorded on the stream the product runs on, so it
@@ -2730,7 +2774,9 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const i64 N = c->N;
   const int H = c->H, D = c->D;
   const bool masked = c->mask_infr != nullptr;
-  HIP_TRY(hipMemsetAsync(c->acc_base, 0, (size_t)(c->ovf_n + c->acc_n) * sizeof(double), c->stream));
+  if (!c->acc_clean)  // (else: zeroed by the selection kernel on its way)
+    HIP_TRY(hipMemsetAsync(c->acc_base, 0, (size_t)(c->ovf_n + c->acc_n) * sizeof(double), c->stream));
+  c->acc_clean = false;
   c->yhat_valid = c->stats_rows_valid = false;
   int r = ensure_B(c);
   if (r) return r;
@@ -2758,7 +2804,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   const i64 rows_per_chunk = (i64)cdiv(nblk, nchunks) * rpb;
   nchunks = (int)cdiv(N, rows_per_chunk);
   const bool second_stream = fork_gemm || nchunks > 1;
-  bool early_recorded = false;
+  bool early_recorded = false, tail_done = false;
   hipStream_t main_stream = c->stream;
   // Forked beside the elimination chain: a resident-sized grid holds every workgroup slot until it has drained, and the
   // grouped split-K drains all at once -- the chain (H / 32 block steps of 128 workgroups each) then runs entirely BEHIND
@@ -3126,11 +3172,17 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
                                                                              c->partial2, cdiv(N, 4), c->acc + a.sigma, PairBins{});
         } else {
           const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
+          // the accumulator tail (counters, census, list checks) as one more workgroup of this launch: one block of
+          // datapoints, complete data, no fused E-step reduction pending (that one writes the scalars the tail reads)
+          TailArgs ta = {};
+          if (nchunks == 1 && !masked && !c->reduce_pending) {
+            ta = make_tail_args(c, a, N, census, skipped);
+            tail_done = true;
+          }
           // complete data: the kernels left the column sums in CS_SLICES slices; else per-block partials of the rows
-          sssc_finish_kernel<<<cdiv(nthr, 256), 256, 0, c->stream>>>(c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs,
-                                                                     c->acc + a.xsz, masked ? c->colpart : sa.cs,
-                                                                     masked ? nblk : CS_SLICES, H, c->y2sum, c->acc + a.y2, D,
-                                                                     sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT, pb);
+          sssc_finish_kernel<<<cdiv(nthr, 256) + (tail_done ? 1 : 0), 256, 0, c->stream>>>(
+              c->acc + a.xss, c->acc + a.xszsz, c->acc + a.xs, c->acc + a.xsz, masked ? c->colpart : sa.cs,
+              masked ? nblk : CS_SLICES, H, c->y2sum, c->acc + a.y2, D, sa.xss_o, sa.xszsz_o, masked ? nullptr : c->PT, pb, ta);
         }
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "colsum + finish");
@@ -3188,10 +3240,7 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   }
   {
     SpanGuard g(c, KID_MISC);
-    tail_kernel<<<1, 256, 0, c->stream>>>(c->acc + a.tail, (double)N, c->dpar, c->flags, 3 * N, N, c->err,
-                                          c->model == EVOAMD_MODEL_SSSC ? (census ? c->clist_n : c->list_n) : nullptr,
-                                          LIST_SHARDS, skipped, c->census, census ? 1 : 0,
-                                          (census && c->model == EVOAMD_MODEL_SSSC) ? c->list_n : nullptr, c->pending_skip);
+    if (!tail_done) tail_kernel<<<1, 256, 0, c->stream>>>(make_tail_args(c, a, N, census, skipped));
     HIP_TRY(hipGetLastError());
     DBG_SYNC(c, "stats contraction + tail");
     c->lists_clean = c->model == EVOAMD_MODEL_SSSC;
@@ -3408,9 +3457,12 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     if (c->sssc_prec32) round_f32_kernel<<<cdiv(a.y2 - a.s_sz, 256), 256, 0, c->stream>>>(c->acc + a.s_sz, a.y2 - a.s_sz);
     if (learn & L_W)
       launch_gemm_nn_raw(c, c->acc + a.sWp, H, c->tmpA, H, c->W, H, D, H, H);
-    if (learn & L_PSI)
+    const bool masked = c->mask_infr != nullptr;  // sssc.py:747-755: the trace term arrives in tail[7]
+    // (Psi's element-wise finish rides along with the trace partials below when both run)
+    const bool psi_with_trace = (learn & L_PSI) && (learn & L_SIGMA2) && !masked;
+    if ((learn & L_PSI) && !psi_with_trace)
       sssc_psi_finish_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->tmpC, c->tmpB, c->acc + a.s_sz, c->mus, H, c->Psi);
-    else
+    else if (!(learn & L_PSI))
       psi_floor_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->Psi, H);
     HIP_TRY(hipGetLastError());
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, /*deterministic=*/true);  // G = W^T W (new W)
@@ -3418,12 +3470,20 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     const int n_part = (int)std::min<i64>(1024, cdiv(HH, 1024));
     r = ensure_colpart(c, (size_t)n_part);
     if (r) return r;
-    const bool masked = c->mask_infr != nullptr;  // sssc.py:747-755: the trace term arrives in tail[7]
-    if ((learn & L_SIGMA2) && !masked)
+    if (psi_with_trace)
+      sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart, c->tmpC,
+                                                               c->tmpB, c->acc + a.s_sz, c->mus, c->Psi);
+    else if ((learn & L_SIGMA2) && !masked)
       sssc_trace_partial_kernel<<<n_part, 256, 0, c->stream>>>(c->acc + a.sz_sz, c->G, H, cdiv(HH, n_part), c->colpart);
+    unsigned long long fold_seq = 0;
+    if (c->mbox_fold_req) {
+      fold_seq = ++c->mbox_seq;
+      c->mbox_folded_seq = fold_seq;
+    }
     sssc_sigma_precompute_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.y2, D, c->colpart, masked ? 0 : n_part, H, Nptr, learn,
                                                             c->pies, c->pilbar_v, c->dpar, masked ? c->rel_frac : -1.0,
-                                                            c->acc + a.tail + 7, c->sssc_prec32);
+                                                            c->acc + a.tail + 7, c->sssc_prec32,
+                                                            fold_seq ? c->h_theta_dev : nullptr, c->acc + a.tail, c->err, fold_seq);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   } else {
@@ -3515,7 +3575,9 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
       segs.n[3] = (long long)H;
     }
   }
-  const unsigned long long seq = ++c->mbox_seq;
+  const bool folded = c->mbox_folded_seq != 0 && !with_theta && !dma;  // the update's last kernel wrote the header
+  const unsigned long long seq = folded ? c->mbox_folded_seq : ++c->mbox_seq;
+  c->mbox_folded_seq = 0;
   const long long total = MAILBOX_HDR + (with_theta ? (long long)(DH + HH + 2 * H) : 0);
   const int grid = (int)std::min<long long>(64, cdiv(total, 256 * 8));
   // The mailbox kernel writes to pinned host memory and ends in a system-scope fence: 26 us of which nothing behind it
@@ -3527,13 +3589,14 @@ static int mailbox_roundtrip(evoamd_ctx *c, bool with_theta, bool prefetch = fal
   // c2 0.386 -> 0.404: the event pair costs ~10 us, and a 3 MB Theta copy beside the refresh only delays the host -- so
   // only the mailbox of a long iteration goes there, with Theta on board only at the north-star size)
   const double it_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H : 2.0 * (double)c->N * c->D * c->H;
-  if (c->mbox_side && !dma && it_flops >= (with_theta ? 8e10 : 8e9)) {
+  if (!folded && c->mbox_side && !dma && it_flops >= (with_theta ? 8e10 : 8e9)) {
     HIP_TRY(hipEventRecord(c->ev_mbox, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream_copy, c->ev_mbox, 0));
     mstream = c->stream_copy;
   }
-  mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, mstream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
-                                                           c->mbox_counter, seq);
+  if (!folded)
+    mailbox_kernel<<<grid < 1 ? 1 : grid, 256, 0, mstream>>>(c->h_theta_dev, c->acc + a.tail, c->err, segs,
+                                                             c->mbox_counter, seq);
   HIP_TRY(hipGetLastError());
   if (refresh) {
     int rr = refresh_after_update(c);
@@ -3668,7 +3731,13 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   }
   if (bak_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_bak, 0));
   if (learn_mask) {
+    {
+      // lazy Theta with the mailbox on the main stream: the header rides in the update's last kernel
+      const double it_flops = 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H;
+      c->mbox_fold_req = theta_home && c->model == EVOAMD_MODEL_SSSC && !(c->mbox_side && it_flops >= 8e9);
+    }
     r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true, bak_inline);
+    c->mbox_fold_req = false;
     if (r) return r;
     if (bak_inline) c->theta_bak_valid = true;
     c->stats_rows_valid = false;  // the rows belong to the previous Theta now
@@ -3687,6 +3756,7 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
     c->spd_fallbacks++;
     HIP_TRY(hipMemsetAsync(c->dpar + DP_STATUS, 0, sizeof(double), c->stream));
     HIP_TRY(hipMemcpyAsync(c->dpar + DP_LJC, c->dpar + DP_LJC_PREV, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->mbox_folded_seq = 0;
     r = update_params_device(c, learn_mask, /*force_pivot=*/true, /*defer_refresh=*/true);
     if (r) return r;
     r = mailbox_roundtrip(c, !theta_home, /*prefetch=*/true, /*refresh=*/true);

@@ -297,12 +297,32 @@ __global__ __launch_bounds__(256) void gemm_nn_naive_f32(const float *__restrict
 //   per-call if/elif priority (_models.py:585-590) and cleared, but only if some kernel raised
 //   any (word err[1]); the overflow-list counters of the statistics pass become dpar[DP_NGT*]
 //   and are zeroed for the next chain; a non-empty list behind a skipped level sets err[0] |= 4.
-__global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, double N, double *__restrict__ dpar,
-                                                   unsigned *__restrict__ flags, i64 nflags3, i64 nper,
-                                                   int *__restrict__ err, int *__restrict__ list_n, int nshards,
-                                                   int skipped_mask, const double *__restrict__ census,
-                                                   int census_lists = 0, int *__restrict__ fly_n = nullptr,
-                                                   int fly_skip = 0) {
+struct TailArgs {
+  double *tail;  // nullptr: nothing to do (a kernel that carries the tail as an extra workgroup)
+  double N;
+  double *dpar;
+  unsigned *flags;
+  i64 nflags3, nper;
+  int *err;
+  int *list_n;
+  int nshards, skipped_mask;
+  const double *census;
+  int census_lists;
+  int *fly_n;
+  int fly_skip;
+};
+// one workgroup of 256 threads
+__device__ __forceinline__ void tail_body(const TailArgs &ta) {
+  double *__restrict__ tail = ta.tail;
+  const double N = ta.N;
+  double *__restrict__ dpar = ta.dpar;
+  unsigned *__restrict__ flags = ta.flags;
+  const i64 nper = ta.nper;
+  int *__restrict__ err = ta.err;
+  int *__restrict__ list_n = ta.list_n;
+  const int nshards = ta.nshards, skipped_mask = ta.skipped_mask, census_lists = ta.census_lists, fly_skip = ta.fly_skip;
+  const double *__restrict__ census = ta.census;
+  int *__restrict__ fly_n = ta.fly_n;
   __shared__ int cnt[3];
   __shared__ int lvl[3];
   const int t = threadIdx.x;
@@ -375,6 +395,8 @@ __global__ __launch_bounds__(256) void tail_kernel(double *__restrict__ tail, do
     err[1] = 0;
   }
 }
+
+__global__ __launch_bounds__(256) void tail_kernel(TailArgs ta) { tail_body(ta); }
 
 // Reset counters with the reference's per-call if/elif priority (_models.py:585-590): one
 // "call" per datapoint per flag array.  counters[0..2] += {#nan calls, #(<eps) calls, #inf calls}.
@@ -479,10 +501,18 @@ __global__ __launch_bounds__(256) void vary_kn_kernel(u64 *__restrict__ states, 
                                                       double *__restrict__ rowsum, double *__restrict__ fpartial,
                                                       int *__restrict__ list_n, int n_list,
                                                       u64 *__restrict__ dig, const u64 *__restrict__ cand_dig,
-                                                      int dig_dedup, int skipped_mask, int *__restrict__ err) {
+                                                      int dig_dedup, int skipped_mask, int *__restrict__ err,
+                                                      int *__restrict__ clist_n = nullptr, int n_clist = 0, int census_skip = 0,
+                                                      double *__restrict__ zero_ptr = nullptr, i64 zero_n = 0) {
   __shared__ int blk_uniq[4], blk_sub[4];
   if (blockIdx.x == 0 && list_n)  // the statistics pass that follows appends to fresh overflow lists
     clear_lists_checked(list_n, n_list, skipped_mask, err);
+  // Two launches that used to stand between this kernel and the statistics pass ride along (c2: 14 us of 360):
+  //  * the census of the OLD K^n is dead from here on (every pass over it was enqueued before this kernel): its counters
+  //    are checked (a level nobody launched must have had an empty list) and cleared for the census of the new K^n;
+  //  * the accumulators of the statistics pass that follows are zeroed (the M-step that read the last ones is done).
+  if (blockIdx.x == 0 && clist_n) clear_lists_checked(clist_n, n_clist, census_skip, err);
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (i64)gridDim.x * 256) zero_ptr[i] = 0.0;
   __shared__ double wsum[4];
   __shared__ double new_v[4][64 * CPL];
   __shared__ int new_i[4][64 * CPL], old_i[4][64 * CPL];

@@ -1377,9 +1377,16 @@ __global__ __launch_bounds__(256) void psi_floor_kernel(double *__restrict__ Psi
 // partial sums of trace(sz_sz . G) = sum_ij sz_sz[i][j] G[j][i] over contiguous element ranges, one
 // partial per workgroup (fixed order => the same bits on every rank); a single workgroup walking
 // the H^2 products with a strided G took 0.24 ms at H = 512.
+// psi_raw != nullptr: the element-wise finish of Psi (sssc_psi_finish_kernel's arithmetic) rides along -- both walk
+// the H x H index space once and neither reads what the other writes (one launch instead of two).
 __global__ __launch_bounds__(256) void sssc_trace_partial_kernel(const double *__restrict__ sz_sz,
                                                                  const double *__restrict__ G, int H,
-                                                                 i64 per_block, double *__restrict__ part) {
+                                                                 i64 per_block, double *__restrict__ part,
+                                                                 const double *__restrict__ psi_raw = nullptr,
+                                                                 const double *__restrict__ T2inv = nullptr,
+                                                                 const double *__restrict__ s_sz = nullptr,
+                                                                 const double *__restrict__ mus = nullptr,
+                                                                 double *__restrict__ Psi = nullptr) {
   __shared__ double sh[256];
   const i64 e0 = (i64)blockIdx.x * per_block;
   const i64 e1 = (e0 + per_block < (i64)H * H) ? e0 + per_block : (i64)H * H;
@@ -1387,6 +1394,13 @@ __global__ __launch_bounds__(256) void sssc_trace_partial_kernel(const double *_
   for (i64 e = e0 + threadIdx.x; e < e1; e += 256) {
     const int i = (int)(e / H), j = (int)(e - (i64)i * H);
     s += sz_sz[e] * G[(i64)j * H + i];
+    if (psi_raw) {
+      double v = psi_raw[e];
+      v -= 2 * mus[i] * s_sz[e];  // mus[i] is the NEW mean (sssc.py:733), written by the prepare kernel
+      v *= T2inv[e];
+      if (i == j && v < 1e-5) v = 1e-5;
+      Psi[e] = v;
+    }
   }
   sh[threadIdx.x] = s;
   __syncthreads();
@@ -1406,7 +1420,12 @@ __global__ __launch_bounds__(256) void round_f32_kernel(double *__restrict__ x, 
 __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     const double *__restrict__ y2, int D, const double *__restrict__ trace_part, int n_part, int H,
     const double *__restrict__ Nptr, int learn, const double *__restrict__ pies, double *__restrict__ pil_bar,
-    double *__restrict__ dpar, double rel_frac, const double *__restrict__ pad, int prec32 = 0) {
+    double *__restrict__ dpar, double rel_frac, const double *__restrict__ pad, int prec32 = 0,
+    double *__restrict__ mbox = nullptr, const double *__restrict__ tail24 = nullptr, const int *__restrict__ errw = nullptr,
+    unsigned long long seq = 0) {
+  // mbox != nullptr: this is the last kernel of the update and Theta stays on the device -- the mailbox header (tail |
+  // scalar block | error words, then the sequence number the host polls; mailbox_kernel's layout) is written here
+  // instead of by a launch of its own.
   // rel_frac >= 0: incomplete data (sssc.py:352-357, 747-755): no trace partials (n_part = 0); *pad = the
   // masked square sum of y_hat, the reliable-entry count times the OLD sigma2 is added
   __shared__ double sh[MS_T];
@@ -1456,6 +1475,14 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
     else
       dpar[DP_LJC] = sh[0] - D / 2.0 * log(2 * M_PI) - 0.5 * (D * log(s2));
     if (!(s2 == s2) || isinf(s2)) dpar[DP_STATUS] = 2.0;
+  }
+  if (mbox) {
+    __syncthreads();  // thread 0's scalar block
+    if (t < 24) mbox[8 + t] = tail24[t];
+    if (t < 4) ((int *)(mbox + 1))[t] = errw[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store((unsigned long long *)mbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

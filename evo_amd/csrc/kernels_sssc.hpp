@@ -1906,7 +1906,12 @@ __global__ __launch_bounds__(256) void sssc_finish_kernel(double *__restrict__ x
                                                           const double *__restrict__ y2sum, double *__restrict__ y2out,
                                                           int D, const double *__restrict__ xss_o,
                                                           const double *__restrict__ xszsz_o,
-                                                          const PairEntry *__restrict__ PT, PairBins pb) {
+                                                          const PairEntry *__restrict__ PT, PairBins pb,
+                                                          TailArgs ta = TailArgs{}) {
+  if (ta.tail && blockIdx.x == gridDim.x - 1) {  // the accumulator tail rides along as one extra workgroup (was a launch)
+    tail_body(ta);
+    return;
+  }
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t < D) y2out[t] = y2sum[t];
   if (t >= (i64)H * H) return;

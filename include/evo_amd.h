@@ -136,6 +136,8 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "fold_clear" (0/1, default 1): the selection kernel (evoamd_vary_kn) zeroes the accumulators of the statistics pass that
+ * follows and checks + clears the counters of the census lists on its way; 0: a memset and a one-workgroup kernel do.
  * "early_fork" (-1 = automatic, 0, 1): the stream of the forked K = N contraction branches off as soon as the [Es | Ez] rows are
  * written, i.e. in front of the pair-bin reduce and the finish kernel instead of behind them; automatic = for products below
  * 2e10 flops, where it also makes the fork itself pay from 5e8 flops on (c2: 0.377 -> 0.368 ms per iteration).
