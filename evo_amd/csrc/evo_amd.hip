@@ -173,6 +173,7 @@ struct evoamd_ctx {
   // the census counters on its way (was a memset and a one-workgroup kernel in front of the census)
   int fold_clear = 1;
   bool acc_clean = false, clist_clean = false;
+  bool wq_copy_valid = false;  // EBSC: tmpA holds a copy of Wq (written by the finish kernel of the last statistics pass)
   bool mbox_fold_req = false;
   unsigned long long mbox_folded_seq = 0;
   int stats_chunks = 1;  // option "stats_chunks": the statistics pass runs in this many blocks of datapoints, the MFMA
@@ -2746,6 +2747,11 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
   // beside the pair-bin reduce, the finish kernel and the register-resident inverse instead of in front of them
   const bool early = c->early_fork == 1 || (c->early_fork < 0 && gemm_flops < 2e10);
   if (c->model == EVOAMD_MODEL_SSSC && !c->comm && early && gemm_flops >= 5e8 && !c->mask_infr) pays = true;
+  // EBSC the same (c3: the 48 us product beside the reduce, the finish kernel and the 9-launch elimination chain) where
+  // the wave-per-datapoint statistics kernel runs (the branch point sits behind it)
+  if (c->model == EVOAMD_MODEL_BSC && !c->comm && early && gemm_flops >= 5e8 && !c->mask_infr && c->bsc_wave_opt &&
+      dig_for(c, c->states) && cdiv(c->S, 64) <= 4 && (size_t)5 * c->H * sizeof(double) <= 150 * 1024 && !c->f32)
+    pays = true;
   if (c->comm && c->model == EVOAMD_MODEL_SSSC) {
     // np.array_split shards differ by one row, so a shard size next to the threshold would make some ranks
     // issue three all-reduces and others one: agree once per geometry (max over ranks), same call on every rank
@@ -2904,6 +2910,10 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
 #undef BSC_WAVE
         HIP_TRY(hipGetLastError());
         DBG_SYNC(c, "bsc stats (wave)");
+        if (second_stream && nchunks == 1 && early && !masked) {  // the E_q[s] rows are written: the product may start
+          HIP_TRY(hipEventRecord(c->ev_chunk[0], main_stream));
+          early_recorded = true;
+        }
         if (bsc_pb.ent) {
           pair_bins_reduce_kernel<<<bsc_pb.nb * bsc_pb.nsh, PB_RTHREADS, (size_t)3 * 2 * bsc_pb.rf * H * sizeof(double), c->stream>>>(
               bsc_pb, H, 0);
@@ -3163,13 +3173,20 @@ static int stats_compute(evoamd_ctx *c, bool fork_gemm = false) {
       {
         SpanGuard g(c, KID_MISC);
         if (c->model == EVOAMD_MODEL_BSC) {
+          TailArgs ta = {};  // (as for ES3C below) + a copy of Wq where the device update's inverse wants it
+          if (nchunks == 1 && !masked && !c->reduce_pending) {
+            ta = make_tail_args(c, a, N, false, skipped);
+            tail_done = true;
+          }
+          double *wq_copy = (!c->comm && !masked && c->tmpA) ? c->tmpA : nullptr;
+          c->wq_copy_valid = wq_copy != nullptr;
+          const unsigned fgrid = cdiv((i64)H * H, 256) + (tail_done ? 1 : 0);
           if (bsc_wave)
-            bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->acc_base + 4,
-                                                                             BSC_CS_SLICES, H, c->partial2, bsc_grid,
-                                                                             c->acc + a.sigma, bsc_pb);
+            bsc_finish_kernel<<<fgrid, 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->acc_base + 4, BSC_CS_SLICES, H,
+                                                             c->partial2, bsc_grid, c->acc + a.sigma, bsc_pb, ta, wq_copy);
           else
-            bsc_finish_kernel<<<cdiv((i64)H * H, 256), 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H,
-                                                                             c->partial2, cdiv(N, 4), c->acc + a.sigma, PairBins{});
+            bsc_finish_kernel<<<fgrid, 256, 0, c->stream>>>(c->acc + a.Wq, c->acc + a.pies, c->colpart, nblk, H, c->partial2,
+                                                             cdiv(N, 4), c->acc + a.sigma, PairBins{}, ta, wq_copy);
         } else {
           const i64 nthr = (i64)H * H > D ? (i64)H * H : D;
           // the accumulator tail (counters, census, list checks) as one more workgroup of this launch: one block of
@@ -3488,7 +3505,9 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     c->B_valid = false;
   } else {
     if (learn & L_W) {  // W^T = solve(Wq, Wp)  (bsc.py:237; lstsq == solve for a non-singular Wq)
-      HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      if (!c->wq_copy_valid || force_pivot)  // (else the finish kernel of the statistics pass left the copy in tmpA)
+        HIP_TRY(hipMemcpyAsync(c->tmpA, c->acc + a.Wq, HH * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      c->wq_copy_valid = false;
       r = launch_inverse(c, c->tmpA, nullptr, H, force_pivot);
       if (r) return r;
       r = join_fork(c);  // Wp comes from the contraction
@@ -3496,8 +3515,14 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H);
       transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
     }
+    unsigned long long fold_seq = 0;
+    if (c->mbox_fold_req) {
+      fold_seq = ++c->mbox_seq;
+      c->mbox_folded_seq = fold_seq;
+    }
     bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar,
-                                                  c->mask_infr ? c->rel_frac : -1.0);
+                                                  c->mask_infr ? c->rel_frac : -1.0, fold_seq ? c->h_theta_dev : nullptr,
+                                                  c->acc + a.tail, c->err, fold_seq);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   }
@@ -3733,8 +3758,9 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   if (learn_mask) {
     {
       // lazy Theta with the mailbox on the main stream: the header rides in the update's last kernel
-      const double it_flops = 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H;
-      c->mbox_fold_req = theta_home && c->model == EVOAMD_MODEL_SSSC && !(c->mbox_side && it_flops >= 8e9);
+      const double it_flops = c->model == EVOAMD_MODEL_SSSC ? 2.0 * (double)c->N * (c->D + 2.0 * c->H) * c->H
+                                                            : 2.0 * (double)c->N * c->D * c->H;
+      c->mbox_fold_req = theta_home && !(c->mbox_side && it_flops >= 8e9);
     }
     r = update_params_device(c, learn_mask, false, /*defer_refresh=*/true, bak_inline);
     c->mbox_fold_req = false;

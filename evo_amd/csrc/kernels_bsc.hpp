@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "kernels_mstep.hpp"
 #include "pair_bins.hpp"
+#include "kernels_common.hpp"  // TailArgs / tail_body
 
 #define BSC_CHUNK 8  // states handled by one wavefront before it moves on (y_n stays in registers)
 
@@ -689,9 +690,16 @@ __global__ __launch_bounds__(256) void bsc_stats_wave_kernel(
 __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq, double *__restrict__ pies,
                                                          const double *__restrict__ part, int nblk, int H,
                                                          const double *__restrict__ sig_part, i64 nsig,
-                                                         double *__restrict__ sigma, PairBins pb) {
+                                                         double *__restrict__ sigma, PairBins pb, TailArgs ta = TailArgs{},
+                                                         double *__restrict__ Wq_copy = nullptr) {
+  // ta.tail: the accumulator tail rides along as one extra workgroup (was a launch of its own); Wq_copy: a second copy
+  // of Wq for the in-place inverse of the device update (was a device-to-device copy in front of it)
+  if (ta.tail && blockIdx.x == gridDim.x - 1) {
+    tail_body(ta);
+    return;
+  }
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {  // last workgroup: sigma (tree over 256 threads, fixed order)
+  if (blockIdx.x == gridDim.x - (ta.tail ? 2 : 1)) {  // last workgroup of the H x H part: sigma (tree over 256 threads, fixed order)
     __shared__ double sh[256];
     const double s = (i64)threadIdx.x < nsig ? ordered_strided_sum(sig_part + threadIdx.x, 256, (nsig - threadIdx.x + 255) / 256) : 0.0;
     sh[threadIdx.x] = s;
@@ -708,11 +716,16 @@ __global__ __launch_bounds__(256) void bsc_finish_kernel(double *__restrict__ Wq
     const double s = ordered_strided_sum(part + i, H, nblk);
     pies[i] = s;
     Wq[t] = s;
+    if (Wq_copy) Wq_copy[t] = s;
   } else if (i < j) {  // this thread owns (i, j) and (j, i): atomics' sum + what went through the pair bins
     double bq = 0.0, bu, bl;
     if (pb.part) pb_collect(pb, H, i, j, bq, bu, bl);
     const double v = Wq[t] + bq;
     Wq[t] = v;
     Wq[(i64)j * H + i] = v;
+    if (Wq_copy) {
+      Wq_copy[t] = v;
+      Wq_copy[(i64)j * H + i] = v;
+    }
   }
 }

@@ -1491,7 +1491,11 @@ __global__ __launch_bounds__(MS_T) void sssc_sigma_precompute_kernel(
 __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restrict__ pies_sum,
                                                            const double *__restrict__ sig_sum, int H, int D,
                                                            const double *__restrict__ Nptr, int learn,
-                                                           double *__restrict__ dpar, double rel_frac) {
+                                                           double *__restrict__ dpar, double rel_frac,
+                                                           double *__restrict__ mbox = nullptr,
+                                                           const double *__restrict__ tail24 = nullptr,
+                                                           const int *__restrict__ errw = nullptr, unsigned long long seq = 0) {
+  // mbox: the mailbox header rides along (see sssc_sigma_precompute_kernel)
   // rel_frac >= 0: incomplete data, mean reliable entries per datapoint (bsc.py:113-118, 266-272)
   __shared__ double sh[MS_T];
   const int t = threadIdx.x;
@@ -1523,5 +1527,13 @@ __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restr
     dpar[DP_LJC_PREV] = dpar[DP_LJC];
     dpar[DP_LJC] = H * log(1.0 - pi) - (rel_frac >= 0.0 ? rel_frac : (double)D) / 2.0 * log(2 * M_PI * sigma * sigma);
     if (!(sigma == sigma) || !(pi == pi)) dpar[DP_STATUS] = 2.0;
+  }
+  if (mbox) {
+    __syncthreads();  // thread 0's scalar block
+    if (t < 24) mbox[8 + t] = tail24[t];
+    if (t < 4) ((int *)(mbox + 1))[t] = errw[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store((unsigned long long *)mbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
