@@ -173,7 +173,9 @@ struct evoamd_ctx {
   // the census counters on its way (was a memset and a one-workgroup kernel in front of the census)
   int fold_clear = 1;
   bool acc_clean = false, clist_clean = false;
-  bool wq_copy_valid = false;  // EBSC: tmpA holds a copy of Wq (written by the finish kernel of the last statistics pass)
+  bool wq_copy_valid = false;
+  double *gram_diag_out = nullptr;  // set around a launch_gemm_tn call whose Gram kernel should also write diag(G)
+  bool gram_diag_written = false;  // EBSC: tmpA holds a copy of Wq (written by the finish kernel of the last statistics pass)
   bool mbox_fold_req = false;
   unsigned long long mbox_folded_seq = 0;
   int stats_chunks = 1;  // option "stats_chunks": the statistics pass runs in this many blocks of datapoints, the MFMA
@@ -1271,11 +1273,12 @@ extern "C" int evoamd_download_lpj(evoamd_ctx *c, double *lpj) {
 // 16-byte row pieces need an even leading dimension and a 16-byte aligned base
 static bool gemm_vec_ok(const double *p, int ld) { return (ld % 2) == 0 && ((uintptr_t)p % 16) == 0; }
 
-static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
-                               i64 M, int Nc, int K) {
+// Ct / ldct: C^T as well where the parameter-sized kernel runs; returns whether it was written
+static bool launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                               i64 M, int Nc, int K, double *Ct = nullptr, int ldct = 0) {
   if (M <= 1024 && Nc <= 1024 && K <= 1024) {  // parameter-sized: one wave per 16 x 16 block
-    gemm_nn_small_kernel<<<dim3(cdiv(Nc, 16), cdiv(M, 16)), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, (int)M, Nc, K);
-    return;
+    gemm_nn_small_kernel<<<dim3(cdiv(Nc, 16), cdiv(M, 16)), 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, (int)M, Nc, K, Ct, ldct);
+    return Ct != nullptr;
   }
   const int gx = (int)cdiv(Nc, GEMM_BN), gy = (int)cdiv(M, GEMM_BM);
   const int rows_per_xcd = (gy + 7) / 8;
@@ -1284,6 +1287,7 @@ static void launch_gemm_nn_raw(evoamd_ctx *c, const double *A, int lda, const do
     gemm_nn_f64<true><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, gx, gy, rows_per_xcd);
   else
     gemm_nn_f64<false><<<grid, 256, 0, c->stream>>>(A, lda, B, ldb, C, ldc, M, Nc, K, gx, gy, rows_per_xcd);
+  return false;
 }
 
 // C (M x Nc) = A^T B, K rows; C is zeroed first when K is split.
@@ -1317,7 +1321,8 @@ static int launch_gemm_tn(evoamd_ctx *c, const double *A, int lda, const double 
     // G = W^T W of the Theta update: one wave per 16 x 16 block (gram_small_kernel)
     SpanGuard g(c, KID_GEMM);
     const int nb16 = (int)cdiv(M, 16);
-    gram_small_kernel<<<dim3(nb16, nb16), 256, 0, c->stream>>>(A, lda, (int)K, M, C, ldc);
+    gram_small_kernel<<<dim3(nb16, nb16), 256, 0, c->stream>>>(A, lda, (int)K, M, C, ldc, c->gram_diag_out);
+    c->gram_diag_written = c->gram_diag_out != nullptr;
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -3434,9 +3439,12 @@ static int refresh_after_update(evoamd_ctx *c) {
     if (r) return r;
     c->B_valid = true;
   } else if (!c->bsc_direct) {
+    c->gram_diag_out = c->diag;  // the parameter-sized Gram kernel leaves diag(G) on its way
+    c->gram_diag_written = false;
     r = launch_gemm_tn(c, c->W, H, c->W, H, c->G, H, H, H, D, true);
+    c->gram_diag_out = nullptr;
     if (r) return r;
-    extract_diag_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->G, H, c->diag);
+    if (!c->gram_diag_written) extract_diag_kernel<<<cdiv(H, 256), 256, 0, c->stream>>>(c->G, H, c->diag);
     r = launch_B(c);
     if (r) return r;
     c->B_valid = true;
@@ -3512,8 +3520,8 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
       if (r) return r;
       r = join_fork(c);  // Wp comes from the contraction
       if (r) return r;
-      launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H);
-      transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
+      if (!launch_gemm_nn_raw(c, c->tmpA, H, c->acc + a.Wp, D, c->Wt, D, H, D, H, c->W, H))  // W^T, and W on the way
+        transpose_kernel<<<cdiv((i64)H * D, 256), 256, 0, c->stream>>>(c->Wt, H, D, c->W);
     }
     unsigned long long fold_seq = 0;
     if (c->mbox_fold_req) {

@@ -885,8 +885,9 @@ __device__ __forceinline__ v4f64 small_gemm_reduce4(v4f64 acc, double (*part)[4]
 // global memory (W is L2 resident, D x H x 8 <= 1 MB).  The tiled kernel gives this problem 4..64
 // workgroups and one software-pipeline ramp: 20 us at c2.
 // Upper blocks only (block row <= block column); lower blocks are written transposed by the same wave.
+// diag != nullptr: the diagonal of G as a vector too (EBSC's lpj kernels read it; was a launch of its own)
 __global__ __launch_bounds__(256) void gram_small_kernel(const double *__restrict__ W, int ldw, int D, int H,
-                                                         double *__restrict__ G, int ldg) {
+                                                         double *__restrict__ G, int ldg, double *__restrict__ diag = nullptr) {
   __shared__ double part[3][4][64];
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bi > bj) return;
@@ -922,6 +923,7 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const double *__restric
     if (gi < H && gj < H) {
       G[(size_t)gi * ldg + gj] = acc[r];
       if (bi != bj) G[(size_t)gj * ldg + gi] = acc[r];
+      if (diag && gi == gj) diag[gi] = acc[r];
     }
   }
 }
@@ -932,7 +934,9 @@ __global__ __launch_bounds__(256) void gram_small_kernel(const double *__restric
 // each: 12 us at c2, 80 us at c5 for 0.5 GFLOP.
 __global__ __launch_bounds__(256) void gemm_nn_small_kernel(const double *__restrict__ A, int lda,
                                                             const double *__restrict__ B, int ldb,
-                                                            double *__restrict__ C, int ldc, int M, int Nc, int K) {
+                                                            double *__restrict__ C, int ldc, int M, int Nc, int K,
+                                                            double *__restrict__ Ct = nullptr, int ldct = 0) {
+  // Ct != nullptr: C^T as well (EBSC keeps W and W^T; was a transpose launch behind this one)
   __shared__ double part[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.y * 16 + (lane & 15), j = blockIdx.x * 16 + (lane & 15), kq = lane >> 4;
@@ -964,7 +968,10 @@ __global__ __launch_bounds__(256) void gemm_nn_small_kernel(const double *__rest
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int gi = blockIdx.y * 16 + (lane >> 4) + 4 * r, gj = blockIdx.x * 16 + (lane & 15);
-    if (gi < M && gj < Nc) C[(size_t)gi * ldc + gj] = acc[r];
+    if (gi < M && gj < Nc) {
+      C[(size_t)gi * ldc + gj] = acc[r];
+      if (Ct) Ct[(size_t)gj * ldct + gi] = acc[r];
+    }
   }
 }
 
