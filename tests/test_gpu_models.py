@@ -396,6 +396,48 @@ def test_overlap_gemm_option(engine, algo):
             np.testing.assert_allclose(out[0][1][k], out[other][1][k], rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("algo,lazy", [("ebsc", True), ("es3c", True), ("es3c", False)])
+def test_round4_launch_folding_options(engine, algo, lazy):
+    """Round 4 took ten launches out of an iteration: the selection kernel zeroes the next accumulators and clears the
+    census counters ("fold_clear"), the wavefront kernel serves the few states with 5..8 latents ("merge_small_levels"),
+    the forked contraction branches off in front of the pair-bin reduce ("early_fork"); the accumulator tail, Psi's
+    finish, the mailbox header, EBSC's Wq copy / W^T / diag(G) ride in neighbouring kernels unconditionally.  With the
+    three options off the old launch sequence runs: same K^n decisions (F of the first step bit for bit -- nothing
+    differs before the first statistics pass --, then to 1e-9) and the same Theta after four steps.  The shape is large
+    enough for the fork to be taken (5e8 flops) and sparse enough for the merged levels."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(4)
+    D, H, S, N = 48, 128, 24, 6000
+    W0 = rng.normal(size=(D, H))
+    Y = (rng.random_sample((N, H)) < 2.0 / H).astype(float) @ W0.T + 0.4 * rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    cls = BSC if algo == "ebsc" else SSSC
+    out = []
+    for on in (1, 0):
+        engine.set_option("fold_clear", on)
+        engine.set_option("merge_small_levels", on)
+        engine.set_option("early_fork", -1 if on else 0)
+        try:
+            np.random.seed(3)
+            model = cls(D, H, S, rng="device", sync_host=False, engine=engine, seed=5, device_mstep=True, lazy_theta=lazy)
+            theta = model.check_params(model.standard_init(my_data))
+            suff = init_states(N, S, H, "fit", "randflip", 6, 1, 1)
+            Fs = []
+            for _ in range(4):
+                F, _, _, theta = model.step(theta, suff, my_data)
+                Fs.append(F)
+            out.append((np.array(Fs), {k: np.array(v) for k, v in theta.items()}))
+        finally:
+            engine.set_option("fold_clear", 1)
+            engine.set_option("merge_small_levels", 1)
+            engine.set_option("early_fork", -1)
+    assert out[0][0][0] == out[1][0][0]
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-9)
+    for k in out[0][1]:
+        np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-7, atol=1e-10, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense", "ebsc_perm", "es3c_perm"])
 def test_device_mstep_matches_host(engine, name):
     """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
