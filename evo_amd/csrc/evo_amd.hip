@@ -3742,6 +3742,8 @@ extern "C" int evoamd_mstep_device(evoamd_ctx *c, int learn_mask, double *tail_o
   REQUIRE(!(c && c->mask_infr && c->rel_frac < 0.0), "incomplete data: evoamd_set_reliable_fraction first (bsc.py:113-118)");
   const bool theta_home = (learn_mask & 64) != 0;  // the caller fetches Theta^new on demand (evoamd_get_params_*)
   c->theta_bak_valid = false;
+  c->mbox_folded_seq = 0;  // (a header written by an update whose mailbox was never polled is not this call's)
+  c->mbox_fold_req = false;
   bool bak_pending = false;
   double *bak_inline = nullptr;
   if ((learn_mask & 31) && theta_home) {  // before the statistics pass is enqueued: the copy runs beside it
