@@ -167,6 +167,10 @@ struct evoamd_ctx {
   // alone costs 11 us there; N / 8 of c4 1.122 -> 1.114; N / 4 and larger lose 2-5 %: the persistent product then takes the
   // slots the reduce needs)
   int early_fork = -1;
+  // option "background_unit" (permanent["background"], variational/utils.py:42-47): the last latent is on in every state;
+  // the evolutionary operators leave it alone (eas.py:213-239) and the Theta update pins its prior to 1 - 1.1e-5
+  // (bsc.py:259-260, sssc.py:718-719)
+  int bg_unit = 0;
   // the mailbox header written by the last kernel of the ES3C update (lazy Theta, mailbox on the main stream): request
   // (evoamd_mstep_device) and the sequence number that kernel was given (0 = the mailbox kernel has to run)
   // option "fold_clear": evoamd_vary_kn's kernel zeroes the accumulators of the next statistics pass and checks + clears
@@ -701,6 +705,10 @@ extern "C" int evoamd_set_option(evoamd_ctx *c, const char *name, int value) {
   }
   if (strcmp(name, "gemm_per_xcd") == 0) {
     c->gemm_per_xcd = value;
+    return 0;
+  }
+  if (strcmp(name, "background_unit") == 0) {
+    c->bg_unit = value != 0;
     return 0;
   }
   if (strcmp(name, "fold_clear") == 0) {
@@ -2376,7 +2384,7 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
   {
     SpanGuard g(c, KID_EVOLVE);
 #define EV_LAUNCH(SPL)                                                                                         \
-  evolve_randflip_kernel<SPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H, \
+  evolve_randflip_kernel<SPL><<<cdiv(c->N, 4), 256, 0, c->stream>>>(c->states, c->lpj, c->N, c->S, c->S_perm, c->H - c->bg_unit, \
                                                                     c->HW, n_parents, n_children, c->Cmax, seed,  \
                                                                     fit_parents, c->cand, c->cand_counts, c->list_n,   \
                                                                     c->model == EVOAMD_MODEL_SSSC ? 4 * LIST_SHARDS : 0, \
@@ -2407,7 +2415,7 @@ extern "C" int evoamd_evolve_randflip(evoamd_ctx *c, int n_parents, int n_childr
 // ---------------------------------------------------------------------------------------
 static bool fused_shape_ok(const evoamd_ctx *c, int n_parents, int n_children) {
   // (the LDS condition is the one under which launch_sssc_lpj<0> serves K^n from the census lists)
-  return c->model == EVOAMD_MODEL_SSSC && c->S_perm == 0 && !c->mask_infr && c->use_digest && c->dig && census_mode(c) &&
+  return c->model == EVOAMD_MODEL_SSSC && c->S_perm == 0 && !c->bg_unit && !c->mask_infr && c->use_digest && c->dig && census_mode(c) &&
          c->H <= 1024 && c->H >= 2 && (c->H % 2) == 0 && n_parents * n_children <= 64 && n_parents * n_children <= c->Cmax &&
          c->rowF && c->defer &&
          ((size_t)(1024 / c->S + 2) * c->H + (c->H <= 512 ? (size_t)4 * c->H : 0)) * sizeof(double) <= MAIN_LPJ_LDS_MAX;
@@ -2626,7 +2634,7 @@ extern "C" int evoamd_evolve_states(evoamd_ctx *c, int mutation, int fit_parents
   a.N = c->N;
   a.S = c->S;
   a.S_perm = c->S_perm;
-  a.H = c->H;
+  a.H = c->H - c->bg_unit;  // the operators' domain: without the permanent background unit (eas.py:213-239)
   a.HW = c->HW;
   a.Cmax = c->Cmax;
   a.n_parents = n_parents;
@@ -3469,7 +3477,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     sssc_mstep_prepare_kernel<<<cdiv(HH, 256), 256, 0, c->stream>>>(c->acc + a.xs, c->acc + a.xsz, c->acc + a.xss,
                                                                     c->acc + a.xszsz, Nptr, H, learn,
                                                                     c->pies, c->mus, c->tmpA, c->tmpC, c->tmpB, bak, c->W,
-                                                                    c->Psi, c->dpar, D);
+                                                                    c->Psi, c->dpar, D, c->bg_unit);
     if ((learn & L_W) && (learn & L_PSI))
       r = launch_inverse(c, c->tmpA, c->tmpB, H, force_pivot);
     else if (learn & L_W)
@@ -3530,7 +3538,7 @@ static int update_params_device(evoamd_ctx *c, int learn, bool force_pivot = fal
     }
     bsc_scalars_kernel<<<1, MS_T, 0, c->stream>>>(c->acc + a.pies, c->acc + a.sigma, H, D, Nptr, learn, c->dpar,
                                                   c->mask_infr ? c->rel_frac : -1.0, fold_seq ? c->h_theta_dev : nullptr,
-                                                  c->acc + a.tail, c->err, fold_seq);
+                                                  c->acc + a.tail, c->err, fold_seq, c->bg_unit);
     HIP_TRY(hipGetLastError());
     c->B_valid = false;
   }

@@ -200,6 +200,15 @@ __device__ __forceinline__ const u64 *evg_state(const EvolveArgs &a, i64 n, int 
   return j < a.S ? a.states + (n * (i64)a.S + j) * a.HW : a.cand + (n * (i64)a.Cmax + (j - a.S)) * a.HW;
 }
 
+// Bits of word w that belong to the mutation domain, latents 0 .. H-1.  H is the number of latents the operators see:
+// all of them, or all but the last with the permanent background unit (eas.py:213-239: the operators get
+// parents[:, :H-1] and every child the unit back, switched on -- here the children simply inherit it, nothing below
+// ever touches a latent >= H).
+__device__ __forceinline__ u64 evg_domain_mask(int w, int H) {
+  const int valid = H - 64 * w;
+  return valid >= 64 ? ~0ull : (valid <= 0 ? 0ull : (~0ull << (64 - valid)));
+}
+
 // sparseflip probabilities of a parent with s_abs active bits (eas.py:75-83, same operation order)
 __device__ __forceinline__ void evg_sparse_p(double H, double s_abs, double sparseness, double p_bf, double &p0, double &p1) {
   const double eps = 1e-100;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(64) void evolve_general_kernel(EvolveArgs a) {
       }
       if (flip1 >= 0 && (flip1 >> 6) == w) v ^= (0x8000000000000000ull >> (flip1 & 63));
       dst[w] = v;
-      s_abs += __popcll(v);
+      s_abs += __popcll(v & evg_domain_mask(w, H));
     }
     if (a.kind == EV_SPARSEFLIP || a.kind == EV_CROSS_SPARSEFLIP) {
       double p0, p1;
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(64) void evolve_general_kernel(EvolveArgs a) {
       // bits that are 1: one uniform each (index = latent); bits that are 0: geometric skipping with p0
       for (int w = 0; w < HW; w++) {
         const u64 orig = dst[w];
-        u64 v = orig, bits = orig;
+        u64 v = orig, bits = orig & evg_domain_mask(w, H);
         while (bits) {
           const int b = pop_msb(bits);
           if (rng_u01(a.seed, (u64)n, kp, 1 + (u64)(w * 64 + b)) < p1) v ^= (0x8000000000000000ull >> b);

@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
     double *__restrict__ pies, double *__restrict__ mus, double *__restrict__ xszsz_copy,
     double *__restrict__ psi_raw, double *__restrict__ T2, double *__restrict__ bak = nullptr,
     const double *__restrict__ Wsrc = nullptr, const double *__restrict__ Psisrc = nullptr,
-    const double *__restrict__ dpar = nullptr, int D = 0) {
+    const double *__restrict__ dpar = nullptr, int D = 0, int bg_unit = 0) {
   const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
   if (t >= (i64)H * H) return;
   const int i = (int)(t / H), j = (int)(t - (i64)i * H);
@@ -1342,6 +1342,7 @@ __global__ __launch_bounds__(256) void sssc_mstep_prepare_kernel(
       p = xs[i] / N;
       if (p <= 5e-5) p = 5e-5;  // eps_pies
       if (p >= 1.0 - 5e-5) p = 1.0 - 5e-5;
+      if (bg_unit && i == H - 1) p = 1.0 - 1.1e-5;  // permanent background unit (sssc.py:718-719)
     }
     p = fmax(1e-5, p);  // check_params: pies in [tol, 1 - tol]
     p = fmin(1.0 - 1e-5, p);
@@ -1494,14 +1495,16 @@ __global__ __launch_bounds__(MS_T) void bsc_scalars_kernel(const double *__restr
                                                            double *__restrict__ dpar, double rel_frac,
                                                            double *__restrict__ mbox = nullptr,
                                                            const double *__restrict__ tail24 = nullptr,
-                                                           const int *__restrict__ errw = nullptr, unsigned long long seq = 0) {
+                                                           const int *__restrict__ errw = nullptr, unsigned long long seq = 0,
+                                                           int bg_unit = 0) {
   // mbox: the mailbox header rides along (see sssc_sigma_precompute_kernel)
+  // bg_unit: pies_new[-1] = 1 - 1.1e-5 before pi = mean(pies_new) (permanent background unit, bsc.py:259-261)
   // rel_frac >= 0: incomplete data, mean reliable entries per datapoint (bsc.py:113-118, 266-272)
   __shared__ double sh[MS_T];
   const int t = threadIdx.x;
   const double N = *Nptr;
   double s = 0.0;
-  for (int h = t; h < H; h += MS_T) s += pies_sum[h] / N;
+  for (int h = t; h < H; h += MS_T) s += (bg_unit && h == H - 1) ? 1.0 - 1.1e-5 : pies_sum[h] / N;
   sh[t] = s;
   __syncthreads();
   for (int o = MS_T / 2; o > 0; o >>= 1) {

@@ -261,10 +261,13 @@ class Model:
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])
-        if my_suff_stat["permanent"]["background"]:
-            raise NotImplementedError("permanent background unit is outside the accelerated path")
+        background = bool(my_suff_stat["permanent"]["background"])  # last latent on in every state (utils.py:42-47)
         cmax = self._cmax(my_suff_stat) if "n_parents" in my_suff_stat else 1
         eng = self.engine
+        self._background = background  # update_params / the device update pin the unit's prior (bsc.py:259, sssc.py:718)
+        if getattr(eng, "_bg_unit", False) != background:  # (only on a change: setting an option drops a prefetched pass)
+            eng.set_option("background_unit", 1 if background else 0)
+            eng._bg_unit = background
         f32 = self.dtype == np.float32
         if not eng.same_geometry(self.model_name, N, D, self.H, self.S, S_perm, cmax) or eng.f32 != f32:
             eng.set_option("ebsc_f32", 1 if f32 else 0)  # read by configure
@@ -686,12 +689,11 @@ class Model:
         (_models.py:333-451; H < 12).  The 2^H - 1 non-zero states are ONE shared candidate set
         evaluated against every datapoint in a single launch."""
         permanent = my_suff_stat["permanent"]
-        if permanent["background"]:
-            raise NotImplementedError("permanent background unit is outside the accelerated path")
+        background = bool(permanent["background"])
         Y = my_data["y"]
         N_loc = Y.shape[0]
         N = self.comm.allreduce(N_loc)
-        force_zero = full and not permanent["allzero"]
+        force_zero = full and not permanent["allzero"] and not background  # (_models.py:366-373)
         S_perm = 1 if force_zero else my_suff_stat["S_perm"]
         if full or compute_lpj:
             # a scratch engine geometry is fine here: only Y and Theta are needed
@@ -700,7 +702,10 @@ class Model:
         if full:
             sm = my_suff_stat["sm"]
             assert sm is not None
-            body = eng.lpj_shared(sm[1:, :])
+            if background:  # every state of the other H - 1 latents with the unit on; no all-zero state (_models.py:389-390)
+                body = eng.lpj_shared(np.concatenate((sm, np.ones((sm.shape[0], 1), dtype=bool)), axis=1))
+            else:
+                body = eng.lpj_shared(sm[1:, :])
         elif compute_lpj:
             eng.lpj_resident()
             body = eng.download_lpj()[:, my_suff_stat["S_perm"]:]

@@ -97,6 +97,8 @@ class BSC(Model):
             model_params["W"] = W_new.T
         if "pi" in self.to_learn:
             pies_new = sums["pies"] / N
+            if getattr(self, "_background", False):  # permanent background unit (bsc.py:259-260)
+                pies_new[-1] = 1.0 - 1.1e-5
             model_params["pi"] = pies_new.sum() / H
             model_params["pies"] = pies_new
         if "sigma" in self.to_learn:

@@ -197,6 +197,8 @@ class SSSC(Model):
             pies_new = np.array(sums["xpt_s"]) / N
             pies_new[pies_new <= self.eps_pies] = self.eps_pies
             pies_new[pies_new >= (1 - self.eps_pies)] = 1 - self.eps_pies
+            if getattr(self, "_background", False):  # permanent background unit (sssc.py:718-719)
+                pies_new[H - 1] = 1.0 - 1.1e-5
             model_params["pies"] = pies_new
         if "mus" in learn:
             model_params["mus"] = sums["xpt_sz"] * 1.0 / (sums["xpt_s"] + self.eps_mus)

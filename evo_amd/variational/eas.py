@@ -107,8 +107,7 @@ def evolve_states(my_suff_stat, model_params, eval_lpj):
     """
     lpj0 = my_suff_stat["this_lpj"]
     kn = my_suff_stat["this_states"]
-    if my_suff_stat["permanent"]["background"]:
-        raise NotImplementedError("permanent background unit is outside the accelerated path")
+    background = bool(my_suff_stat["permanent"]["background"])  # eas.py:213-239: the last latent is not mutated
     select = my_suff_stat["parent_selection"]
     mutate = my_suff_stat["mutation_algorithm"]
     n_par, n_child = my_suff_stat["n_parents"], my_suff_stat["n_children"]
@@ -122,7 +121,9 @@ def evolve_states(my_suff_stat, model_params, eval_lpj):
     pool_s, pool_l = kn, lpj0
     for g in range(n_gen):
         n_pick = np.min([pool_s.shape[0], n_par]) if g else np.min([S, n_par])
-        kids = mutate(select(pool_s, n_pick, pool_l)[:, :H], n_child, sparseness, p_bf)
+        kids = mutate(select(pool_s, n_pick, pool_l)[:, :(H - 1 if background else H)], n_child, sparseness, p_bf)
+        if background:
+            kids = np.concatenate((kids, np.ones((kids.shape[0], 1), dtype=bool)), axis=1)
         n_known = known.shape[0]
         both = np.concatenate((known, kids), axis=0)
         _, first, inverse = np.unique(row_keys(both), return_index=True, return_inverse=True)
@@ -156,8 +157,11 @@ def first_generation_candidates(kn, lpj, my_suff_stat, sparseness):
     S, H = kn.shape
     n_pick = np.min([S, my_suff_stat["n_parents"]])
     parents = my_suff_stat["parent_selection"](kn, n_pick, lpj)
-    kids = my_suff_stat["mutation_algorithm"](parents[:, :H], my_suff_stat["n_children"], sparseness,
-                                              my_suff_stat["bitflip_prob"])
+    background = bool(my_suff_stat["permanent"]["background"])
+    kids = my_suff_stat["mutation_algorithm"](parents[:, :(H - 1 if background else H)], my_suff_stat["n_children"],
+                                              sparseness, my_suff_stat["bitflip_prob"])
+    if background:
+        kids = np.concatenate((kids, np.ones((kids.shape[0], 1), dtype=bool)), axis=1)
     known = np.concatenate((my_suff_stat["incl"], kn), axis=0)
     both = np.concatenate((known, kids), axis=0)
     _, first = np.unique(row_keys(both), return_index=True)

@@ -36,23 +36,43 @@ def init_states(N, S, H, parent_selection, mutation_algorithm, no_parents, no_ch
                 bitflip_prob=None, Mprime=None, p_init_Kn=None, permanent=None):
     """Build ``my_suff_stat`` (variational/utils.py:19-228): S unique Bernoulli(p_init_Kn) states per
     datapoint (RNG: np.random.random((S,H)) per round, rounds repeated until S unique rows exist)
-    plus the EA hyper-parameters.  Keys and dtypes are the reference's.  Not supported on the
-    accelerated path: the permanent background unit and exact E-steps (S == 2^H)."""
+    plus the EA hyper-parameters.  Keys and dtypes are the reference's.
+
+    ``permanent["background"]`` (:42-47, :96-98, :140-141): the last latent is a background unit, on in every state --
+    the draws and the state table ``sm`` cover the other H - 1 latents, and there is no permanent all-zero state
+    whatever ``allzero`` says.  ``S == 2 ** H_`` (H_ = latents that vary; < 12) means exact E-steps (:55, :71-88): K^n is
+    the whole state table for every datapoint and no random number is drawn (with the permanent all-zero state the
+    table's other 2^H - 1 rows: K^n then has one row fewer than S, as in the reference)."""
     permanent = permanent or {"background": False, "allzero": False, "singletons": False}
-    if permanent["background"]:
-        raise NotImplementedError("permanent background unit is outside the accelerated path")
-    if S == 2 ** H:
-        raise NotImplementedError("exact E-steps (S == 2^H) are outside the accelerated path")
-    S_perm = 1 if (permanent["allzero"] == 1 and permanent["singletons"] == 0) else 0
-    incl = np.zeros((S_perm, H), dtype=bool)
-    p0 = 1.0 / H if p_init_Kn is None else p_init_Kn
-    ss = np.empty((N, S, H), dtype=bool)
-    for n in range(N):
-        have = _unique_after([incl, np.random.random(size=(S, H)) < p0], S_perm)
-        while have.shape[0] < S:
-            more = np.random.random(size=(S, H)) < p0
-            have = np.concatenate((have, _unique_after([incl, have, more], S_perm + have.shape[0])), axis=0)
-        ss[n] = have[:S]
+    background = bool(permanent["background"])
+    Hv = H - 1 if background else H
+    S_perm = 0 if background else (1 if (permanent["allzero"] == 1 and permanent["singletons"] == 0) else 0)
+    incl = np.zeros((S_perm, Hv), dtype=bool)
+    sm = enumerate_states(Hv) if Hv < 12 else None
+    if S == 2 ** Hv:
+        assert Hv < 12, "Exact E-steps too expensive for H={})".format(Hv)
+        pprint("Computing exact E-steps")
+        if background:
+            table = np.concatenate((sm, np.ones((sm.shape[0], 1), dtype=bool)), axis=1)
+            lpj = np.empty((N, 2 ** Hv))
+        else:
+            table = (sm[1:] if S_perm else sm).copy()
+            lpj = np.empty((N, S + S_perm))
+        ss = np.tile(table[None], (N, 1, 1))
+    else:
+        p0 = 1.0 / H if p_init_Kn is None else p_init_Kn
+        lpj = np.empty((N, S + S_perm))
+        ss = np.empty((N, S, H), dtype=bool)
+        if background:
+            ss[:, :, -1] = True
+        for n in range(N):
+            have = _unique_after([incl, np.random.random(size=(S, Hv)) < p0], S_perm)
+            while have.shape[0] < S:
+                more = np.random.random(size=(S, Hv)) < p0
+                have = np.concatenate((have, _unique_after([incl, have, more], S_perm + have.shape[0])), axis=0)
+            ss[n, :, :Hv] = have[:S]
+    if background:
+        incl = np.zeros((S_perm, H), dtype=bool)
     if "cross" in mutation_algorithm:
         no_children = no_parents - 1
         pprint("Setting no_children to pre-determined value `no_parents - 1` ({}) when using crossover".format(
@@ -62,8 +82,7 @@ def init_states(N, S, H, parent_selection, mutation_algorithm, no_parents, no_ch
         Mprime = S
     assert Mprime <= S
     return {
-        "ss": ss, "lpj": np.empty((N, S + S_perm)), "permanent": permanent, "incl": incl, "S_perm": S_perm,
-        "sm": enumerate_states(H) if H < 12 else None,
+        "ss": ss, "lpj": lpj, "permanent": permanent, "incl": incl, "S_perm": S_perm, "sm": sm,
         "n_parents": no_parents, "n_children": no_children, "n_generations": no_generations,
         "parent_selection": PARENT_SELECTION[parent_selection],
         "mutation_algorithm": MUTATION[mutation_algorithm],

@@ -136,6 +136,10 @@ int evoamd_synchronize(evoamd_ctx *ctx);
  * every slab of the operands through its L2 (a quarter of the stream-K form's HBM reads); 0: always stream-K.
  * "gemm_per_xcd" (0 = automatic): K chunks per XCD of the long-K 128-tile contraction
  * (measurement aid: tools/gemm_sweep.sh).
+ * "background_unit" (0/1, default 0): permanent["background"] of the reference (variational/utils.py:42-47) -- the last latent
+ * is on in every state: the device evolutionary operators mutate the other H - 1 latents only (eas.py:213-239) and the
+ * device Theta update pins its prior to 1 - 1.1e-5 (bsc.py:259-260, sssc.py:718-719).  The host classes set it from
+ * my_suff_stat["permanent"].
  * "fold_clear" (0/1, default 1): the selection kernel (evoamd_vary_kn) zeroes the accumulators of the statistics pass that
  * follows and checks + clears the counters of the census lists on its way; 0: a memset and a one-workgroup kernel do.
  * "early_fork" (-1 = automatic, 0, 1): the stream of the forked K = N contraction branches off as soon as the [Es | Ez] rows are

@@ -21,9 +21,9 @@ the same operands) so trajectories agree bit-for-bit on the fixture inputs; the 
 organisation (pure functions over explicit arguments instead of the reference's class +
 scratch-dict protocol) is our own.
 
-Scope restrictions: complete data (``x_infr`` all True), no
-``background`` permanent state.  The ``allzero`` permanent state is supported because the
-exact-likelihood path (``free_energy(full=True)``) needs it.
+Permanent states: ``allzero`` (the exact-likelihood path ``free_energy(full=True)`` needs it) and, since round 4,
+the ``background`` unit (last latent on in every state) and exact E-steps (S == 2^H_); pinned by
+tests/golden/background.npz and step_*_bg / step_*_exact*.npz.
 """
 from __future__ import annotations
 
@@ -171,8 +171,9 @@ def evolve_states(states, lpj, ea, piH, eval_lpj):
     """eas.py:153-313.  ``states`` (S,H) bool, ``lpj`` (S,), ``ea`` the hyper-parameter dict
     made by init_states.  Returns (new unique states in lexicographic order per generation,
     their lpj).  Includes the reference's re-use of old lpj values with the index shift of
-    eas.py:284-293; permanent background unit is out of scope (asserted)."""
-    assert not ea["permanent"]["background"]
+    eas.py:284-293.  Permanent background unit (eas.py:213-239): the last latent is not mutated -- the
+    operators see the parents without it and every child gets it back switched on."""
+    background = bool(ea["permanent"]["background"])
     incl = ea["incl"]
     n_par, n_child, n_gen = ea["n_parents"], ea["n_children"], ea["n_generations"]
     select, mutate = ea["parent_selection"], ea["mutation_algorithm"]
@@ -188,7 +189,9 @@ def evolve_states(states, lpj, ea, piH, eval_lpj):
             parents = select(states, np.min([K, n_par]), lpj)
         else:
             parents = select(out_states[pool], np.min([len(pool), n_par]), out_lpj[pool])
-        kids = mutate(parents[:, :H], n_child, piH, ea["bitflip_prob"])
+        kids = mutate(parents[:, :(H - 1 if background else H)], n_child, piH, ea["bitflip_prob"])
+        if background:
+            kids = np.concatenate((kids, np.ones((kids.shape[0], 1), dtype=bool)), axis=1)
         if g == 0:
             per_gen = kids.shape[0]
             out_states = np.zeros((per_gen * n_gen, H), dtype=bool)
@@ -246,31 +249,47 @@ def all_states_matrix(H):
 
 def init_states(N, S, H, parent_selection, mutation_algorithm, no_parents, no_children,
                 no_generations, bitflip_prob=None, Mprime=None, p_init_Kn=None, permanent=None):
-    """variational/utils.py:19-228 (background unit and exact E-steps S==2^H out of scope).
-    Draws S Bernoulli(p_init_Kn) rows per datapoint, tops up until S unique rows exist
-    (first-occurrence order of the sorted-unique result), and stores the EA knobs."""
+    """variational/utils.py:19-228.  Draws S Bernoulli(p_init_Kn) rows per datapoint, tops up until S unique rows
+    exist (first-occurrence order of the sorted-unique result), and stores the EA knobs.  Permanent background unit
+    (:42-47, :96-98, :140-141): the draws cover the first H - 1 latents, the last one is on in every state, no permanent
+    all-zero state whatever ``allzero`` says.  Exact E-steps (:55, :71-88): S == 2^H_ makes K^n the full state table for
+    every datapoint (with the all-zero permanent state: its 2^H - 1 other rows, i.e. ONE ROW FEWER than S)."""
     if permanent is None:
         permanent = {"background": False, "allzero": False, "singletons": False}
-    assert not permanent["background"]
-    S_perm = 1 if (permanent["allzero"] == 1 and permanent["singletons"] == 0) else 0
-    incl = np.zeros((S_perm, H), dtype=bool)
-    assert S != 2 ** H, "exact E-steps are out of the oracle's scope"
-    sm = all_states_matrix(H) if H < 12 else None
-    if p_init_Kn is None:
-        p_init_Kn = 1.0 / H
-    lpj = np.empty((N, S + S_perm))
-    ss = np.empty((N, S, H), dtype=bool)
-    for n in range(N):
-        draw = np.random.random(size=(S, H)) < p_init_Kn
-        conc, first = _first_unique([incl, draw], H)
-        first = first[first >= S_perm]
-        have = conc[first, :].astype(np.bool_)
-        while have.shape[0] < S:
-            more = np.random.random(size=(S, H)) < p_init_Kn
-            conc, first = _first_unique([incl, have, more], H)
-            first = first[first >= (S_perm + have.shape[0])]
-            have = np.concatenate((have, conc[first, :].astype(np.bool_)), axis=0)
-        ss[n] = have[:S]
+    background = bool(permanent["background"])
+    Hd = H - 1 if background else H  # latents that are drawn / enumerated
+    S_perm = 0 if background else (1 if (permanent["allzero"] == 1 and permanent["singletons"] == 0) else 0)
+    incl = np.zeros((S_perm, Hd), dtype=bool)
+    sm = all_states_matrix(Hd) if Hd < 12 else None
+    if S == 2 ** Hd:
+        assert Hd < 12, "Exact E-steps too expensive for H={})".format(Hd)
+        if background:
+            table = np.concatenate((sm, np.ones((sm.shape[0], 1), dtype=bool)), axis=1)
+            lpj = np.empty((N, 2 ** Hd))
+        else:
+            lpj = np.empty((N, S + S_perm))
+            table = sm[1:, :].copy() if S_perm == 1 else sm.copy()
+        ss = np.tile(table[None, :, :], (N, 1, 1))
+    else:
+        if p_init_Kn is None:
+            p_init_Kn = 1.0 / H
+        lpj = np.empty((N, S + S_perm))
+        ss = np.empty((N, S, H), dtype=bool)
+        if background:
+            ss[:, :, -1] = True
+        for n in range(N):
+            draw = np.random.random(size=(S, Hd)) < p_init_Kn
+            conc, first = _first_unique([incl, draw], Hd)
+            first = first[first >= S_perm]
+            have = conc[first, :].astype(np.bool_)
+            while have.shape[0] < S:
+                more = np.random.random(size=(S, Hd)) < p_init_Kn
+                conc, first = _first_unique([incl, have, more], Hd)
+                first = first[first >= (S_perm + have.shape[0])]
+                have = np.concatenate((have, conc[first, :].astype(np.bool_)), axis=0)
+            ss[n, :, :Hd] = have[:S]
+    if background:
+        incl = np.zeros((S_perm, H), dtype=bool)
     if "cross" in mutation_algorithm:
         no_children = no_parents - 1
     assert no_parents <= S
@@ -490,7 +509,7 @@ def bsc_accumulate(theta, suff, Y, x_infr=None, y_rec=None):
     return {"Wp": Wp, "Wq": Wq, "pies": pies, "sigma": sig}
 
 
-def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma"), n_reliable=None):
+def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma"), n_reliable=None, background=False):
     """bsc.py:226-277: Theta update from the all-reduced sums.  Mutates and returns theta.
     rcond follows the reference's version test, which yields -1 on NumPy 2.x.
     n_reliable = x_infr.sum() selects the incomplete-data sigma (bsc.py:266-272: the OLD sigma
@@ -507,6 +526,8 @@ def bsc_update(theta, sums, N, D, H, to_learn=("W", "pi", "sigma"), n_reliable=N
                 theta["W"] = (theta["W"].T + (EPS_W * np.random.normal(0, 1, [H, D]))).T
     if "pi" in to_learn:
         pies_new = sums["pies"] / N
+        if background:  # bsc.py:259-260
+            pies_new[-1] = 1.0 - 1.1e-5
         theta["pi"] = pies_new.sum() / H
         theta["pies"] = pies_new
     if "sigma" in to_learn:
@@ -556,7 +577,8 @@ def bsc_step(theta, suff, Y, to_learn=("W", "pi", "sigma"), trace=None, reconstr
     sums["Fs"] = Fs
     if len(to_learn) > 0:
         incmpl = x_infr is not None and not x_infr.all()
-        theta = bsc_update(theta, sums, N, D, H, to_learn, n_reliable=x_infr.sum() if incmpl else None)
+        theta = bsc_update(theta, sums, N, D, H, to_learn, n_reliable=x_infr.sum() if incmpl else None,
+                           background=bool(suff["permanent"]["background"]))
     return F, nu / N, nsub / N, theta, sums
 
 
@@ -568,6 +590,12 @@ def bsc_free_energy_full(theta, suff, Y):
     sm = suff["sm"]
     assert sm is not None
     counters = bsc_precompute(theta, D, H)
+    if suff.get("permanent", {}).get("background", False):  # _models.py:389-390: every state of the H - 1 others with the unit on, no all-zero state
+        states = np.concatenate((sm, np.ones((sm.shape[0], 1), dtype=bool)), axis=1)
+        lpj = np.zeros((N, states.shape[0]))
+        for n in range(N):
+            lpj[n] = bsc_lpj(theta, states, Y[n], counters)
+        return theta["ljc"] + free_energy_sum(lpj) / N
     states = sm[1:, :].astype(bool)
     lpj = np.zeros((N, states.shape[0] + 1))
     for n in range(N):
@@ -806,7 +834,7 @@ def sssc_EM_accumulate(theta, suff, Y, use_storage=True, trace=None,
     return acc
 
 
-def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Psi")):
+def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Psi"), background=False):
     """sssc.py:687-770: Theta update from the all-reduced sums, including the reference's
     element-wise Psi product and dead '+eps' statement and the sigma2 formula
     built from first moments and the *new* W (Q4).  Mutates and returns theta."""
@@ -824,6 +852,8 @@ def sssc_update(theta, acc, N, D, H, to_learn=("W", "pies", "mus", "sigma2", "Ps
         pies = acc["xpt_s"] / N
         pies[pies <= EPS_PIES] = EPS_PIES
         pies[pies >= (1 - EPS_PIES)] = 1 - EPS_PIES
+        if background:  # sssc.py:718-719
+            pies[H - 1] = 1.0 - 1.1e-5
         theta["pies"] = pies
     if "mus" in to_learn:
         theta["mus"] = acc["xpt_sz"] * 1.0 / (acc["xpt_s"] + F64_EPS)
@@ -856,7 +886,7 @@ def sssc_step(theta, suff, Y, use_storage=True, to_learn=("W", "pies", "mus", "s
     acc = sssc_EM_accumulate(theta, suff, Y, use_storage, trace, to_learn, reconstruct_x=reconstruct_x,
                              x_infr=x_infr, precision=precision)
     ljc = theta["ljc"]
-    theta = sssc_update(theta, acc, N, D, H, to_learn)
+    theta = sssc_update(theta, acc, N, D, H, to_learn, background=bool(suff["permanent"]["background"]))
     F = ljc + acc["Fs"] / N
     return F, acc["n_uniq"] / N, acc["n_sub"] / N, theta, acc
 
@@ -867,6 +897,13 @@ def sssc_free_energy_full(theta, suff, Y):
     sm = suff["sm"]
     assert sm is not None
     counters = sssc_precompute(theta, D)
+    if suff.get("permanent", {}).get("background", False):
+        states = np.concatenate((sm, np.ones((sm.shape[0], 1), dtype=bool)), axis=1)
+        lpj = np.zeros((N, states.shape[0]))
+        cache = {}
+        for n in range(N):
+            lpj[n] = sssc_lpj(theta, states, Y[n], counters, cache)
+        return theta["ljc"] + free_energy_sum(lpj) / N
     states = sm[1:, :].astype(bool)
     lpj = np.zeros((N, states.shape[0] + 1))
     cache = {}

@@ -150,6 +150,7 @@ def make_step_fixture(name, algo, D, H, S, N, seed, n_steps=2, data="randn", ea=
         "ea_bitflip_prob": np.float64(np.nan if bitflip_prob is None else bitflip_prob),
         "ea_Mprime": np.int64(suff["Mprime"]), "use_storage": np.bool_(use_storage),
         "precision32": np.bool_(np.dtype(precision) == np.float32),
+        "background": np.bool_(bool(permanent) and bool(permanent["background"])),
     }
     out.update(run_steps(model, keys, theta, suff, my_data, n_steps, seed0=1000 + seed))
     path = os.path.join(HERE, "step_%s.npz" % name)
@@ -452,6 +453,61 @@ def make_lpj_dense():
     Y = rng.normal(size=(2, D))
     lpj, suff = _operator_fixture(os.path.join(HERE, "lpj_sssc_dense.npz"), model, theta, sets, H, Y)
     print("dense-state fixture: k = %s, lpj in [%.1f, %.1f]" % ([len(x) for x in sets], lpj.min(), lpj.max()))
+
+
+PERM_BG = {"background": True, "allzero": False, "singletons": False}
+
+
+def make_background_fixtures():
+    """Round 4: the permanent background unit (latent H-1 on in every state: variational/utils.py:42-47,96-98,
+    eas.py:213-239, bsc.py:259, sssc.py:718) and exact E-steps (S == 2^H_, variational/utils.py:55,71-88) --
+    init_states outputs with their np.random stream, full steps, and the exact log-likelihood with a background unit."""
+    out = {}
+    cases = [("bg", 5, 8, 7, dict(PERM_BG), 0.25), ("exact", 3, 16, 4, None, None), ("exact_bg", 3, 16, 5, dict(PERM_BG), None),
+             ("exact_zero", 3, 16, 4, dict(PERM_ZERO), None), ("bg_zero_ignored", 4, 6, 9,
+                                                               {"background": True, "allzero": True, "singletons": False}, None)]
+    for nm, N, S, H, perm, p0 in cases:
+        np.random.seed(31)
+        suff = init_states(N, S, H, "fit", "randflip", 3, 2, 1, None, None, p0, perm)
+        out[nm + "_N"], out[nm + "_S"], out[nm + "_H"] = np.int64(N), np.int64(S), np.int64(H)
+        out[nm + "_p0"] = np.float64(np.nan if p0 is None else p0)
+        out[nm + "_perm"] = np.array([bool(perm and perm[k]) for k in ("background", "allzero", "singletons")])
+        out[nm + "_ss"] = suff["ss"].copy()
+        out[nm + "_lpj_shape"] = np.array(suff["lpj"].shape, dtype=np.int64)
+        out[nm + "_S_perm"] = np.int64(suff["S_perm"])
+        out[nm + "_incl_shape"] = np.array(suff["incl"].shape, dtype=np.int64)
+        out[nm + "_sm"] = suff["sm"].copy() if suff["sm"] is not None else np.zeros((0, 0), dtype=bool)
+        out[nm + "_next_random"] = np.float64(np.random.random())  # where the stream stands afterwards
+    # exact log-likelihood with a background unit (_models.py:389-390)
+    for algo in ("ebsc", "es3c"):
+        np.random.seed(12)
+        H, D, N, S = 7, 9, 20, 10
+        if algo == "ebsc":
+            model = BSC(D, H, S)
+            gen = {"W": 6.0 * np.random.randn(D, H), "pi": 2.0 / H, "sigma": 1.0}
+            keys = BSC_KEYS
+        else:
+            model = SSSC(D, H, S)
+            gen = {"W": 6.0 * np.random.randn(D, H), "pies": np.ones(H) * 2.0 / H, "sigma2": np.array(1.0),
+                   "mus": np.ones(H) * 0.3, "Psi": np.eye(H) * 1.0}
+            keys = SSSC_KEYS
+        Y = model.generate_data(gen, N)["y"]
+        gen = model.check_params(gen)
+        my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+        suff = init_states(N, S, H, "fit", "randflip", 5, 1, 1, permanent=dict(PERM_BG))
+        L = model.free_energy(my_data, dict(gen), suff, full=True)
+        out["full_" + algo + "_Y"] = Y
+        out["full_" + algo + "_L"] = np.float64(L)
+        out.update(theta_arrays("full_" + algo + "_", gen, keys))
+        print(algo, "L with background unit", L)
+    np.savez_compressed(os.path.join(HERE, "background.npz"), **out)
+    make_step_fixture("ebsc_bg", "ebsc", 20, 24, 12, 30, seed=81, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=dict(PERM_BG))
+    make_step_fixture("es3c_bg", "es3c", 20, 24, 12, 30, seed=82, n_steps=2, ea=("fit", "randflip", 4, 2, 1), permanent=dict(PERM_BG))
+    make_step_fixture("es3c_bg_cross", "es3c", 16, 12, 10, 24, seed=83, n_steps=2, ea=("fit", "cross_randflip", 4, 1, 2),
+                      permanent=dict(PERM_BG))
+    make_step_fixture("ebsc_exact", "ebsc", 12, 5, 32, 20, seed=84, n_steps=2, ea=("fit", "randflip", 4, 2, 1))
+    make_step_fixture("es3c_exact_bg", "es3c", 12, 6, 32, 20, seed=85, n_steps=2, ea=("fit", "randflip", 4, 2, 1),
+                      permanent=dict(PERM_BG))
 
 
 def make_vary_kn():
@@ -793,6 +849,9 @@ if __name__ == "__main__":
         make_lpj_indefinite()
         make_lpj_dense()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bg":  # round 4: permanent background unit, exact E-steps
+        make_background_fixtures()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "prec32":  # SSSC(precision=np.float32) (sssc.py:49), added in round 3
         make_step_fixture("es3c_f32", "es3c", 24, 72, 30, 40, seed=4, n_steps=2, precision=np.float32)
         sys.exit(0)
@@ -823,6 +882,7 @@ if __name__ == "__main__":
     make_lpj_singular_k3()
     make_lpj_indefinite()
     make_lpj_dense()
+    make_background_fixtures()
     make_learn_bars()
     for nm in sorted(SHAPES):
         a, D, H, S, N, seed, ea = SHAPES[nm][:7]

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm",
+                 "ebsc_bg", "es3c_bg", "es3c_bg_cross", "ebsc_exact", "es3c_exact_bg"]  # r4: background unit, exact E-steps
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +32,8 @@ def make_suff(g, ss):
     S_perm = int(g["S_perm"]) if "S_perm" in g else 0  # permanent all-zero state (variational/utils.py:39-54)
     return {
         "ss": ss.copy(), "lpj": np.empty((N, S + S_perm)), "S_perm": S_perm, "incl": np.zeros((S_perm, H), dtype=bool),
-        "permanent": {"background": False, "allzero": S_perm == 1, "singletons": False}, "sm": None,
+        "permanent": {"background": bool(g["background"]) if "background" in g else False, "allzero": S_perm == 1,
+                      "singletons": False}, "sm": None,
         "n_parents": int(g["ea_n_parents"]), "n_children": int(g["ea_n_children"]),
         "n_generations": int(g["ea_n_generations"]),
         "parent_selection": PARENT_SELECTION[str(g["ea_parent_selection"])],
@@ -206,6 +208,65 @@ def test_full_free_energy(engine):
         L = model.free_energy({"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}, theta, suff, full=True)
         np.testing.assert_allclose(L, float(g[algo + "_L"]), rtol=1e-11)
         assert suff["S_perm"] == 0 and not suff["permanent"]["allzero"]
+
+
+def test_full_free_energy_with_background_unit(engine):
+    """free_energy(full=True) with permanent["background"] (_models.py:389-390): every state of the other H - 1 latents
+    with the unit on, no all-zero state -- against the reference's value (tests/golden/background.npz)."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    g = load_golden("background.npz")
+    H, D, N, S = 7, 9, 20, 10
+    for algo, cls, keys in (("ebsc", BSC, BSC_KEYS), ("es3c", SSSC, SSSC_KEYS)):
+        Y = g["full_%s_Y" % algo]
+        theta = {k: np.array(g["full_%s_%s" % (algo, k)]) for k in keys}
+        for k in ("pi", "sigma", "sigma2"):
+            if k in theta:
+                theta[k] = np.float64(theta[k])
+        np.random.seed(0)
+        suff = init_states(N, S, H, "fit", "randflip", 5, 1, 1, permanent={"background": True, "allzero": False, "singletons": False})
+        assert suff["ss"][:, :, -1].all() and suff["S_perm"] == 0
+        model = cls(D, H, S, engine=engine)
+        L = model.free_energy({"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}, theta, suff, full=True)
+        np.testing.assert_allclose(L, float(g["full_%s_L" % algo]), rtol=1e-11)
+
+
+@pytest.mark.parametrize("algo,ea", [("ebsc", ("fit", "randflip", 5, 2, 1)), ("es3c", ("fit", "randflip", 5, 1, 1)),
+                                     ("es3c", ("rand", "sparseflip", 4, 2, 2)), ("ebsc", ("fit", "cross_randflip", 4, 1, 2))])
+def test_background_unit_on_the_device_path(engine, algo, ea):
+    """rng="device" + device M-step with the permanent background unit: the device operators (fast randflip kernel and
+    the general kernel) never touch the last latent -- it stays on in every state of K^n over ten EM steps --, the other
+    latents keep moving (new states are accepted), and the unit's prior sits at 1 - 1.1e-5 after every update
+    (bsc.py:259-261: there through pi = mean(pies_new); sssc.py:718-719)."""
+    from evo_amd.models import BSC, SSSC
+    from evo_amd.variational import init_states
+    rng = np.random.RandomState(6)
+    D, H, S, N = 20, 70, 16, 300  # H = 70: the unit sits in the second 64-bit word of a state
+    W0 = rng.normal(size=(D, H))
+    Y = (rng.random_sample((N, H)) < 2.0 / H).astype(float) @ W0.T + W0[:, -1] + 0.3 * rng.normal(size=(N, D))
+    my_data = {"y": Y, "x_infr": np.ones_like(Y, dtype=bool)}
+    perm = {"background": True, "allzero": False, "singletons": False}
+    np.random.seed(2)
+    cls = BSC if algo == "ebsc" else SSSC
+    model = cls(D, H, S, rng="device", sync_host=True, engine=engine, seed=4, device_mstep=True)
+    theta = model.check_params(model.standard_init(my_data))
+    suff = init_states(N, S, H, ea[0], ea[1], ea[2], ea[3], ea[4], bitflip_prob=0.05, permanent=perm)
+    moved = 0.0
+    try:
+        for _ in range(10):
+            before = suff["ss"].copy()
+            F, nu, nsub, theta = model.step(theta, suff, my_data)
+            assert np.isfinite(F)
+            assert suff["ss"][:, :, -1].all(), "the background unit was switched off"
+            moved += float((before != suff["ss"]).any(axis=2).mean())
+            if algo == "es3c":
+                assert abs(float(theta["pies"][-1]) - (1.0 - 1.1e-5)) < 1e-15
+        assert moved > 0.05  # the other latents are being explored
+        if algo == "ebsc":
+            assert float(theta["pi"]) > 1.0 / H  # the pinned unit alone contributes (1 - 1.1e-5) / H
+    finally:
+        engine.set_option("background_unit", 0)
+        engine._bg_unit = False
 
 
 def test_per_datapoint_operator(engine):
@@ -438,7 +499,8 @@ def test_round4_launch_folding_options(engine, algo, lazy):
         np.testing.assert_allclose(out[0][1][k], out[1][1][k], rtol=1e-7, atol=1e-10, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense", "ebsc_perm", "es3c_perm"])
+@pytest.mark.parametrize("name", ["ebsc_mid", "es3c_mid", "es3c_bars", "ebsc_dense", "ebsc_perm", "es3c_perm", "ebsc_bg",
+                                  "es3c_bg", "es3c_exact_bg"])
 def test_device_mstep_matches_host(engine, name):
     """device_mstep=True: the Theta update, clamps and precompute run on the GPU (Gauss-Jordan solves
     instead of LAPACK).  Same inputs as the host path => Theta within 1e-8, F and K^n identical

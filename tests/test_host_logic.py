@@ -58,10 +58,13 @@ def fake_eval(states):
 
 @pytest.mark.parametrize("mutation,parent,n_par,n_child,n_gen,S_perm", [
     ("randflip", "fit", 5, 1, 1, 0), ("randflip", "fit", 4, 2, 3, 0), ("randflip", "rand", 4, 2, 3, 1),
-    ("sparseflip", "fit", 4, 2, 2, 0), ("cross_randflip", "fit", 4, 1, 2, 1), ("cross", "rand", 3, 1, 2, 0)])
+    ("sparseflip", "fit", 4, 2, 2, 0), ("cross_randflip", "fit", 4, 1, 2, 1), ("cross", "rand", 3, 1, 2, 0),
+    ("randflip", "fit", 4, 2, 2, -1), ("sparseflip", "rand", 4, 2, 2, -1), ("cross_sparseflip", "fit", 4, 1, 2, -1)])
 def test_evolve_states_matches_oracle(mutation, parent, n_par, n_child, n_gen, S_perm):
+    """(S_perm = -1: the permanent background unit -- no permanent all-zero state, the last latent on and never mutated)"""
     H, S = 12, 10
-    permanent = {"background": False, "allzero": bool(S_perm), "singletons": False}
+    permanent = {"background": S_perm < 0, "allzero": S_perm > 0, "singletons": False}
+    S_perm = max(S_perm, 0)
     np.random.seed(5)
     suff = vutils.init_states(6, S, H, parent, mutation, n_par, n_child, n_gen, bitflip_prob=0.1, permanent=permanent)
     np.random.seed(5)
@@ -79,6 +82,8 @@ def test_evolve_states_matches_oracle(mutation, parent, n_par, n_child, n_gen, S
         suff["this_states"], suff["this_lpj"] = st, lpj
         got_s, got_l = eas.evolve_states(suff, {"piH": 2.5}, fake_eval)
         assert np.array_equal(got_s, want_s) and np.array_equal(got_l, want_l)
+        if permanent["background"]:
+            assert st[:, -1].all() and got_s[:, -1].all()
         if n_gen == 1:
             np.random.seed(100 + n)
             first = eas.first_generation_candidates(st, lpj, suff, 2.5)
@@ -510,3 +515,20 @@ def test_datalog_routes_like_the_reference(tmp_path, capsys):
         with tables.open_file(str(tmp_path / "training.h5")) as h5:
             np.testing.assert_array_equal(h5.root.F[:], [-10.0, -9.0, -8.0])
             assert h5.root.W.shape == (3, 2, 3)
+
+
+def test_init_states_background_and_exact_against_reference():
+    """Round 4: the host mirror of init_states with the permanent background unit and with exact E-steps against the
+    reference's outputs (tests/golden/background.npz): K^n, shapes, state table, and where np.random stands afterwards."""
+    g = load_golden("background.npz")
+    for nm in ("bg", "exact", "exact_bg", "exact_zero", "bg_zero_ignored"):
+        N, S, H = int(g[nm + "_N"]), int(g[nm + "_S"]), int(g[nm + "_H"])
+        p0 = float(g[nm + "_p0"])
+        perm = dict(zip(("background", "allzero", "singletons"), (bool(v) for v in g[nm + "_perm"])))
+        np.random.seed(31)
+        suff = vutils.init_states(N, S, H, "fit", "randflip", 3, 2, 1, None, None, None if np.isnan(p0) else p0, perm)
+        assert np.array_equal(suff["ss"], g[nm + "_ss"]), nm
+        assert list(suff["lpj"].shape) == list(g[nm + "_lpj_shape"]), nm
+        assert suff["S_perm"] == int(g[nm + "_S_perm"]) and list(suff["incl"].shape) == list(g[nm + "_incl_shape"]), nm
+        assert np.array_equal(suff["sm"], g[nm + "_sm"]), nm
+        assert np.random.random() == float(g[nm + "_next_random"]), nm

@@ -9,7 +9,8 @@ from conftest import load_golden, unpack_bits
 from oracle import evo_oracle as orc
 
 STEP_FIXTURES = ["ebsc_bars", "es3c_bars", "ebsc_mid", "es3c_mid", "es3c_dense", "ebsc_dense",
-                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm", "es3c_f32"]
+                 "ebsc_sparseflip", "es3c_cross", "ebsc_gen2", "ebsc_perm", "es3c_perm", "es3c_f32",
+                 "ebsc_bg", "es3c_bg", "es3c_bg_cross", "ebsc_exact", "es3c_exact_bg"]  # r4: background unit, exact E-steps
 BSC_KEYS = ("W", "pi", "sigma")
 SSSC_KEYS = ("W", "pies", "mus", "Psi", "sigma2")
 
@@ -20,7 +21,8 @@ def suff_from_fixture(g, ss_bool):
     S_perm = int(g["S_perm"]) if "S_perm" in g else 0  # permanent all-zero state (variational/utils.py:39-54)
     return {
         "ss": ss_bool.copy(), "lpj": np.empty((N, S + S_perm)), "S_perm": S_perm, "incl": np.zeros((S_perm, H), dtype=bool),
-        "permanent": {"background": False, "allzero": S_perm == 1, "singletons": False}, "sm": None,
+        "permanent": {"background": bool(g["background"]) if "background" in g else False, "allzero": S_perm == 1,
+                      "singletons": False}, "sm": None,
         "n_parents": int(g["ea_n_parents"]), "n_children": int(g["ea_n_children"]),
         "n_generations": int(g["ea_n_generations"]),
         "parent_selection": orc.PARENT_SELECTION[str(g["ea_parent_selection"])],
@@ -369,3 +371,43 @@ def test_missing_data_replay_es3c():
         np.testing.assert_allclose(acc["y_reconstructed"], g["t%d_y_reconstructed" % t], rtol=1e-10, atol=1e-11)
         for k in SSSC_KEYS:
             np.testing.assert_allclose(theta[k], g["t%d_out_%s" % (t, k)], rtol=1e-8, atol=1e-10, err_msg=k)
+
+
+def test_init_states_background_and_exact():
+    """Round 4: init_states with the permanent background unit and with exact E-steps (S == 2^H_) against the
+    reference's own outputs -- K^n, shapes, the state table and where np.random stands afterwards
+    (variational/utils.py:42-47, 55, 71-98, 140-141)."""
+    g = load_golden("background.npz")
+    for nm in ("bg", "exact", "exact_bg", "exact_zero", "bg_zero_ignored"):
+        N, S, H = int(g[nm + "_N"]), int(g[nm + "_S"]), int(g[nm + "_H"])
+        p0 = float(g[nm + "_p0"])
+        perm = dict(zip(("background", "allzero", "singletons"), (bool(v) for v in g[nm + "_perm"])))
+        np.random.seed(31)
+        suff = orc.init_states(N, S, H, "fit", "randflip", 3, 2, 1, None, None, None if np.isnan(p0) else p0, perm)
+        assert np.array_equal(suff["ss"], g[nm + "_ss"]), nm
+        assert list(suff["lpj"].shape) == list(g[nm + "_lpj_shape"]), nm
+        assert suff["S_perm"] == int(g[nm + "_S_perm"]) and list(suff["incl"].shape) == list(g[nm + "_incl_shape"]), nm
+        assert np.array_equal(suff["sm"], g[nm + "_sm"]), nm
+        assert np.random.random() == float(g[nm + "_next_random"]), nm
+        if perm["background"]:
+            assert suff["ss"][:, :, -1].all()
+
+
+@pytest.mark.parametrize("algo", ["ebsc", "es3c"])
+def test_full_free_energy_background(algo):
+    g = load_golden("background.npz")
+    keys = BSC_KEYS if algo == "ebsc" else SSSC_KEYS
+    theta = {k: np.array(g["full_%s_%s" % (algo, k)]) for k in keys}
+    for k in ("pi", "sigma", "sigma2"):
+        if k in theta:
+            theta[k] = np.float64(theta[k])
+    Y = g["full_%s_Y" % algo]
+    H = theta["W"].shape[1]
+    suff = {"sm": orc.all_states_matrix(H - 1), "permanent": {"background": True, "allzero": False, "singletons": False}}
+    if algo == "ebsc":
+        theta = orc.check_params(theta, orc.BSC_POLICY)
+        L = orc.bsc_free_energy_full(theta, suff, Y)
+    else:
+        theta = orc.check_params(theta, orc.SSSC_POLICY)
+        L = orc.sssc_free_energy_full(theta, suff, Y)
+    np.testing.assert_allclose(L, float(g["full_%s_L" % algo]), rtol=1e-12)
