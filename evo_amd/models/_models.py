@@ -232,8 +232,19 @@ class Model:
         y_reconstructed and K^n again.  Needed after IN-PLACE edits of those arrays (the reference re-reads
         my_data every step; here an unchanged array object is taken to hold unchanged data)."""
         self._y_token = self._x_infr_token = self._yrec_token = None
+        self._xi_all_token = None
         self._resident = False
         self._dev_theta = None
+
+    def _complete(self, my_data):
+        """my_data["x_infr"].all(), scanned ONCE per array object (25 M flags at the north-star shape: half a millisecond of
+        host time per EM step where the reference's own step re-reads them -- on the critical path between two
+        iterations); in-place edits need invalidate(), like everything else that is resident."""
+        xi = my_data["x_infr"]
+        tok = getattr(self, "_xi_all_token", None)
+        if tok is None or tok[0] is not xi:
+            self._xi_all_token = (xi, bool(xi.all()))
+        return self._xi_all_token[1]
 
     @staticmethod
     def _same_objects(token, *objs):
@@ -257,7 +268,7 @@ class Model:
         xi_objs = (xi, my_data.get("x"))
         new_masks = not self._same_objects(self._x_infr_token, *xi_objs)
         if new_masks:  # checked once per array object, like the Y upload below
-            self._incomplete = not xi.all()
+            self._incomplete = not self._complete(my_data)
         N, D = Y.shape
         assert D == self.D
         S_perm = int(my_suff_stat["S_perm"])

@@ -50,7 +50,7 @@ class BSC(Model):
         model_params["pre1"] = -1.0 / 2.0 / sigma / sigma
         model_params["pil_bar"] = np.log(pi / (1.0 - pi))
         xi = my_data["x_infr"]
-        if xi.all():
+        if self._complete(my_data):
             model_params["ljc"] = self.H * np.log(1.0 - pi) - self.D / 2 * np.log(2 * np.pi * sigma * sigma)
             self._n_reliable = None
         else:  # bsc.py:113-118: the Gaussian normaliser counts the reliable entries

@@ -126,7 +126,7 @@ class SSSC(Model):
         model_params["ljc"] = ljc - 0.5 * (D * np.log(s2).astype(self.dtype_precision))
         xi = my_data["x_infr"]
         self._n_reliable = None
-        if not xi.all():  # sssc.py:352-357: the Gaussian normaliser counts the reliable entries
+        if not self._complete(my_data):  # sssc.py:352-357: the Gaussian normaliser counts the reliable entries
             N = self.comm.allreduce(xi.shape[0])
             self._n_total = N
             self._n_reliable = self.comm.allreduce(int(xi.sum()))
@@ -165,7 +165,7 @@ class SSSC(Model):
     def step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """check_params -> fused EM_step (sssc.py:407-417)."""
         if self.device_mstep:
-            if not my_data["x_infr"].all() and not do_reconstruction:
+            if not self._complete(my_data) and not do_reconstruction:
                 raise ValueError("ES3C on incomplete data needs do_reconstruction=True in every step: the reference's "
                                  "Wp accumulation reads the reconstructed row (sssc.py:630-633)")
             return self._step_device(model_params, my_suff_stat, my_data, do_reconstruction)
@@ -238,7 +238,7 @@ class SSSC(Model):
     def EM_step(self, model_params, my_suff_stat, my_data, do_reconstruction=False):
         """Fused E- and M-step (sssc.py:419-813).  Returns (F, S_nunique, S_sub, Theta_new); F uses
         the ljc of the Theta the E-step ran with (sssc.py:472,780)."""
-        if not my_data["x_infr"].all() and not do_reconstruction:
+        if not self._complete(my_data) and not do_reconstruction:
             raise ValueError("ES3C on incomplete data needs do_reconstruction=True in every step: the reference's "
                              "Wp accumulation reads the reconstructed row (sssc.py:630-633)")
         F, S_nunique, S_sub = self.E_step(model_params, my_suff_stat, my_data, _keep_acc=True,
